@@ -1,0 +1,143 @@
+"""The oracle (oracle/mod16_oracle.py) against golden vectors produced by the
+reference itself (tests/golden/make_golden.py). Bit-exact: the oracle keeps the
+reference's operation order, so equality is required, not closeness."""
+import numpy as np
+import pytest
+
+from oracle import mod16_oracle as oracle
+
+SEP = ('canopy_day', 'soil_day', 'trans_day',
+       'canopy_night', 'soil_night', 'trans_night')
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, (a.shape, b.shape, a.dtype, b.dtype)
+    assert np.array_equal(a, b, equal_nan=True), np.nanmax(np.abs(a - b))
+
+
+def params_of(vec):
+    return dict(zip(oracle.PARAM_NAMES, vec))
+
+
+def check_sep(res, f):
+    flat = list(res[0]) + list(res[1])
+    for name, got in zip(SEP, flat):
+        same(got, f[name])
+
+
+def test_f1_scalar_set(golden):
+    f = golden('f1_tests_scalars')
+    p = params_of(f['params'])
+    drv = list(f['drivers'])
+    day, night = oracle.evapotranspiration(p, *drv)
+    same(day, f['day'])
+    same(night, f['night'])
+    check_sep(oracle.evapotranspiration(p, *drv, separate=True), f)
+    # full-precision known answers recorded in SURVEY.md section 8c
+    assert float(day) == 9.872769855543006e-06
+    assert float(night) == 6.802468709788471e-06
+
+
+def test_f1_component_known_answers(golden):
+    f = golden('f1_tests_scalars')
+    p = params_of(f['params'])
+    temp_k, vpd, lai, fpar = 273.15 + 30, 1000, 1.5, 0.5
+    pressure, tmin, rad = 100e3, 285, 5000
+    r_corr = (101300 / pressure) * (temp_k / 293.15)**1.75
+    same(oracle.evaporation_soil(p, pressure, temp_k, vpd, fpar, rad, r_corr),
+         f['kat_evaporation_soil'])
+    same(oracle.transpiration(p, pressure, temp_k, vpd, lai, fpar, rad, tmin,
+                              r_corr, daytime=True), f['kat_transpiration_day'])
+    same(oracle.transpiration(p, pressure, temp_k, vpd, lai, fpar, rad, tmin,
+                              r_corr, daytime=False), f['kat_transpiration_night'])
+    same(oracle.evaporation_wet_canopy(p, pressure, temp_k, vpd, lai, fpar, rad),
+         f['kat_wet_canopy'])
+
+
+def test_f2_verify_three_pixels(golden):
+    f = golden('f2_verify_3pixel')
+    p = params_of(f['params'])
+    drv = [f['drv_' + k] for k in oracle.DRIVER_NAMES]
+    check_sep(oracle.evapotranspiration(p, *drv, separate=True), f)
+    # SURVEY.md section 8c, F2 day transpiration
+    np.testing.assert_array_equal(
+        f['trans_day'],
+        [8.5064801746365699e-06, 1.4835055809704346e-05, 1.8276591240061832e-05])
+
+
+@pytest.mark.parametrize('name,dtype', [('f3_random64_f64', np.float64),
+                                        ('f5_random64_f32', np.float32)])
+def test_random_multiclass_raster(golden, name, dtype):
+    f = golden(name)
+    bplut = {k: f['table'][:, j].astype(dtype)
+             for j, k in enumerate(oracle.PARAM_NAMES)}
+    drv = list(f['drivers'])
+    assert drv[0].dtype == dtype
+    day, night = oracle.evapotranspiration_raster(bplut, f['cls'], *drv)
+    same(day, f['day'])
+    same(night, f['night'])
+    check_sep(oracle.evapotranspiration_raster(
+        bplut, f['cls'], *drv, separate=True), f)
+    # the fixture exercises every branch the raster path has
+    assert np.isnan(f['day']).any() and (f['canopy_day'] > 0).any()
+    assert (f['canopy_day'] == 0).any() and (f['trans_day'] == 0).any()
+
+
+def test_f4_edge_cases(golden):
+    f = golden('f4_edge_cases')
+    p = params_of(f['params'])
+    drv = list(f['drivers'])
+    day, night = oracle.evapotranspiration(p, *drv)
+    same(day, f['day'])
+    same(night, f['night'])
+    check_sep(oracle.evapotranspiration(p, *drv, separate=True), f)
+    # invalid-but-in-range classes 0 and 11 -> NaN
+    bplut = {k: f['cls_case_table'][:, j]
+             for j, k in enumerate(oracle.PARAM_NAMES)}
+    day, night = oracle.evapotranspiration_raster(
+        bplut, f['cls_case_cls'], *list(f['cls_case_drivers']))
+    same(day, f['cls_case_day'])
+    same(night, f['cls_case_night'])
+    assert np.isnan(day[1]) and np.isnan(day[2]) and np.isfinite(day[0])
+
+
+def test_class_out_of_range_raises(golden):
+    f = golden('f4_edge_cases')
+    bplut = {k: f['cls_case_table'][:, j]
+             for j, k in enumerate(oracle.PARAM_NAMES)}
+    with pytest.raises(IndexError):
+        oracle.gather_params(bplut, np.array([1, 13], np.uint8))
+
+
+def test_f6_submethods(golden):
+    f = golden('f6_submethods')
+    p = params_of(f['params'])
+    (lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_a, tmin, vpd_d, vpd_n, pa,
+     fpar, lai) = list(f['drivers'])
+    same(oracle.svp(t_d), f['svp'])
+    same(oracle.svp_slope(t_d), f['svp_slope'])
+    same(oracle.latent_heat_vaporization(t_d), f['lhv'])
+    same(oracle.psychrometric_constant(pa, t_d), f['psychrometric_constant'])
+    rh = oracle.rhumidity(t_d, vpd_d)
+    same(rh, f['rhumidity'])
+    same(oracle.air_density(t_d, pa, rh), f['air_density'])
+    g = oracle.soil_heat_flux(p, sw_d * (1 - alb) + lw_d, lw_n, t_d, t_n, t_a)
+    same(g[0], f['soil_heat_flux_day'])
+    same(g[1], f['soil_heat_flux_night'])
+    rs = oracle.radiation_soil(p, lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_a, fpar)
+    same(rs[0], f['radiation_soil_day'])
+    same(rs[1], f['radiation_soil_night'])
+    same(oracle.surface_conductance(p, tmin, vpd_d), f['surface_conductance'])
+    rad_c = f['rad_canopy']
+    same(oracle.evaporation_wet_canopy(p, pa, t_d, vpd_d, lai, fpar, rad_c),
+         f['evaporation_wet_canopy'])
+    same(oracle.evaporation_soil(p, pa, t_d, vpd_d, fpar, rs[0]),
+         f['evaporation_soil'])
+    sat, unsat = oracle.potential_soil_evaporation(p, pa, t_d, vpd_d, fpar, rs[0])
+    same(sat, f['potential_soil_sat'])
+    same(unsat, f['potential_soil_unsat'])
+    same(oracle.transpiration(p, pa, t_d, vpd_d, lai, fpar, rad_c, tmin),
+         f['transpiration_day'])
+    same(oracle.transpiration(p, pa, t_n, vpd_n, lai, fpar, fpar * lw_n, tmin,
+                              daytime=False), f['transpiration_night'])
