@@ -1,0 +1,190 @@
+/*
+ * mod16_hip.h -- C ABI of libmod16hip.so, the MI355X (gfx950) engine behind the
+ * MOD16 forward run.
+ *
+ * The reference (arthur-e/MOD16 v1.2.0) is pure Python/numpy and has no FFI of
+ * its own; the boundary this library replaces is the body of
+ *     MOD16.evapotranspiration()            reference mod16/__init__.py:675-793
+ * and the sub-methods it calls (:795-1258, :1261-1397), plus the per-pixel
+ * parameter gather `bplut[key][pft_map]` that precedes it for multi-class
+ * rasters (reference mod16/utils.py:81-117 + forward-run notebook cell 32).
+ * The Python class `mod16_amd.MOD16` binds these entry points with ctypes
+ * (see INTEGRATION.md for the stub a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the ABI; every call returns
+ *     MOD16_OK (0) or a negative MOD16_ERR_* code; mod16_last_error() has text;
+ *   - the library never frees or retains caller memory;
+ *   - `where` says whether the data pointers are HOST (pageable or pinned
+ *     memory; the call stages tiles through the GPU and is synchronous) or
+ *     DEVICE (zero-copy, asynchronous on `stream`, a hipStream_t or NULL);
+ *   - one ctx per host thread and GPU; a ctx is not thread-safe.
+ */
+#ifndef MOD16_HIP_H
+#define MOD16_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOD16_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define MOD16_API __attribute__((visibility("default")))
+#else
+#define MOD16_API
+#endif
+
+/* MOD16.evapotranspiration() argument order, mod16/__init__.py:675-682 */
+#define MOD16_N_DRIVERS 14
+enum mod16_driver {
+    MOD16_LW_NET_DAY = 0, MOD16_LW_NET_NIGHT, MOD16_SW_RAD_DAY,
+    MOD16_SW_RAD_NIGHT, MOD16_SW_ALBEDO, MOD16_TEMP_DAY, MOD16_TEMP_NIGHT,
+    MOD16_TEMP_ANNUAL, MOD16_TMIN, MOD16_VPD_DAY, MOD16_VPD_NIGHT,
+    MOD16_PRESSURE, MOD16_FPAR, MOD16_LAI
+};
+
+/* MOD16.required_parameters order, mod16/__init__.py:152-155 */
+#define MOD16_N_PARAMS 11
+enum mod16_param {
+    MOD16_TMIN_CLOSE = 0, MOD16_TMIN_OPEN, MOD16_VPD_OPEN, MOD16_VPD_CLOSE,
+    MOD16_GL_SH, MOD16_GL_WV, MOD16_G_CUTICULAR, MOD16_CSL, MOD16_RBL_MIN,
+    MOD16_RBL_MAX, MOD16_BETA
+};
+
+/* restore_bplut() arrays have 13 entries indexed by PFT code (utils.py:104) */
+#define MOD16_N_CLASSES 13
+
+/* order of the optional component outputs (`separate=True`, :789-790) */
+#define MOD16_N_COMPONENTS 6
+enum mod16_component {
+    MOD16_CANOPY_DAY = 0, MOD16_SOIL_DAY, MOD16_TRANS_DAY,
+    MOD16_CANOPY_NIGHT, MOD16_SOIL_NIGHT, MOD16_TRANS_NIGHT
+};
+
+enum mod16_status {
+    MOD16_OK = 0,
+    MOD16_ERR_ARG = -1,          /* NULL / misaligned / inconsistent argument */
+    MOD16_ERR_HIP = -2,          /* a HIP runtime call failed                 */
+    MOD16_ERR_CLASS_RANGE = -3,  /* a class code >= 13 (numpy: IndexError)    */
+    MOD16_ERR_NOMEM = -4,
+    MOD16_ERR_NO_DEVICE = -5,    /* no usable gfx950 device                   */
+    MOD16_ERR_NO_BPLUT = -6      /* class raster given before a BPLUT was set */
+};
+
+enum mod16_where { MOD16_HOST = 0, MOD16_DEVICE = 1 };
+
+/* flags of mod16_et_* */
+#define MOD16_MATH_FAST   0u  /* strength-reduced arithmetic (default)          */
+#define MOD16_MATH_EXACT  1u  /* reference operation order, IEEE divide/pow     */
+
+typedef struct mod16_ctx mod16_ctx;
+
+MOD16_API int mod16_version(void);
+MOD16_API const char* mod16_strerror(int status);
+/* text of the last failure on this ctx ("" if none); valid until next call */
+MOD16_API const char* mod16_last_error(const mod16_ctx* ctx);
+
+MOD16_API int mod16_device_count(int* count);
+MOD16_API int mod16_create(int device, mod16_ctx** out);
+MOD16_API int mod16_destroy(mod16_ctx* ctx);
+
+/*
+ * Biome-properties look-up table: `lut` is a host array [13][11] of float64,
+ * row = PFT code, column = enum mod16_param; rows of invalid classes hold NaN
+ * (what restore_bplut() leaves at 0 and 11, utils.py:104-116). Replaces the
+ * reference's per-pixel gather `params_dict[key][pft_map]`.
+ */
+MOD16_API int mod16_set_bplut_f64(mod16_ctx* ctx, const double* lut);
+
+/*
+ * The forward run over n pixels: replaces MOD16.evapotranspiration()
+ * (mod16/__init__.py:675-793) and everything below it.
+ *
+ *   cls      uint8 class raster [n], or NULL. With a class raster the
+ *            parameters come from the BPLUT (set beforehand); a code >= 13
+ *            makes the call (HOST) or mod16_check_status() (DEVICE) return
+ *            MOD16_ERR_CLASS_RANGE and yields NaN for that pixel.
+ *   drivers  the 14 driver arrays, order enum mod16_driver.
+ *   dstride  element stride of each driver: 1 = dense array of n elements,
+ *            0 = one value broadcast to every pixel (numpy scalar).
+ *   params   used only when cls == NULL: the 11 parameters, each dense
+ *            (pstride 1, per-pixel `params_dict[key][pft_map]` arrays) or a
+ *            broadcast scalar (pstride 0, the single-PFT MOD16(params) case).
+ *   out_day, out_night   [n] totals in kg m-2 s-1 (:792); may be NULL if
+ *            only components are wanted.
+ *   out_sep  NULL, or 6 arrays [n] in enum mod16_component order (any entry
+ *            may be NULL) -- the `separate=True` outputs (:790).
+ *   flags    MOD16_MATH_*.
+ */
+MOD16_API int mod16_et_f64(mod16_ctx* ctx, const uint8_t* cls,
+                 const double* const* drivers, const int64_t* dstride,
+                 const double* const* params, const int64_t* pstride,
+                 int64_t n, double* out_day, double* out_night,
+                 double* const* out_sep, unsigned flags, int where,
+                 void* stream);
+
+/* float32 variant: same meaning, float32 data and float32 arithmetic */
+MOD16_API int mod16_et_f32(mod16_ctx* ctx, const uint8_t* cls,
+                 const float* const* drivers, const int64_t* dstride,
+                 const float* const* params, const int64_t* pstride,
+                 int64_t n, float* out_day, float* out_night,
+                 float* const* out_sep, unsigned flags, int where,
+                 void* stream);
+
+/*
+ * Waits for the ctx's outstanding work on `stream` and reports deferred
+ * errors of DEVICE-mode calls (MOD16_ERR_CLASS_RANGE, MOD16_ERR_HIP).
+ */
+MOD16_API int mod16_check_status(mod16_ctx* ctx, void* stream);
+
+/*
+ * Diagnostics of a (day, night) result pair [n] (device pointers): a
+ * deterministic two-level tree sum in fixed order. diag (host, 8 doubles) =
+ * { sum_day, sum_night, n_finite_day, n_finite_night, n_nan_day, n_nan_night,
+ *   max_day, max_night }, NaN pixels skipped as np.nansum would. Synchronous.
+ * ddiag (device, 8 doubles, may be NULL) receives the same vector
+ * asynchronously for an RCCL all-reduce without a host round trip; pass
+ * diag == NULL to stay asynchronous.
+ */
+MOD16_API int mod16_reduce_diag_f64(mod16_ctx* ctx, const double* day,
+                          const double* night, int64_t n, double* diag,
+                          double* ddiag, void* stream);
+MOD16_API int mod16_reduce_diag_f32(mod16_ctx* ctx, const float* day,
+                          const float* night, int64_t n, double* diag,
+                          double* ddiag, void* stream);
+
+/*
+ * On-device synthetic driver fields: fills the class
+ * raster and the 14 dense driver arrays (device pointers, n elements each)
+ * for global pixel indices [pixel_offset, pixel_offset + n) of time step
+ * `step` from a counter-based generator keyed on (seed, step, variable,
+ * pixel), so any tiling of a raster over any number of GPUs sees the same
+ * field. Asynchronous on `stream`.
+ */
+MOD16_API int mod16_synth_f64(mod16_ctx* ctx, uint64_t seed, int64_t step,
+                    int64_t pixel_offset, int64_t n, uint8_t* cls,
+                    double* const* drivers, void* stream);
+MOD16_API int mod16_synth_f32(mod16_ctx* ctx, uint64_t seed, int64_t step,
+                    int64_t pixel_offset, int64_t n, uint8_t* cls,
+                    float* const* drivers, void* stream);
+
+/*
+ * Timing aid for bench.py: runs `launches` back-to-back launches of the
+ * DEVICE-mode f64/f32 forward run on `stream`, bracketed by HIP events on
+ * that stream, and returns the mean milliseconds per launch in *ms.
+ * Arguments as mod16_et_f64 / mod16_et_f32 (is_f32 selects), where = DEVICE.
+ */
+MOD16_API int mod16_time_et(mod16_ctx* ctx, int is_f32, const uint8_t* cls,
+                  const void* const* drivers, const int64_t* dstride,
+                  const void* const* params, const int64_t* pstride,
+                  int64_t n, void* out_day, void* out_night,
+                  void* const* out_sep, unsigned flags, int launches,
+                  void* stream, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOD16_HIP_H */

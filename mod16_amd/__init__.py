@@ -1,0 +1,275 @@
+r'''
+MI355X-native MOD16 forward run.
+
+Drop-in for the forward-run surface of the reference package ``mod16``
+(arthur-e/MOD16 v1.2.0): the ``MOD16`` class (reference mod16/__init__.py:124),
+``MOD16.evapotranspiration()`` (:675-793), the BPLUT look-up
+(``mod16_amd.utils.restore_bplut``, ``mod16_amd.models.MOD16Collection61``)
+and the module constants keep their names, argument order, units and error
+behaviour. The per-pixel Penman-Monteith stack itself runs as one fused HIP
+kernel on gfx950 through ``libmod16hip.so`` (C ABI: ``include/mod16_hip.h``).
+There is no CPU fallback: without the library or without an MI355X the
+forward run raises.
+
+Two ways in:
+
+- ``MOD16(params).evapotranspiration(*drivers)`` -- numpy in, numpy out, as
+  the reference; ``params`` values may be scalars (one land-cover type) or
+  arrays broadcastable against the drivers (``params_dict[key][pft_map]``).
+- ``evapotranspiration_raster(bplut, cls, *drivers)`` -- multi-class rasters:
+  the BPLUT is held in LDS and indexed by the uint8 class raster in-kernel,
+  which replaces the reference idiom of gathering 11 per-pixel parameter
+  arrays first. ``mod16_amd.raster.RasterEngine`` is the device-resident
+  (zero-copy, asynchronous) form of the same call for large grids.
+'''
+
+__version__ = 'v1.2.0+mi355x.r1'
+
+import numpy as np
+
+from . import _lib
+
+# Module constants, same names and values as reference mod16/__init__.py:106-118
+PFT_VALID = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12)
+STEFAN_BOLTZMANN = 5.67e-8  # W m-2 K-4
+SPECIFIC_HEAT_CAPACITY_AIR = 1013  # J kg-1 K-1
+MOL_WEIGHT_WET_DRY_RATIO_AIR = 0.622
+TEMP_LAPSE_RATE = 0.0065  # -(deg K) m-1
+GRAV_ACCEL = 9.80665  # m s-2
+GAS_LAW_CONST = 8.3143  # m3 Pa (mol)-1 K-1
+AIR_MOL_WEIGHT = 28.9644e-3  # kg (mol)-1
+STD_TEMP_K = 288.15
+STD_PRESSURE_PASCALS = 101325.0
+AIR_PRESSURE_RATE = GRAV_ACCEL / (
+    TEMP_LAPSE_RATE * (GAS_LAW_CONST / AIR_MOL_WEIGHT))
+
+DRIVER_NAMES = (
+    'lw_net_day', 'lw_net_night', 'sw_rad_day', 'sw_rad_night', 'sw_albedo',
+    'temp_day', 'temp_night', 'temp_annual', 'tmin', 'vpd_day', 'vpd_night',
+    'pressure', 'fpar', 'lai')
+
+
+def _result_dtype(values):
+    '''float32 only if every array-like input is float32 (numpy's own rule
+    for the reference code); Python scalars are weak.'''
+    strong = [np.asarray(v).dtype for v in values
+              if isinstance(v, (np.ndarray, np.generic))]
+    if strong and np.result_type(*strong) == np.float32:
+        return np.dtype(np.float32)
+    return np.dtype(np.float64)
+
+
+def _marshal(values, shape, dtype):
+    '''-> (keepalive arrays, addresses, element strides) for the C ABI: a
+    size-1 input is passed as a broadcast scalar (stride 0), anything else is
+    made dense over ``shape`` (stride 1).'''
+    keep, ptrs, strides = [], [], []
+    for v in values:
+        a = np.asarray(v, dtype=dtype)
+        if a.size == 1:
+            a = np.ascontiguousarray(a.reshape(1))
+            strides.append(0)
+        else:
+            if a.shape != shape:
+                a = np.broadcast_to(a, shape)
+            a = np.ascontiguousarray(a)
+            strides.append(1)
+        keep.append(a)
+        ptrs.append(a.ctypes.data)
+    return keep, ptrs, strides
+
+
+def _forward(cls, drivers, params, separate, flags, device):
+    '''Shared host path of MOD16.evapotranspiration and
+    evapotranspiration_raster: marshal numpy inputs, run mod16_et_* in HOST
+    mode, shape the outputs as the reference does (mod16/__init__.py:789-793).
+    '''
+    ctx = _lib.context(device)
+    values = list(drivers) + (list(params) if params is not None else [])
+    dtype = _result_dtype(values)
+    shapes = [np.shape(v) for v in values]
+    if cls is not None:
+        cls = np.asarray(cls)
+        if cls.dtype != np.uint8:
+            if cls.size and (cls.min() < 0 or cls.max() > 255):
+                raise IndexError('class code outside [0, 255]')
+            cls = cls.astype(np.uint8)
+        shapes.append(cls.shape)
+    shape = np.broadcast_shapes(*shapes)
+    n = int(np.prod(shape, dtype=np.int64))
+    keep_d, dptr, dstride = _marshal(drivers, shape, dtype)
+    pptr = pstride = cptr = None
+    if cls is not None:
+        cls = np.ascontiguousarray(np.broadcast_to(cls, shape))
+        cptr = cls.ctypes.data
+    else:
+        keep_p, pptr, pstride = _marshal(params, shape, dtype)
+    if separate:
+        outs = [np.empty(shape, dtype) for _ in range(6)]
+        day = night = None
+        sep = [o.ctypes.data for o in outs]
+    else:
+        outs = [np.empty(shape, dtype) for _ in range(2)]
+        day, night = outs[0].ctypes.data, outs[1].ctypes.data
+        sep = None
+    if n:
+        ctx.et(dtype, cptr, dptr, dstride, pptr, pstride, n, day, night, sep,
+               flags=flags, where=_lib.HOST)
+    if not shape:      # all-scalar input: numpy scalars, as the reference
+        outs = [o[()] for o in outs]
+    if separate:
+        return (tuple(outs[0:3]), tuple(outs[3:6]))
+    return (outs[0], outs[1])
+
+
+class MOD16(object):
+    r'''
+    The MODIS MxD16 Evapotranspiration model on MI355X. Same construction as
+    the reference class (mod16/__init__.py:124-160); the required model
+    parameters are:
+
+    - `tmin_close`: Temperature at which stomata are almost completely
+        closed due to (minimum) temperature stress (deg C)
+    - `tmin_open`: Temperature at which stomata are completely open (deg C)
+    - `vpd_open`: The VPD at which stomata are completely open (Pa)
+    - `vpd_close`: The VPD at which stomata are almost completely closed (Pa)
+    - `gl_sh`: Leaf conductance to sensible heat per unit LAI (m s-1 LAI-1)
+    - `gl_wv`: Leaf conductance to evaporated water per unit LAI
+        (m s-1 LAI-1)
+    - `g_cuticular`: Leaf cuticular conductance (m s-1)
+    - `csl`: Mean potential stomatal conductance per unit leaf area (m s-1)
+    - `rbl_min`: Minimum atmospheric boundary layer resistance (s m-1)
+    - `rbl_max`: Maximum atmospheric boundary layer resistance (s m-1)
+    - `beta`: Factor in soil moisture constraint on potential soil
+        evaporation, i.e., (VPD / beta)
+
+    Parameters
+    ----------
+    params : dict
+        Dictionary of model parameters: scalars, or arrays broadcastable
+        against the driver arrays (per-pixel parameters)
+    device : int
+        (Extension) index of the GPU to run on (Default: 0)
+    '''
+    required_parameters = [
+        'tmin_close', 'tmin_open', 'vpd_open', 'vpd_close', 'gl_sh', 'gl_wv',
+        'g_cuticular', 'csl', 'rbl_min', 'rbl_max', 'beta'
+    ]
+
+    #: arithmetic of the fused kernel: _lib.MATH_FAST (default) or
+    #: _lib.MATH_EXACT (reference operation order, IEEE divide and pow)
+    math = _lib.MATH_FAST
+
+    def __init__(self, params, device=0):
+        self.params = params
+        self.device = device
+        for key in self.required_parameters:   # KeyError if one is missing
+            setattr(self, key, params[key])
+
+    def _param_values(self):
+        return [getattr(self, key) for key in self.required_parameters]
+
+    def evapotranspiration(
+            self, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
+            sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
+            vpd_night, pressure, fpar, lai, f_wet=None, separate=False):
+        r'''
+        Instantaneous evapotranspiration (ET) [kg m-2 s-1] for day and night,
+        the sum of wet-canopy evaporation, bare-soil evaporation and
+        transpiration: same arguments, semantics and return value as the
+        reference method (mod16/__init__.py:675-793), computed by the fused
+        gfx950 kernel.
+
+        Parameters
+        ----------
+        lw_net_day, lw_net_night : float or numpy.ndarray
+            Net downward long-wave radiation integrated over daylight /
+            night-time hours (J m-2 s-1)
+        sw_rad_day, sw_rad_night : float or numpy.ndarray
+            Down-welling short-wave radiation, day / night (J m-2 s-1)
+        sw_albedo : float or numpy.ndarray
+            Down-welling short-wave albedo
+        temp_day, temp_night : float or numpy.ndarray
+            Average temperature during daylight / night-time hours (deg K)
+        temp_annual : float or numpy.ndarray
+            Annual average daily temperature (deg K)
+        tmin : float or numpy.ndarray
+            Minimum daily temperature (deg K)
+        vpd_day, vpd_night : float or numpy.ndarray
+            Daytime / night-time mean vapor pressure deficit (Pa)
+        pressure : float or numpy.ndarray
+            Air pressure (Pa)
+        fpar : float or numpy.ndarray
+            Fraction of photosynthetically active radiation absorbed [0, 1]
+        lai : float or numpy.ndarray
+            Leaf area index
+        f_wet : float or numpy.ndarray
+            Accepted for interface compatibility and ignored, as in the
+            reference (it recomputes the wet fraction from VPD, :764)
+        separate : bool
+            True to return the components (canopy evaporation, soil
+            evaporation, transpiration) separately (Default: False)
+
+        Returns
+        -------
+        tuple
+            ``(day, night)``; with ``separate = True`` each of the two is a
+            3-tuple ``(canopy, soil, transpiration)``
+        '''
+        drivers = (
+            lw_net_day, lw_net_night, sw_rad_day, sw_rad_night, sw_albedo,
+            temp_day, temp_night, temp_annual, tmin, vpd_day, vpd_night,
+            pressure, fpar, lai)
+        return _forward(
+            None, drivers, self._param_values(), separate, self.math,
+            self.device)
+
+
+def evapotranspiration_raster(
+        bplut, cls, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
+        sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
+        vpd_night, pressure, fpar, lai, separate=False, beta=None,
+        math=_lib.MATH_FAST, device=0):
+    r'''
+    Forward run over a multi-class raster. Equivalent to the reference idiom
+    (forward-run notebook, cell 32)::
+
+        params = {k: bplut[k][cls] for k in MOD16.required_parameters}
+        MOD16(params).evapotranspiration(*drivers)
+
+    but the 11 per-pixel parameter arrays are never materialised: the BPLUT
+    sits in LDS and is indexed by the class raster inside the kernel.
+
+    Parameters
+    ----------
+    bplut : dict or numpy.ndarray
+        What ``restore_bplut`` returns (11 arrays of 13), or a (13, 11) table
+        in ``MOD16.required_parameters`` column order
+    cls : numpy.ndarray
+        Land-cover class (PFT code) raster, integers in [0, 12]. Codes that
+        are not PFTs (0, 11) give NaN, as NaN parameters do in the reference;
+        a code >= 13 raises IndexError, as the numpy gather would.
+    beta : float
+        (Optional) value for the ``beta`` column where the table has none
+    separate : bool
+        As in ``MOD16.evapotranspiration``
+
+    Returns
+    -------
+    tuple
+        As ``MOD16.evapotranspiration``
+    '''
+    from .utils import bplut_table
+    if isinstance(bplut, dict):
+        table = bplut_table(bplut, beta=beta)
+    else:
+        table = np.array(bplut, np.float64)
+        if beta is not None:
+            fill = np.isnan(table[:, 10]) & ~np.isnan(table[:, 0])
+            table[fill, 10] = beta
+    _lib.context(device).set_bplut(table)
+    drivers = (
+        lw_net_day, lw_net_night, sw_rad_day, sw_rad_night, sw_albedo,
+        temp_day, temp_night, temp_annual, tmin, vpd_day, vpd_night,
+        pressure, fpar, lai)
+    return _forward(cls, drivers, None, separate, math, device)

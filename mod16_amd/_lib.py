@@ -1,0 +1,191 @@
+'''
+ctypes binding of ``libmod16hip.so`` (C ABI: ``include/mod16_hip.h``).
+
+There is no CPU fallback: if the library is missing, or no MI355X is visible
+when a computation is requested, the call fails loudly.
+'''
+import ctypes as C
+import os
+
+import numpy as np
+
+N_DRIVERS = 14
+N_PARAMS = 11
+N_CLASSES = 13
+N_COMPONENTS = 6
+HOST, DEVICE = 0, 1
+MATH_FAST, MATH_EXACT = 0, 1
+
+OK = 0
+ERR_ARG, ERR_HIP, ERR_CLASS_RANGE, ERR_NOMEM, ERR_NO_DEVICE, ERR_NO_BPLUT = \
+    -1, -2, -3, -4, -5, -6
+
+LIB_NAME = 'libmod16hip.so'
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+
+class Mod16Error(RuntimeError):
+    '''A failed call into libmod16hip (anything but a class-range error).'''
+
+    def __init__(self, status, message):
+        super().__init__('libmod16hip: %s (status %d)' % (message, status))
+        self.status = status
+
+
+_PP = C.POINTER(C.c_void_p)
+_I64P = C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes); one entry per function declared in the header
+PROTOTYPES = {
+    'mod16_version': (C.c_int, []),
+    'mod16_strerror': (C.c_char_p, [C.c_int]),
+    'mod16_last_error': (C.c_char_p, [C.c_void_p]),
+    'mod16_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'mod16_create': (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    'mod16_destroy': (C.c_int, [C.c_void_p]),
+    'mod16_set_bplut_f64': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mod16_et_f64': (C.c_int, [
+        C.c_void_p, C.c_void_p, _PP, _I64P, _PP, _I64P, C.c_int64, C.c_void_p,
+        C.c_void_p, _PP, C.c_uint, C.c_int, C.c_void_p]),
+    'mod16_et_f32': (C.c_int, [
+        C.c_void_p, C.c_void_p, _PP, _I64P, _PP, _I64P, C.c_int64, C.c_void_p,
+        C.c_void_p, _PP, C.c_uint, C.c_int, C.c_void_p]),
+    'mod16_check_status': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mod16_reduce_diag_f64': (C.c_int, [
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+        C.c_void_p]),
+    'mod16_reduce_diag_f32': (C.c_int, [
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+        C.c_void_p]),
+    'mod16_synth_f64': (C.c_int, [
+        C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+        _PP, C.c_void_p]),
+    'mod16_synth_f32': (C.c_int, [
+        C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+        _PP, C.c_void_p]),
+    'mod16_time_et': (C.c_int, [
+        C.c_void_p, C.c_int, C.c_void_p, _PP, _I64P, _PP, _I64P, C.c_int64,
+        C.c_void_p, C.c_void_p, _PP, C.c_uint, C.c_int, C.c_void_p,
+        C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load():
+    '''Load libmod16hip.so (once) and declare its prototypes.'''
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            '%s is not built: run `python -c "import __graft_entry__ as g; '
+            'g.build()"` (or mod16_amd/csrc/build.py) at the repo root. '
+            'mod16_amd has no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mod16_version() != 1:
+        raise ImportError('libmod16hip ABI version %d, expected 1'
+                          % lib.mod16_version())
+    _lib = lib
+    return lib
+
+
+def device_count():
+    n = C.c_int(0)
+    load().mod16_device_count(C.byref(n))
+    return n.value
+
+
+def ptr_array(ptrs):
+    '''Python ints / None -> void*[len]'''
+    arr = (C.c_void_p * len(ptrs))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p
+    return arr
+
+
+def i64_array(vals):
+    return (C.c_int64 * len(vals))(*[int(v) for v in vals])
+
+
+class Context:
+    '''One device context (``mod16_ctx``): BPLUT, staging tiles, workspace.'''
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self.handle = C.c_void_p()
+        self.device = device
+        rc = self.lib.mod16_create(int(device), C.byref(self.handle))
+        if rc != OK:
+            self.handle = C.c_void_p()
+            raise Mod16Error(rc, (
+                'cannot create a context on device %d: %s -- mod16_amd needs '
+                'an MI355X (gfx950); there is no CPU fallback'
+                % (device, self.lib.mod16_strerror(rc).decode())))
+        self._bplut_key = None
+
+    def close(self):
+        if getattr(self, 'handle', None) and self.handle.value:
+            self.lib.mod16_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc == OK:
+            return
+        msg = self.lib.mod16_last_error(self.handle).decode() or \
+            self.lib.mod16_strerror(rc).decode()
+        if rc == ERR_CLASS_RANGE:
+            # what numpy raises for params_dict[key][pft_map] with a code >= 13
+            raise IndexError(msg)
+        raise Mod16Error(rc, msg)
+
+    def set_bplut(self, table):
+        '''table: float64 [13][11], rows = PFT code, columns in
+        MOD16.required_parameters order.'''
+        table = np.ascontiguousarray(table, np.float64)
+        if table.shape != (N_CLASSES, N_PARAMS):
+            raise ValueError('BPLUT table must have shape (13, 11), got %r'
+                             % (table.shape,))
+        key = table.tobytes()
+        if key != self._bplut_key:
+            self.check(self.lib.mod16_set_bplut_f64(
+                self.handle, table.ctypes.data))
+            self._bplut_key = key
+
+    def et(self, dtype, cls, drivers, dstride, params, pstride, n, out_day,
+           out_night, out_sep, flags=MATH_FAST, where=HOST, stream=None):
+        '''Thin wrapper of mod16_et_f64 / mod16_et_f32; every array argument
+        is a raw address (int) or None.'''
+        fn = self.lib.mod16_et_f32 if np.dtype(dtype) == np.float32 \
+            else self.lib.mod16_et_f64
+        self.check(fn(
+            self.handle, cls, ptr_array(drivers), i64_array(dstride),
+            ptr_array(params) if params is not None else None,
+            i64_array(pstride) if pstride is not None else None,
+            int(n), out_day, out_night,
+            ptr_array(out_sep) if out_sep is not None else None,
+            int(flags), int(where), stream))
+
+    def check_status(self, stream=None):
+        self.check(self.lib.mod16_check_status(self.handle, stream))
+
+
+_contexts = {}
+
+
+def context(device=0):
+    '''Process-wide context per device (created on first use).'''
+    ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = _contexts[device] = Context(device)
+    return ctx

@@ -1,0 +1,498 @@
+// libmod16hip.so -- host side of the C ABI declared in include/mod16_hip.h.
+// Owns the device context (BPLUT, status word, staging tiles, reduction
+// workspace) and launches the gfx950 kernels of mod16_kernels.hpp.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+
+#include "../../include/mod16_hip.h"
+#include "mod16_kernels.hpp"
+
+using namespace mod16;
+
+namespace {
+constexpr int64_t kTilePixels = int64_t(1) << 21;   // HOST mode: pixels per staged tile
+constexpr int kDiagBlocks = 1024;
+constexpr int kSlots = 2;                           // double buffering
+}  // namespace
+
+struct mod16_ctx {
+    int device = 0;
+    int cus = 256;
+    int grid_mult = 8;
+    bool have_lut = false;
+    double* lut64 = nullptr;     // device [MOD16_LUT_ROWS][kLutCols]
+    float* lut32 = nullptr;
+    unsigned* status = nullptr;      // device status word
+    unsigned* status_host = nullptr; // pinned mirror
+    double* diag_partial = nullptr;  // device [kDiagBlocks][kDiag]
+    double* diag_dev = nullptr;      // device [kDiag]
+    double* diag_host = nullptr;     // pinned [kDiag]
+    // HOST-mode staging: per slot one device slab + one stream
+    void* slab[kSlots] = {nullptr, nullptr};
+    size_t slab_bytes = 0;
+    hipStream_t streams[kSlots] = {nullptr, nullptr};
+    void* scalars = nullptr;         // device copies of broadcast scalars
+    std::string err;
+};
+
+#define HIPCHK(ctx, call)                                                          \
+    do {                                                                           \
+        hipError_t e_ = (call);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            char b_[512];                                                          \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call,                \
+                     hipGetErrorString(e_), __FILE__, __LINE__);                   \
+            (ctx)->err = b_;                                                       \
+            return MOD16_ERR_HIP;                                                  \
+        }                                                                          \
+    } while (0)
+
+static int fail(mod16_ctx* ctx, int code, const char* msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+extern "C" int mod16_version(void) { return MOD16_ABI_VERSION; }
+
+extern "C" const char* mod16_strerror(int status) {
+    switch (status) {
+        case MOD16_OK: return "ok";
+        case MOD16_ERR_ARG: return "invalid argument";
+        case MOD16_ERR_HIP: return "HIP runtime error";
+        case MOD16_ERR_CLASS_RANGE: return "class code out of range (>= 13)";
+        case MOD16_ERR_NOMEM: return "out of memory";
+        case MOD16_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case MOD16_ERR_NO_BPLUT: return "class raster given but no BPLUT set";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char* mod16_last_error(const mod16_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : "";
+}
+
+extern "C" int mod16_device_count(int* count) {
+    if (!count) return MOD16_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return MOD16_OK;
+}
+
+extern "C" int mod16_destroy(mod16_ctx* ctx) {
+    if (!ctx) return MOD16_OK;
+    (void)hipSetDevice(ctx->device);
+    for (int s = 0; s < kSlots; ++s) {
+        if (ctx->slab[s]) (void)hipFree(ctx->slab[s]);
+        if (ctx->streams[s]) (void)hipStreamDestroy(ctx->streams[s]);
+    }
+    if (ctx->scalars) (void)hipFree(ctx->scalars);
+    if (ctx->lut64) (void)hipFree(ctx->lut64);
+    if (ctx->lut32) (void)hipFree(ctx->lut32);
+    if (ctx->status) (void)hipFree(ctx->status);
+    if (ctx->status_host) (void)hipHostFree(ctx->status_host);
+    if (ctx->diag_partial) (void)hipFree(ctx->diag_partial);
+    if (ctx->diag_dev) (void)hipFree(ctx->diag_dev);
+    if (ctx->diag_host) (void)hipHostFree(ctx->diag_host);
+    delete ctx;
+    return MOD16_OK;
+}
+
+extern "C" int mod16_create(int device, mod16_ctx** out) {
+    if (!out) return MOD16_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+        return MOD16_ERR_NO_DEVICE;
+    mod16_ctx* ctx = new (std::nothrow) mod16_ctx;
+    if (!ctx) return MOD16_ERR_NOMEM;
+    ctx->device = device;
+    int rc = [&]() -> int {
+        HIPCHK(ctx, hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIPCHK(ctx, hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            ctx->err = std::string("device is ") + prop.gcnArchName + ", this library is gfx950 only";
+            return MOD16_ERR_NO_DEVICE;
+        }
+        ctx->cus = prop.multiProcessorCount;
+        if (const char* g = getenv("MOD16_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(g));
+        const size_t nlut = MOD16_LUT_ROWS * kLutCols;
+        HIPCHK(ctx, hipMalloc(&ctx->lut64, nlut * sizeof(double)));
+        HIPCHK(ctx, hipMalloc(&ctx->lut32, nlut * sizeof(float)));
+        HIPCHK(ctx, hipMalloc(&ctx->status, sizeof(unsigned)));
+        HIPCHK(ctx, hipMemset(ctx->status, 0, sizeof(unsigned)));
+        HIPCHK(ctx, hipHostMalloc(&ctx->status_host, sizeof(unsigned)));
+        HIPCHK(ctx, hipMalloc(&ctx->diag_partial, sizeof(double) * kDiagBlocks * kDiag));
+        HIPCHK(ctx, hipMalloc(&ctx->diag_dev, sizeof(double) * kDiag));
+        HIPCHK(ctx, hipHostMalloc(&ctx->diag_host, sizeof(double) * kDiag));
+        HIPCHK(ctx, hipMalloc(&ctx->scalars, 32 * sizeof(double)));
+        return MOD16_OK;
+    }();
+    if (rc != MOD16_OK) {
+        // keep the message for the caller? the ctx is gone: print it once
+        fprintf(stderr, "mod16_create: %s\n", ctx->err.c_str());
+        mod16_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return MOD16_OK;
+}
+
+extern "C" int mod16_set_bplut_f64(mod16_ctx* ctx, const double* lut) {
+    if (!ctx || !lut) return fail(ctx, MOD16_ERR_ARG, "mod16_set_bplut_f64: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    double h64[MOD16_LUT_ROWS * kLutCols];
+    float h32[MOD16_LUT_ROWS * kLutCols];
+    for (int c = 0; c < kLutCols; ++c) {
+        double row[MOD16_LUT_ROWS];
+        for (int k = 0; k < MOD16_LUT_ROWS; ++k) row[k] = nan;
+        if (c < MOD16_N_CLASSES) {
+            const double* p = lut + (size_t)c * MOD16_N_PARAMS;
+            for (int k = 0; k < MOD16_N_PARAMS; ++k) row[k] = p[k];
+            row[11] = 1.0 / (p[MOD16_TMIN_OPEN] - p[MOD16_TMIN_CLOSE]);
+            row[12] = 1.0 / (p[MOD16_VPD_CLOSE] - p[MOD16_VPD_OPEN]);
+            row[13] = (p[MOD16_RBL_MAX] - p[MOD16_RBL_MIN]) / (p[MOD16_VPD_CLOSE] - p[MOD16_VPD_OPEN]);
+            row[14] = 1.0 / p[MOD16_BETA];
+        }
+        for (int k = 0; k < MOD16_LUT_ROWS; ++k) {
+            h64[k * kLutCols + c] = row[k];
+            h32[k * kLutCols + c] = (float)row[k];
+        }
+    }
+    HIPCHK(ctx, hipMemcpy(ctx->lut64, h64, sizeof h64, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->lut32, h32, sizeof h32, hipMemcpyHostToDevice));
+    ctx->have_lut = true;
+    return MOD16_OK;
+}
+
+// ------------------------------------------------------------------ launch
+template <typename T> static const T* ctx_lut(const mod16_ctx* ctx);
+template <> const double* ctx_lut<double>(const mod16_ctx* ctx) { return ctx->lut64; }
+template <> const float* ctx_lut<float>(const mod16_ctx* ctx) { return ctx->lut32; }
+
+template <typename T> struct VecOf;
+template <> struct VecOf<double> { static constexpr int v = 2; };
+template <> struct VecOf<float> { static constexpr int v = 4; };
+
+template <typename T, int V>
+static void launch_variant(const EtArgs<T>& a, bool lut, bool fast, int grid, hipStream_t st) {
+    if (lut) {
+        if (fast) hipLaunchKernelGGL((et_kernel<T, V, true, true>), dim3(grid), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((et_kernel<T, V, true, false>), dim3(grid), dim3(kBlock), 0, st, a);
+    } else {
+        if (fast) hipLaunchKernelGGL((et_kernel<T, V, false, true>), dim3(grid), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((et_kernel<T, V, false, false>), dim3(grid), dim3(kBlock), 0, st, a);
+    }
+}
+
+static int grid_for(const mod16_ctx* ctx, int64_t nvec) {
+    int64_t need = (nvec + kBlock - 1) / kBlock;
+    int64_t cap = (int64_t)ctx->cus * ctx->grid_mult;
+    return (int)std::max<int64_t>(1, std::min(need, cap));
+}
+
+// All pointers are device pointers here.
+template <typename T>
+static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st) {
+    constexpr int V = VecOf<T>::v;
+    const bool lut = a.cls != nullptr;
+    const bool fast = (flags & MOD16_MATH_EXACT) == 0;
+    if (a.n <= 0) return MOD16_OK;
+    a.lut = ctx_lut<T>(ctx);
+    a.status = ctx->status;
+    // 16-byte vector path needs every dense pointer 16-byte aligned
+    bool aligned = true;
+    auto chk = [&](const void* p, size_t al) {
+        if (p && (reinterpret_cast<uintptr_t>(p) % al)) aligned = false;
+    };
+    for (int k = 0; k < 14; ++k) if (a.dstride[k]) chk(a.drv[k], 16);
+    if (lut) chk(a.cls, V);
+    else for (int k = 0; k < 11; ++k) if (a.pstride[k]) chk(a.par[k], 16);
+    chk(a.out_day, 16);
+    chk(a.out_night, 16);
+    for (int k = 0; k < 6; ++k) chk(a.sep[k], 16);
+    const int64_t nbody = aligned ? (a.n / V) * V : 0;
+    if (nbody) {
+        EtArgs<T> b = a;
+        b.n = nbody;
+        launch_variant<T, V>(b, lut, fast, grid_for(ctx, nbody / V), st);
+    }
+    if (nbody < a.n) {   // ragged tail (or unaligned input): scalar variant
+        EtArgs<T> t = a;
+        const int64_t off = nbody;
+        for (int k = 0; k < 14; ++k) if (t.dstride[k]) t.drv[k] += off;
+        if (lut) t.cls += off;
+        else for (int k = 0; k < 11; ++k) if (t.pstride[k]) t.par[k] += off;
+        if (t.out_day) t.out_day += off;
+        if (t.out_night) t.out_night += off;
+        for (int k = 0; k < 6; ++k) if (t.sep[k]) t.sep[k] += off;
+        t.n = a.n - off;
+        launch_variant<T, 1>(t, lut, fast, grid_for(ctx, t.n), st);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return MOD16_OK;
+}
+
+template <typename T>
+static int fill_args(mod16_ctx* ctx, EtArgs<T>& a, const uint8_t* cls, const T* const* drivers,
+                     const int64_t* dstride, const T* const* params, const int64_t* pstride,
+                     int64_t n, T* out_day, T* out_night, T* const* out_sep) {
+    if (!ctx) return MOD16_ERR_ARG;
+    if (!drivers || !dstride || n < 0) return fail(ctx, MOD16_ERR_ARG, "mod16_et: NULL drivers/strides or n < 0");
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < 14; ++k) {
+        if (!drivers[k]) return fail(ctx, MOD16_ERR_ARG, "mod16_et: NULL driver array");
+        if (dstride[k] != 0 && dstride[k] != 1) return fail(ctx, MOD16_ERR_ARG, "mod16_et: driver stride must be 0 or 1");
+        a.drv[k] = drivers[k];
+        a.dstride[k] = dstride[k];
+    }
+    a.cls = cls;
+    if (cls) {
+        if (!ctx->have_lut) return fail(ctx, MOD16_ERR_NO_BPLUT, "mod16_et: class raster given but mod16_set_bplut_f64 was not called");
+    } else {
+        if (!params || !pstride) return fail(ctx, MOD16_ERR_ARG, "mod16_et: neither a class raster nor parameter arrays given");
+        for (int k = 0; k < 11; ++k) {
+            if (!params[k]) return fail(ctx, MOD16_ERR_ARG, "mod16_et: NULL parameter array");
+            if (pstride[k] != 0 && pstride[k] != 1) return fail(ctx, MOD16_ERR_ARG, "mod16_et: parameter stride must be 0 or 1");
+            a.par[k] = params[k];
+            a.pstride[k] = pstride[k];
+        }
+    }
+    a.out_day = out_day;
+    a.out_night = out_night;
+    bool any = out_day || out_night;
+    if (out_sep)
+        for (int k = 0; k < 6; ++k) {
+            a.sep[k] = out_sep[k];
+            any = any || out_sep[k];
+        }
+    if (!any) return fail(ctx, MOD16_ERR_ARG, "mod16_et: no output array given");
+    a.n = n;
+    return MOD16_OK;
+}
+
+static int read_status(mod16_ctx* ctx, hipStream_t st) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->status_host, ctx->status, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->status, 0, sizeof(unsigned), st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (*ctx->status_host & kStatusClassRange)
+        return fail(ctx, MOD16_ERR_CLASS_RANGE, "class raster holds a code >= 13 (numpy would raise IndexError)");
+    return MOD16_OK;
+}
+
+// HOST mode: stage tiles of kTilePixels through two device slabs / streams.
+template <typename T>
+static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
+    const int64_t n = h.n;
+    if (n == 0) return MOD16_OK;
+    const int64_t tile = std::min<int64_t>(n, kTilePixels);
+    // slab layout per slot: 14 drivers | 11 params | 8 outputs (T each) | class bytes
+    const size_t per_arr = (((size_t)tile * sizeof(T)) + 255) / 256 * 256;
+    const size_t need = per_arr * (14 + 11 + 8) + (size_t)tile + 256;
+    if (ctx->slab_bytes < need) {
+        for (int s = 0; s < kSlots; ++s) {
+            if (ctx->slab[s]) HIPCHK(ctx, hipFree(ctx->slab[s]));
+            ctx->slab[s] = nullptr;
+        }
+        ctx->slab_bytes = 0;
+        for (int s = 0; s < kSlots; ++s) HIPCHK(ctx, hipMalloc(&ctx->slab[s], need));
+        ctx->slab_bytes = need;
+    }
+    for (int s = 0; s < kSlots; ++s)
+        if (!ctx->streams[s]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->streams[s], hipStreamNonBlocking));
+    // broadcast scalars live in one small device array
+    T hs[32];
+    for (int k = 0; k < 14; ++k) hs[k] = h.dstride[k] ? T(0) : h.drv[k][0];
+    for (int k = 0; k < 11; ++k) hs[14 + k] = (!h.cls && !h.pstride[k]) ? h.par[k][0] : T(0);
+    HIPCHK(ctx, hipMemcpy(ctx->scalars, hs, sizeof(T) * 25, hipMemcpyHostToDevice));
+    const T* dscal = static_cast<const T*>(ctx->scalars);
+
+    int slot = 0;
+    for (int64_t off = 0; off < n; off += tile, slot ^= 1) {
+        const int64_t m = std::min(tile, n - off);
+        hipStream_t st = ctx->streams[slot];
+        HIPCHK(ctx, hipStreamSynchronize(st));   // slab of this slot is free again
+        char* base = static_cast<char*>(ctx->slab[slot]);
+        EtArgs<T> d = h;
+        d.n = m;
+        for (int k = 0; k < 14; ++k) {
+            if (h.dstride[k]) {
+                T* dp = reinterpret_cast<T*>(base + per_arr * k);
+                HIPCHK(ctx, hipMemcpyAsync(dp, h.drv[k] + off, sizeof(T) * m, hipMemcpyHostToDevice, st));
+                d.drv[k] = dp;
+            } else {
+                d.drv[k] = dscal + k;
+            }
+        }
+        if (h.cls) {
+            uint8_t* dc = reinterpret_cast<uint8_t*>(base + per_arr * 33);
+            HIPCHK(ctx, hipMemcpyAsync(dc, h.cls + off, (size_t)m, hipMemcpyHostToDevice, st));
+            d.cls = dc;
+        } else {
+            for (int k = 0; k < 11; ++k) {
+                if (h.pstride[k]) {
+                    T* dp = reinterpret_cast<T*>(base + per_arr * (14 + k));
+                    HIPCHK(ctx, hipMemcpyAsync(dp, h.par[k] + off, sizeof(T) * m, hipMemcpyHostToDevice, st));
+                    d.par[k] = dp;
+                } else {
+                    d.par[k] = dscal + 14 + k;
+                }
+            }
+        }
+        auto out_at = [&](int k) { return reinterpret_cast<T*>(base + per_arr * (25 + k)); };
+        d.out_day = h.out_day ? out_at(0) : nullptr;
+        d.out_night = h.out_night ? out_at(1) : nullptr;
+        for (int k = 0; k < 6; ++k) d.sep[k] = h.sep[k] ? out_at(2 + k) : nullptr;
+        int rc = launch_et<T>(ctx, d, flags, st);
+        if (rc != MOD16_OK) return rc;
+        if (h.out_day) HIPCHK(ctx, hipMemcpyAsync(h.out_day + off, d.out_day, sizeof(T) * m, hipMemcpyDeviceToHost, st));
+        if (h.out_night) HIPCHK(ctx, hipMemcpyAsync(h.out_night + off, d.out_night, sizeof(T) * m, hipMemcpyDeviceToHost, st));
+        for (int k = 0; k < 6; ++k)
+            if (h.sep[k]) HIPCHK(ctx, hipMemcpyAsync(h.sep[k] + off, d.sep[k], sizeof(T) * m, hipMemcpyDeviceToHost, st));
+    }
+    for (int s = 0; s < kSlots; ++s) HIPCHK(ctx, hipStreamSynchronize(ctx->streams[s]));
+    return read_status(ctx, ctx->streams[0]);
+}
+
+template <typename T>
+static int et_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drivers,
+                    const int64_t* dstride, const T* const* params, const int64_t* pstride,
+                    int64_t n, T* out_day, T* out_night, T* const* out_sep, unsigned flags,
+                    int where, void* stream) {
+    EtArgs<T> a;
+    int rc = fill_args<T>(ctx, a, cls, drivers, dstride, params, pstride, n, out_day, out_night, out_sep);
+    if (rc != MOD16_OK) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (where == MOD16_DEVICE) return launch_et<T>(ctx, a, flags, static_cast<hipStream_t>(stream));
+    if (where == MOD16_HOST) return run_host<T>(ctx, a, flags);
+    return fail(ctx, MOD16_ERR_ARG, "mod16_et: `where` must be MOD16_HOST or MOD16_DEVICE");
+}
+
+extern "C" int mod16_et_f64(mod16_ctx* ctx, const uint8_t* cls, const double* const* drivers,
+                            const int64_t* dstride, const double* const* params,
+                            const int64_t* pstride, int64_t n, double* out_day,
+                            double* out_night, double* const* out_sep, unsigned flags,
+                            int where, void* stream) {
+    return et_entry<double>(ctx, cls, drivers, dstride, params, pstride, n, out_day, out_night,
+                            out_sep, flags, where, stream);
+}
+
+extern "C" int mod16_et_f32(mod16_ctx* ctx, const uint8_t* cls, const float* const* drivers,
+                            const int64_t* dstride, const float* const* params,
+                            const int64_t* pstride, int64_t n, float* out_day, float* out_night,
+                            float* const* out_sep, unsigned flags, int where, void* stream) {
+    return et_entry<float>(ctx, cls, drivers, dstride, params, pstride, n, out_day, out_night,
+                           out_sep, flags, where, stream);
+}
+
+extern "C" int mod16_check_status(mod16_ctx* ctx, void* stream) {
+    if (!ctx) return MOD16_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return read_status(ctx, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mod16_time_et(mod16_ctx* ctx, int is_f32, const uint8_t* cls,
+                             const void* const* drivers, const int64_t* dstride,
+                             const void* const* params, const int64_t* pstride, int64_t n,
+                             void* out_day, void* out_night, void* const* out_sep,
+                             unsigned flags, int launches, void* stream, float* ms) {
+    if (!ctx || !ms || launches <= 0) return fail(ctx, MOD16_ERR_ARG, "mod16_time_et: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    HIPCHK(ctx, hipEventCreate(&e0));
+    HIPCHK(ctx, hipEventCreate(&e1));
+    int rc = MOD16_OK;
+    HIPCHK(ctx, hipEventRecord(e0, st));
+    for (int i = 0; i < launches && rc == MOD16_OK; ++i) {
+        if (is_f32)
+            rc = mod16_et_f32(ctx, cls, reinterpret_cast<const float* const*>(drivers), dstride,
+                              reinterpret_cast<const float* const*>(params), pstride, n,
+                              static_cast<float*>(out_day), static_cast<float*>(out_night),
+                              reinterpret_cast<float* const*>(out_sep), flags, MOD16_DEVICE, stream);
+        else
+            rc = mod16_et_f64(ctx, cls, reinterpret_cast<const double* const*>(drivers), dstride,
+                              reinterpret_cast<const double* const*>(params), pstride, n,
+                              static_cast<double*>(out_day), static_cast<double*>(out_night),
+                              reinterpret_cast<double* const*>(out_sep), flags, MOD16_DEVICE, stream);
+    }
+    HIPCHK(ctx, hipEventRecord(e1, st));
+    HIPCHK(ctx, hipEventSynchronize(e1));
+    float t = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&t, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms = t / (float)launches;
+    return rc;
+}
+
+// ------------------------------------------------------------- diagnostics
+template <typename T>
+static int reduce_entry(mod16_ctx* ctx, const T* day, const T* night, int64_t n, double* diag,
+                        double* ddiag, void* stream) {
+    if (!ctx || !day || !night || n < 0) return fail(ctx, MOD16_ERR_ARG, "mod16_reduce_diag: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(kDiagBlocks, (n + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL((diag_partial_kernel<T>), dim3(blocks), dim3(kBlock), 0, st, day, night, n, ctx->diag_partial);
+    double* dst = ddiag ? ddiag : ctx->diag_dev;
+    hipLaunchKernelGGL(diag_final_kernel, dim3(1), dim3(kBlock), 0, st, ctx->diag_partial, blocks, dst);
+    HIPCHK(ctx, hipGetLastError());
+    if (diag) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->diag_host, dst, sizeof(double) * kDiag, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        memcpy(diag, ctx->diag_host, sizeof(double) * kDiag);
+    }
+    return MOD16_OK;
+}
+
+extern "C" int mod16_reduce_diag_f64(mod16_ctx* ctx, const double* day, const double* night,
+                                     int64_t n, double* diag, double* ddiag, void* stream) {
+    return reduce_entry<double>(ctx, day, night, n, diag, ddiag, stream);
+}
+extern "C" int mod16_reduce_diag_f32(mod16_ctx* ctx, const float* day, const float* night,
+                                     int64_t n, double* diag, double* ddiag, void* stream) {
+    return reduce_entry<float>(ctx, day, night, n, diag, ddiag, stream);
+}
+
+// ---------------------------------------------------------------- generator
+template <typename T>
+static int synth_entry(mod16_ctx* ctx, uint64_t seed, int64_t step, int64_t pixel_offset,
+                       int64_t n, uint8_t* cls, T* const* drivers, void* stream) {
+    if (!ctx || !drivers || n < 0) return fail(ctx, MOD16_ERR_ARG, "mod16_synth: bad argument");
+    SynthArgs<T> a;
+    a.cls = cls;
+    for (int k = 0; k < 14; ++k) {
+        if (!drivers[k]) return fail(ctx, MOD16_ERR_ARG, "mod16_synth: NULL driver array");
+        a.drv[k] = drivers[k];
+    }
+    a.seed = seed;
+    a.step = step;
+    a.offset = pixel_offset;
+    a.n = n;
+    if (n == 0) return MOD16_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int grid = (int)std::min<int64_t>((n + kBlock - 1) / kBlock, (int64_t)ctx->cus * 16);
+    hipLaunchKernelGGL((synth_kernel<T>), dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a);
+    HIPCHK(ctx, hipGetLastError());
+    return MOD16_OK;
+}
+
+extern "C" int mod16_synth_f64(mod16_ctx* ctx, uint64_t seed, int64_t step, int64_t pixel_offset,
+                               int64_t n, uint8_t* cls, double* const* drivers, void* stream) {
+    return synth_entry<double>(ctx, seed, step, pixel_offset, n, cls, drivers, stream);
+}
+extern "C" int mod16_synth_f32(mod16_ctx* ctx, uint64_t seed, int64_t step, int64_t pixel_offset,
+                               int64_t n, uint8_t* cls, float* const* drivers, void* stream) {
+    return synth_entry<float>(ctx, seed, step, pixel_offset, n, cls, drivers, stream);
+}

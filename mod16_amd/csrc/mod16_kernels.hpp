@@ -1,0 +1,294 @@
+// gfx950 kernels of libmod16hip: the fused ET pixel kernel, the synthetic
+// driver generator and the diagnostics reduction. Launch code is in
+// mod16_capi.hip.
+//
+// Fused ET kernel -- data movement per pixel (float64): 14 x 8 B driver
+// loads + 1 B class + 2 x 8 B stores = 129 B, each driver array read exactly
+// once with 16-byte (global_load_dwordx4) coalesced accesses; no MFMA (an
+// element-wise map has no contraction). The BPLUT and its derived
+// reciprocals sit in LDS as [row][16] so that lanes of different classes hit
+// different banks and lanes of one class broadcast.
+#pragma once
+#include <stdint.h>
+#include "mod16_physics.hpp"
+
+namespace mod16 {
+
+constexpr int kBlock = 256;
+constexpr int kLutCols = 16;   // 13 class codes + NaN padding (col 13..15)
+constexpr unsigned kStatusClassRange = 1u;
+
+template <typename T> struct EtArgs {
+    const T* drv[14];
+    int64_t dstride[14];
+    const T* par[11];
+    int64_t pstride[11];
+    const uint8_t* cls;
+    const T* lut;          // device [MOD16_LUT_ROWS][kLutCols]
+    T* out_day;
+    T* out_night;
+    T* sep[6];
+    int64_t n;
+    unsigned* status;
+};
+
+template <typename T, int V> struct Vec;
+template <> struct Vec<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct Vec<double, 1> { typedef double type; };
+template <> struct Vec<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct Vec<float, 1> { typedef float type; };
+
+template <typename T, int V>
+__device__ __forceinline__ void load_vec(const T* __restrict__ p, int64_t stride, int64_t i,
+                                         T (&dst)[V]) {
+    if (stride) {   // wave-uniform (kernel argument)
+        typedef typename Vec<T, V>::type VT;
+        VT v = *reinterpret_cast<const VT*>(p + i);
+        if constexpr (V == 1) {
+            dst[0] = v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) dst[j] = v[j];
+        }
+    } else {
+        T s = p[0];
+#pragma unroll
+        for (int j = 0; j < V; ++j) dst[j] = s;
+    }
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void store_vec(T* __restrict__ p, int64_t i, const T (&src)[V]) {
+    typedef typename Vec<T, V>::type VT;
+    if constexpr (V == 1) {
+        p[i] = src[0];
+    } else {
+        VT v;
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = src[j];
+        *reinterpret_cast<VT*>(p + i) = v;
+    }
+}
+
+template <typename T, int V, bool LUT, bool FAST>
+__global__ void __launch_bounds__(kBlock) et_kernel(const EtArgs<T> a) {
+    __shared__ T lut[MOD16_LUT_ROWS * kLutCols];
+    if (LUT) {
+        for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) lut[i] = a.lut[i];
+        __syncthreads();
+    }
+    const int64_t nvec = a.n / V;
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += step) {
+        const int64_t i = v * V;
+        T in[14][V];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) load_vec<T, V>(a.drv[k], a.dstride[k], i, in[k]);
+        unsigned cbits = 0;
+        T pin[11][V];
+        if (LUT) {
+            if constexpr (V == 1) cbits = a.cls[i];
+            else if constexpr (V == 2) cbits = *reinterpret_cast<const uint16_t*>(a.cls + i);
+            else cbits = *reinterpret_cast<const uint32_t*>(a.cls + i);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 11; ++k) load_vec<T, V>(a.par[k], a.pstride[k], i, pin[k]);
+        }
+        T day[V], night[V], sep[6][V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            PixelIn<T> x = {in[0][j], in[1][j], in[2][j], in[3][j], in[4][j], in[5][j], in[6][j],
+                            in[7][j], in[8][j], in[9][j], in[10][j], in[11][j], in[12][j],
+                            in[13][j]};
+            ClassPar<T> p;
+            if (LUT) {
+                unsigned c = (cbits >> (8 * j)) & 0xffu;
+                if (c >= 13u) {   // numpy would raise IndexError: flag it, give NaN
+                    atomicOr(a.status, kStatusClassRange);
+                    c = 13u;
+                }
+                const T* l = lut + c;
+                p.tmin_close = l[0 * kLutCols];
+                p.tmin_open = l[1 * kLutCols];
+                p.vpd_open = l[2 * kLutCols];
+                p.vpd_close = l[3 * kLutCols];
+                p.gl_sh = l[4 * kLutCols];
+                p.gl_wv = l[5 * kLutCols];
+                p.g_cut = l[6 * kLutCols];
+                p.csl = l[7 * kLutCols];
+                p.rbl_min = l[8 * kLutCols];
+                p.rbl_max = l[9 * kLutCols];
+                p.beta = l[10 * kLutCols];
+                if (FAST) {
+                    p.inv_dtmin = l[11 * kLutCols];
+                    p.inv_dvpd = l[12 * kLutCols];
+                    p.rbl_slope = l[13 * kLutCols];
+                    p.inv_beta = l[14 * kLutCols];
+                }
+            } else {
+                p.tmin_close = pin[0][j];
+                p.tmin_open = pin[1][j];
+                p.vpd_open = pin[2][j];
+                p.vpd_close = pin[3][j];
+                p.gl_sh = pin[4][j];
+                p.gl_wv = pin[5][j];
+                p.g_cut = pin[6][j];
+                p.csl = pin[7][j];
+                p.rbl_min = pin[8][j];
+                p.rbl_max = pin[9][j];
+                p.beta = pin[10][j];
+                if (FAST) p.derive();
+            }
+            PixelOut<T> o = FAST ? et_pixel_fast<T>(x, p) : et_pixel_exact<T>(x, p);
+            // mod16/__init__.py:792: (canopy + soil) + transpiration
+            day[j] = (o.canopy_d + o.soil_d) + o.trans_d;
+            night[j] = (o.canopy_n + o.soil_n) + o.trans_n;
+            sep[0][j] = o.canopy_d;
+            sep[1][j] = o.soil_d;
+            sep[2][j] = o.trans_d;
+            sep[3][j] = o.canopy_n;
+            sep[4][j] = o.soil_n;
+            sep[5][j] = o.trans_n;
+        }
+        if (a.out_day) store_vec<T, V>(a.out_day, i, day);
+        if (a.out_night) store_vec<T, V>(a.out_night, i, night);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (a.sep[k]) store_vec<T, V>(a.sep[k], i, sep[k]);
+    }
+}
+
+// ------------------------------------------------------------- diagnostics
+// Deterministic two-level sum: every block walks a fixed slice pattern, the
+// in-block tree is fixed, and the final pass adds the per-block partials in
+// index order -- so the result depends only on (n, grid), never on timing.
+constexpr int kDiag = 8;
+
+__device__ __forceinline__ void diag_merge(double (&a)[kDiag], const double (&b)[kDiag]) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a[k] += b[k];
+    a[6] = (b[6] > a[6]) ? b[6] : a[6];
+    a[7] = (b[7] > a[7]) ? b[7] : a[7];
+}
+
+__device__ __forceinline__ void diag_block_reduce(double (&acc)[kDiag], double* out) {
+    __shared__ double sm[kBlock / 64][kDiag];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double o[kDiag];
+#pragma unroll
+        for (int k = 0; k < kDiag; ++k) o[k] = __shfl_down(acc[k], off, 64);
+        diag_merge(acc, o);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0)
+        for (int k = 0; k < kDiag; ++k) sm[wave][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) {
+            double o[kDiag];
+            for (int k = 0; k < kDiag; ++k) o[k] = sm[w][k];
+            diag_merge(acc, o);
+        }
+        for (int k = 0; k < kDiag; ++k) out[k] = acc[k];
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) diag_partial_kernel(const T* __restrict__ day,
+                                                              const T* __restrict__ night,
+                                                              int64_t n, double* partial) {
+    double acc[kDiag] = {0, 0, 0, 0, 0, 0, -__builtin_huge_val(), -__builtin_huge_val()};
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) {
+        double d = (double)day[i], g = (double)night[i];
+        bool dn = d != d, gn = g != g;
+        acc[0] += dn ? 0.0 : d;
+        acc[1] += gn ? 0.0 : g;
+        acc[2] += dn ? 0.0 : 1.0;
+        acc[3] += gn ? 0.0 : 1.0;
+        acc[4] += dn ? 1.0 : 0.0;
+        acc[5] += gn ? 1.0 : 0.0;
+        acc[6] = (!dn && d > acc[6]) ? d : acc[6];
+        acc[7] = (!gn && g > acc[7]) ? g : acc[7];
+    }
+    diag_block_reduce(acc, partial + (int64_t)blockIdx.x * kDiag);
+}
+
+__global__ void __launch_bounds__(kBlock) diag_final_kernel(const double* partial, int nblocks,
+                                                            double* out) {
+    double acc[kDiag] = {0, 0, 0, 0, 0, 0, -__builtin_huge_val(), -__builtin_huge_val()};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+        double o[kDiag];
+        for (int k = 0; k < kDiag; ++k) o[k] = partial[(int64_t)b * kDiag + k];
+        diag_merge(acc, o);
+    }
+    diag_block_reduce(acc, out);
+}
+
+// --------------------------------------------------------- synthetic fields
+// Counter-based generator: value = f(seed, step,
+// variable, global pixel index) through a splitmix64 finaliser, so a raster
+// tiled over any number of GPUs is the same field.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double u01(uint64_t seed, uint64_t step, unsigned var, uint64_t pix) {
+    uint64_t h = mix64(seed + 0x9e3779b97f4a7c15ull * (step * 64ull + var + 1ull));
+    h = mix64(h ^ (pix * 0xd1342543de82ef95ull + 0x632be59bd9b4e019ull));
+    return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+template <typename T> struct SynthArgs {
+    uint8_t* cls;
+    T* drv[14];
+    uint64_t seed;
+    int64_t step, offset, n;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) synth_kernel(const SynthArgs<T> a) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
+        const uint64_t pix = (uint64_t)(a.offset + i);
+        const uint64_t st = (uint64_t)a.step;
+        auto U = [&](unsigned var, double lo, double hi) {
+            return lo + (hi - lo) * u01(a.seed, st, var, pix);
+        };
+        double t_d = U(0, 255.0, 305.0);
+        double t_n = t_d - U(1, 0.0, 12.0);
+        double tmin = t_n - U(2, 0.0, 3.0);
+        double t_ann = 265.0 + 35.0 * u01(a.seed, 0, 3, pix);   // climatology is static
+        double rh_d = U(4, 0.05, 1.0), rh_n = U(5, 0.05, 1.0);
+        double vpd_d = svp_exact<double>(t_d) * (1.0 - rh_d);
+        double vpd_n = svp_exact<double>(t_n) * (1.0 - rh_n);
+        double fpar = U(11, 0.02, 0.89), lai = U(12, 0.13, 5.34);
+        double r = u01(a.seed, st, 13, pix);       // exact 0 / 1 / NaN specials
+        fpar = (r < 0.01) ? 0.0 : ((r < 0.015) ? 1.0 : ((r < 0.02) ? __builtin_nan("") : fpar));
+        r = u01(a.seed, st, 14, pix);
+        lai = (r < 0.01) ? 0.0 : ((r < 0.015) ? __builtin_nan("") : lai);
+        double rc = u01(a.seed, 0, 15, pix);       // land cover is static
+        unsigned c = (unsigned)(u01(a.seed, 0, 16, pix) * 11.0) % 11u + 1u;   // 1..11
+        c = (c == 11u) ? 12u : c;                  // PFT_VALID = 1..10, 12
+        c = (rc < 0.01) ? 0u : ((rc < 0.02) ? 11u : c);
+        if (a.cls) a.cls[i] = (uint8_t)c;
+        a.drv[0][i] = (T)U(6, -100.0, 0.0);        // lw_net_day
+        a.drv[1][i] = (T)U(7, -50.0, 0.0);         // lw_net_night
+        a.drv[2][i] = (T)U(8, 0.0, 360.0);         // sw_rad_day
+        a.drv[3][i] = (T)0;                        // sw_rad_night
+        a.drv[4][i] = (T)U(9, 0.1, 0.22);          // sw_albedo
+        a.drv[5][i] = (T)t_d;
+        a.drv[6][i] = (T)t_n;
+        a.drv[7][i] = (T)t_ann;
+        a.drv[8][i] = (T)tmin;
+        a.drv[9][i] = (T)vpd_d;
+        a.drv[10][i] = (T)vpd_n;
+        a.drv[11][i] = (T)U(10, 70000.0, 101340.0);  // pressure
+        a.drv[12][i] = (T)fpar;
+        a.drv[13][i] = (T)lai;
+    }
+}
+
+}  // namespace mod16

@@ -1,0 +1,378 @@
+// Per-pixel MOD16 Penman-Monteith stack as device functions (gfx950).
+//
+// Replaces the reference's instance path MOD16.evapotranspiration()
+// (reference mod16/__init__.py:675-793) and its callees. Two formulations:
+//
+//   et_pixel_exact<T>  keeps the reference's operation order, one IEEE
+//                      operation per numpy ufunc, contraction off. Used by
+//                      MOD16_MATH_EXACT and as the on-device cross-check of
+//                      the fast form at full raster sizes.
+//   et_pixel_fast<T>   the production form: every intermediate shared by the
+//                      three components is computed once per period, parallel
+//                      resistances are carried as conductances so each
+//                      component costs one reciprocal, pow/exp/log are the
+//                      FastMath forms. All predicates (np.where masks) are
+//                      kept with the reference's comparison semantics so that
+//                      zero/NaN masks are identical.
+#pragma once
+#include "mod16_math.hpp"
+
+namespace mod16 {
+
+template <typename T> struct PixelIn {
+    T lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_ann, tmin, vpd_d, vpd_n, pa,
+        fpar, lai;
+};
+
+// The 11 reference parameters (mod16/__init__.py:152-155) + derived terms.
+template <typename T> struct ClassPar {
+    T tmin_close, tmin_open, vpd_open, vpd_close, gl_sh, gl_wv, g_cut, csl,
+        rbl_min, rbl_max, beta;
+    // derived (filled by derive()): reciprocal ramp widths, rbl slope, 1/beta
+    T inv_dtmin, inv_dvpd, rbl_slope, inv_beta;
+    __device__ __forceinline__ void derive() {
+        inv_dtmin = T(1) / (tmin_open - tmin_close);
+        inv_dvpd = T(1) / (vpd_close - vpd_open);
+        rbl_slope = (rbl_max - rbl_min) / (vpd_close - vpd_open);
+        inv_beta = T(1) / beta;
+    }
+};
+#define MOD16_LUT_ROWS 15  // 11 parameters + 4 derived, LDS layout [row][16]
+
+template <typename T> struct PixelOut {
+    T canopy_d, soil_d, trans_d, canopy_n, soil_n, trans_n;
+};
+
+// Module constants, mod16/__init__.py:106-118, :869, :1157
+template <typename T> struct K {
+    static constexpr T sigma4 = T(4 * 5.67e-8);       // 4 * STEFAN_BOLTZMANN
+    static constexpr T cp = T(1013);                  // SPECIFIC_HEAT_CAPACITY_AIR
+    static constexpr T eps = T(0.622);                // MOL_WEIGHT_WET_DRY_RATIO_AIR
+    static constexpr T tiny = T(1e-7);
+    static constexpr T t0 = T(273.15);
+};
+
+// ===================================================================== exact
+// One function per reference method; `#pragma clang fp contract(off)` keeps
+// mul and add separate as numpy does.
+
+template <typename T> __device__ __forceinline__ T lhv_exact(T t) {
+#pragma clang fp contract(off)
+    return (T(2.501) - T(0.002361) * (t - K<T>::t0)) * T(1e6);  // :121
+}
+template <typename T> __device__ __forceinline__ T svp_exact(T t) {
+#pragma clang fp contract(off)
+    T tc = t - K<T>::t0;                                          // :1365-1367
+    return T(1e3 * 0.6108) * ExactMath<T>::exp((T(17.27) * tc) / (tc + T(237.3)));
+}
+template <typename T> __device__ __forceinline__ T svp_slope_exact(T t) {
+#pragma clang fp contract(off)
+    T s = svp_exact(t);                                           // :1395-1397
+    T d = (T(239.0) + t) - K<T>::t0;
+    return (T(17.38 * 239.0) * s) / (d * d);
+}
+template <typename T> __device__ __forceinline__ T gamma_exact(T pa, T t) {
+#pragma clang fp contract(off)
+    return (K<T>::cp * pa) / (lhv_exact(t) * K<T>::eps);          // :1288-1290
+}
+template <typename T> __device__ __forceinline__ T rho_exact(T t, T pa, T rh) {
+#pragma clang fp contract(off)
+    return (T(0.348444) * (pa / T(100)) -                         // :408-412
+            (rh * T(100)) * (T(0.00252) * (t - K<T>::t0) - T(0.020582))) / t;
+}
+template <typename T> __device__ __forceinline__ T rh_exact(T t, T vpd) {
+#pragma clang fp contract(off)
+    T esat = svp_exact(t);                                        // :669-673
+    T avp = esat - vpd;
+    T rh = avp / esat;
+    return (avp < T(0)) ? T(0) : ((rh > T(1)) ? T(1) : rh);
+}
+template <typename T> __device__ __forceinline__ T fwet_exact(T rh) {
+    return (rh < T(0.7)) ? T(0) : ExactMath<T>::pow(rh, T(4));    // :764
+}
+template <typename T> __device__ __forceinline__ T rcorr_exact(T pa, T t) {
+#pragma clang fp contract(off)
+    return (T(101300) / pa) * ExactMath<T>::pow(t / T(293.15), T(1.75));  // :771
+}
+template <typename T> __device__ __forceinline__ T rr_exact(T rho, T t) {
+#pragma clang fp contract(off)
+    return (rho * K<T>::cp) / (K<T>::sigma4 * ExactMath<T>::pow(t, T(3)));  // :947
+}
+
+// soil_heat_flux + radiation_soil, :963-1119
+template <typename T>
+__device__ __forceinline__ void rad_soil_exact(const PixelIn<T>& x, const ClassPar<T>& p,
+                                               T& rs_d, T& rs_n) {
+#pragma clang fp contract(off)
+    T a_d = x.sw_d * (T(1) - x.alb) + x.lw_d;                     // :1033
+    T a_n = x.lw_n;                                               // :1034
+    bool cond = (x.t_ann < T(273.15 + 25.0)) &&                   // :1103-1107
+                (x.t_ann >= (K<T>::t0 + p.tmin_close)) && ((x.t_d - x.t_n) >= T(5));
+    T g_d = cond ? (T(4.73) * (x.t_d - K<T>::t0)) - T(20.87) : T(0);  // :1110
+    g_d = (__builtin_fabs(g_d) > (T(0.39) * __builtin_fabs(a_d))) ? T(0.39) * a_d : g_d;
+    T g_n = cond ? (T(4.73) * (x.t_n - K<T>::t0)) - T(20.87) : T(0);
+    g_n = (__builtin_fabs(g_n) > (T(0.39) * __builtin_fabs(a_n))) ? T(0.39) * a_n : g_n;
+    g_d = ((a_d - g_d < T(0)) && (a_d > T(0))) ? a_d : g_d;       // :1039-1041
+    g_n = ((a_d > T(0)) && ((a_n - g_n) < (T(-0.5) * a_d)))       // :1042-1046
+              ? a_n + (T(0.5) * a_d) : g_n;
+    rs_d = (T(1) - x.fpar) * (a_d - g_d);                         // :1051-1052
+    rs_n = (T(1) - x.fpar) * (a_n - g_n);
+}
+
+// evaporation_wet_canopy, :866-961
+template <typename T>
+__device__ __forceinline__ T wet_canopy_exact(const ClassPar<T>& p, T pa, T t, T vpd, T lai,
+                                              T fpar, T rad_canopy, T lhv, T rh, T fwet) {
+#pragma clang fp contract(off)
+    const T tiny = K<T>::tiny;
+    fwet = (fwet == T(0)) ? fwet + tiny : fwet;                   // :934-935
+    lai = (lai == T(0)) ? lai + tiny : lai;
+    T s = svp_slope_exact(t);
+    T rho = rho_exact(t, pa, rh);
+    T r_h = T(1) / (p.gl_sh * lai * fwet);                        // :943
+    T r_e = T(1) / (p.gl_wv * lai * fwet);                        // :945
+    T r_r = rr_exact(rho, t);
+    T r_a = (r_h * r_r) / (r_h + r_r);                            // :951
+    T numer = fwet * ((s * rad_canopy) + (rho * K<T>::cp * fpar * vpd * T(1) / r_a));
+    T denom = s + ((pa * K<T>::cp * r_e) * T(1) / (lhv * K<T>::eps * r_a));
+    T evap = (numer < T(0)) ? T(0) : (numer / denom) / lhv;       // :959
+    return ((fwet <= tiny) || (lai <= tiny)) ? T(0) : evap;       // :961
+}
+
+// potential_soil_evaporation + evaporation_soil, :449-544, :795-864
+template <typename T>
+__device__ __forceinline__ T soil_exact(const ClassPar<T>& p, T pa, T t, T vpd, T fpar,
+                                        T rad_soil, T r_corr, T lhv, T rh, T fwet) {
+#pragma clang fp contract(off)
+    T s = svp_slope_exact(t);
+    T rho = rho_exact(t, pa, rh);
+    T gamma = gamma_exact(pa, t);
+    T r_r = rr_exact(rho, t);
+    T r_tot = (vpd <= p.vpd_open) ? p.rbl_min                      // :527-531
+              : ((vpd >= p.vpd_close) ? p.rbl_max
+                 : p.rbl_max - ((p.rbl_max - p.rbl_min) * (p.vpd_close - vpd)) /
+                                   (p.vpd_close - p.vpd_open));
+    r_tot = r_tot / r_corr;                                       // :533
+    T r_as = (r_tot * r_r) / (r_tot + r_r);                       // :535
+    T numer = (s * rad_soil) + (rho * K<T>::cp * (T(1) - fpar) * (vpd / r_as));
+    T denom = s + gamma * (r_tot / r_as);
+    T sat = (numer * fwet) / denom;                               // :541-543
+    T unsat = (numer * (T(1) - fwet)) / denom;
+    T e = (sat < T(0)) ? T(0) : sat;                              // :858-861
+    e = e + ((unsat < T(0)) ? T(0) : unsat * ExactMath<T>::pow(rh, vpd / p.beta));
+    return e / lhv;                                               // :864
+}
+
+// mod17.linear_constraint (reference README.md:351-369)
+template <typename T> __device__ __forceinline__ T ramp_up_exact(T x, T lo, T hi) {
+#pragma clang fp contract(off)
+    return (x >= hi) ? T(1) : ((x < lo) ? T(0) : (x - lo) / (hi - lo));
+}
+template <typename T> __device__ __forceinline__ T ramp_down_exact(T x, T lo, T hi) {
+#pragma clang fp contract(off)
+    return (x >= hi) ? T(0) : ((x < lo) ? T(1) : T(1) - (x - lo) / (hi - lo));
+}
+
+// surface_conductance + transpiration, :1121-1258
+template <typename T, bool DAY>
+__device__ __forceinline__ T transpiration_exact(const ClassPar<T>& p, T pa, T t, T vpd, T lai,
+                                                 T fpar, T rad_canopy, T tmin, T r_corr,
+                                                 T lhv, T rh, T fwet) {
+#pragma clang fp contract(off)
+    const T tiny = K<T>::tiny;
+    T s = svp_slope_exact(t);
+    T rho = rho_exact(t, pa, rh);
+    T gamma = gamma_exact(pa, t);
+    T r_r = rr_exact(rho, t);
+    T g_surf = T(0);
+    if (DAY) {
+        T gs = p.csl * ramp_up_exact(tmin - K<T>::t0, p.tmin_close, p.tmin_open) *
+               ramp_down_exact(vpd, p.vpd_open, p.vpd_close);    // :1148-1150
+        g_surf = gs / r_corr;                                     // :1237
+    }
+    T g_cut = p.g_cut / r_corr;                                   // :1238
+    T gl_sh = p.gl_sh * lai * (T(1) - fwet);                      // :1242
+    T g = (gl_sh * (g_surf + g_cut)) / (gl_sh + g_surf + g_cut);  // :1243
+    T g_canopy = ((lai > T(0)) && ((T(1) - fwet) > T(0))) ? g : tiny;  // :1245
+    T r_dry = (T(1) / p.gl_sh * r_r) / (T(1) / p.gl_sh + r_r);    // :1248
+    rad_canopy = (rad_canopy < T(0)) ? T(0) : rad_canopy;         // :1251
+    T tr = (T(1) - fwet) * ((s * rad_canopy) + (rho * K<T>::cp * fpar * (vpd / r_dry)));
+    tr = tr / (s + gamma * (T(1) + (T(1) / g_canopy) / r_dry));   // :1255
+    return (g_canopy <= tiny) ? T(0) : tr / lhv;                  // :1258
+}
+
+template <typename T>
+__device__ __forceinline__ PixelOut<T> et_pixel_exact(const PixelIn<T>& x, const ClassPar<T>& p) {
+#pragma clang fp contract(off)
+    PixelOut<T> o;
+    T rs_d, rs_n;
+    rad_soil_exact(x, p, rs_d, rs_n);                             // :737
+    {   // day, :751-792
+        T rad_net = x.sw_d * (T(1) - x.alb) + x.lw_d;
+        T rad_c = x.fpar * rad_net;
+        T rh = rh_exact(x.t_d, x.vpd_d);
+        T fw = fwet_exact(rh);
+        T lhv = lhv_exact(x.t_d);
+        T rc = rcorr_exact(x.pa, x.t_d);
+        o.canopy_d = wet_canopy_exact(p, x.pa, x.t_d, x.vpd_d, x.lai, x.fpar, rad_c, lhv, rh, fw);
+        o.soil_d = soil_exact(p, x.pa, x.t_d, x.vpd_d, x.fpar, rs_d, rc, lhv, rh, fw);
+        o.trans_d = transpiration_exact<T, true>(p, x.pa, x.t_d, x.vpd_d, x.lai, x.fpar, rad_c,
+                                                 x.tmin, rc, lhv, rh, fw);
+    }
+    {   // night
+        T rad_net = x.sw_n * (T(1) - x.alb) + x.lw_n;
+        T rad_c = x.fpar * rad_net;
+        T rh = rh_exact(x.t_n, x.vpd_n);
+        T fw = fwet_exact(rh);
+        T lhv = lhv_exact(x.t_n);
+        T rc = rcorr_exact(x.pa, x.t_n);
+        o.canopy_n = wet_canopy_exact(p, x.pa, x.t_n, x.vpd_n, x.lai, x.fpar, rad_c, lhv, rh, fw);
+        o.soil_n = soil_exact(p, x.pa, x.t_n, x.vpd_n, x.fpar, rs_n, rc, lhv, rh, fw);
+        o.trans_n = transpiration_exact<T, false>(p, x.pa, x.t_n, x.vpd_n, x.lai, x.fpar, rad_c,
+                                                  x.tmin, rc, lhv, rh, fw);
+    }
+    return o;
+}
+
+// ====================================================================== fast
+// Quantities that do not depend on the period (day / night).
+template <typename T> struct PixelShared {
+    T oma;        // 1 - albedo
+    T omf;        // 1 - fpar
+    T p_rel;      // pressure / 101300
+    T k_p;        // Cp * pressure / eps  (= gamma * lhv)
+    T p_mbar_k;   // 0.348444 * pressure / 100
+    T l_wet;      // lai with 0 -> tiny (wet canopy, :935)
+    T glsh_l, glwv_l;   // gl_sh * l_wet, gl_wv * l_wet
+    T glsh_lai;   // gl_sh * lai (transpiration, :1242)
+    T m_tmin;     // Tmin ramp (day only)
+    bool lai_pos, lai_tiny;
+};
+
+template <typename T, bool DAY>
+__device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<T>& p,
+                                            const PixelShared<T>& sh, T t, T vpd, T rad_net,
+                                            T rad_soil, T& canopy, T& soil, T& trans) {
+    typedef FastMath<T> M;
+    const T tiny = K<T>::tiny;
+    const T cp = K<T>::cp;
+    // -- humidity, :646-673 and :763-764
+    T tc = t - K<T>::t0;
+    T esat = T(1e3 * 0.6108) * M::exp((T(17.27) * tc) * M::rcp(tc + T(237.3)));
+    T avp = esat - vpd;
+    T rh = avp * M::rcp(esat);
+    rh = (avp < T(0)) ? T(0) : ((rh > T(1)) ? T(1) : rh);
+    T rh2 = rh * rh;
+    T fwet = (rh < T(0.7)) ? T(0) : rh2 * rh2;
+    T omw = T(1) - fwet;
+    // -- slope of the SVP curve (:1395-1397), latent heat (:121)
+    T ta = (T(239.0) + t) - K<T>::t0;
+    T rta = M::rcp(ta);
+    T s = (T(17.38 * 239.0) * esat) * (rta * rta);
+    T lhv = (T(2.501) - T(0.002361) * tc) * T(1e6);
+    T slhv = s * lhv;
+    // -- 1 / r_corr = (P / 101300) (T / 293.15)^-1.75, :771
+    T inv_rcorr = sh.p_rel * M::pow_m1p75(t * T(1.0 / 293.15));
+    // -- air density (:408-412) and radiative conductance 1/r_r (:947) from
+    //    one reciprocal: rho = N / T, 1/r_r = 4 sigma T^4 / (Cp N)
+    T nn = sh.p_mbar_k - (rh * T(100)) * (T(0.00252) * tc - T(0.020582));
+    T u = M::rcp(nn * t);
+    T rho_cp = cp * ((nn * nn) * u);
+    T t2 = t * t;
+    T g_rr = (K<T>::sigma4 / cp) * ((t2 * t2) * t) * u;
+    T rcfv = rho_cp * vpd;             // rho Cp vpd
+
+    // -- wet canopy, :866-961 in conductances:
+    //    1/r_a = g_h + 1/r_r ; evap = numer g_e / ((s lhv) g_e + k_p / r_a)
+    {
+        T fw = (fwet == T(0)) ? tiny : fwet;                       // :934
+        T g_h = sh.glsh_l * fw;
+        T g_e = sh.glwv_l * fw;
+        T g_a = g_h + g_rr;
+        T numer = fw * __builtin_fma(rcfv * x.fpar, g_a, s * (x.fpar * rad_net));
+        T den = __builtin_fma(slhv, g_e, sh.k_p * g_a);
+        T evap = (numer * g_e) * M::rcp(den);
+        evap = (numer < T(0)) ? T(0) : evap;                       // :959
+        canopy = ((fw <= tiny) || sh.lai_tiny) ? T(0) : evap;      // :961
+    }
+    // -- bare soil, :449-544 and :795-864
+    {
+        T r0 = (vpd <= p.vpd_open) ? p.rbl_min
+               : ((vpd >= p.vpd_close) ? p.rbl_max
+                  : __builtin_fma(-(p.vpd_close - vpd), p.rbl_slope, p.rbl_max));
+        T r_tot = r0 * inv_rcorr;                                  // :533
+        T w = __builtin_fma(r_tot, g_rr, T(1));                    // r_tot / r_as
+        T num = __builtin_fma((s * rad_soil), r_tot, (rcfv * sh.omf) * w);
+        T den = r_tot * __builtin_fma(sh.k_p, w, slhv);
+        T q = num * M::rcp(den);                                   // numer/denom/lhv
+        T sat = q * fwet;
+        T unsat = q * omw;
+        T pw = M::pow01(rh, vpd * p.inv_beta);                     // :861
+        T e = (sat < T(0)) ? T(0) : sat;
+        soil = e + ((unsat < T(0)) ? T(0) : unsat * pw);
+    }
+    // -- transpiration, :1152-1258, with g_canopy = P1 / S1 kept as a ratio
+    {
+        T g_s = T(0);
+        if (DAY) {
+            T m_vpd = (vpd >= p.vpd_close) ? T(0)
+                      : ((vpd < p.vpd_open) ? T(1)
+                         : T(1) - (vpd - p.vpd_open) * p.inv_dvpd);
+            g_s = ((p.csl * sh.m_tmin) * m_vpd) * inv_rcorr;       // :1237
+        }
+        T gsc = g_s + p.g_cut * inv_rcorr;                         // :1238
+        T g_bl = sh.glsh_lai * omw;                                // :1242
+        T p1 = g_bl * gsc;
+        T s1 = g_bl + gsc;
+        bool open = sh.lai_pos && (omw > T(0));                    // :1245
+        // g_canopy <= tiny  <=>  P1 <= tiny S1 (S1 > 0); NaN compares false
+        bool shut = !open || (p1 <= tiny * s1);                    // :1258
+        T g_d = p.gl_sh + g_rr;                                    // 1 / r_a_dry, :1248
+        T rad_c = x.fpar * rad_net;
+        rad_c = (rad_c < T(0)) ? T(0) : rad_c;                     // :1251
+        T num = (omw * __builtin_fma(rcfv * x.fpar, g_d, s * rad_c)) * p1;
+        T den = __builtin_fma(slhv, p1, sh.k_p * __builtin_fma(g_d, s1, p1));
+        T tr = num * M::rcp(den);
+        trans = shut ? T(0) : tr;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const ClassPar<T>& p) {
+    PixelOut<T> o;
+    PixelShared<T> sh;
+    sh.oma = T(1) - x.alb;
+    sh.omf = T(1) - x.fpar;
+    // -- radiation received by the soil, :963-1119 (predicates verbatim)
+    T a_d = __builtin_fma(x.sw_d, sh.oma, x.lw_d);
+    T a_n = x.lw_n;
+    bool cond = (x.t_ann < T(273.15 + 25.0)) && (x.t_ann >= (K<T>::t0 + p.tmin_close)) &&
+                ((x.t_d - x.t_n) >= T(5));
+    T g_d = cond ? (T(4.73) * (x.t_d - K<T>::t0)) - T(20.87) : T(0);
+    g_d = (__builtin_fabs(g_d) > (T(0.39) * __builtin_fabs(a_d))) ? T(0.39) * a_d : g_d;
+    T g_n = cond ? (T(4.73) * (x.t_n - K<T>::t0)) - T(20.87) : T(0);
+    g_n = (__builtin_fabs(g_n) > (T(0.39) * __builtin_fabs(a_n))) ? T(0.39) * a_n : g_n;
+    g_d = ((a_d - g_d < T(0)) && (a_d > T(0))) ? a_d : g_d;
+    g_n = ((a_d > T(0)) && ((a_n - g_n) < (T(-0.5) * a_d))) ? a_n + (T(0.5) * a_d) : g_n;
+    T rs_d = sh.omf * (a_d - g_d);
+    T rs_n = sh.omf * (a_n - g_n);
+    // -- period-independent terms
+    sh.p_rel = x.pa * T(1.0 / 101300.0);
+    sh.k_p = x.pa * T(1013.0 / 0.622);
+    sh.p_mbar_k = x.pa * T(0.348444 / 100.0);
+    sh.l_wet = (x.lai == T(0)) ? K<T>::tiny : x.lai;
+    sh.lai_tiny = sh.l_wet <= K<T>::tiny;
+    sh.lai_pos = x.lai > T(0);
+    sh.glsh_l = p.gl_sh * sh.l_wet;
+    sh.glwv_l = p.gl_wv * sh.l_wet;
+    sh.glsh_lai = p.gl_sh * x.lai;
+    T tm = x.tmin - K<T>::t0;
+    sh.m_tmin = (tm >= p.tmin_open) ? T(1)
+                : ((tm < p.tmin_close) ? T(0) : (tm - p.tmin_close) * p.inv_dtmin);
+    period_fast<T, true>(x, p, sh, x.t_d, x.vpd_d, a_d, rs_d, o.canopy_d, o.soil_d, o.trans_d);
+    T rn_n = __builtin_fma(x.sw_n, sh.oma, x.lw_n);
+    period_fast<T, false>(x, p, sh, x.t_n, x.vpd_n, rn_n, rs_n, o.canopy_n, o.soil_n, o.trans_n);
+    return o;
+}
+
+}  // namespace mod16

@@ -1,0 +1,167 @@
+'''
+Device-resident forward run for large rasters.
+
+``RasterEngine`` is the zero-copy, asynchronous form of
+``mod16_amd.evapotranspiration_raster``: drivers, class raster and outputs are
+``torch`` tensors already in HBM, the kernel is enqueued on the current HIP
+stream through the C ABI (``mod16_et_*`` with ``where = MOD16_DEVICE``) and
+nothing is copied. PyTorch is used for device memory and streams only.
+'''
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+#: algorithmic HBM bytes per pixel: 14 driver loads +
+#: 1 class byte + 2 stores
+BYTES_PER_PIXEL = {'float64': 14 * 8 + 1 + 2 * 8, 'float32': 14 * 4 + 1 + 2 * 4}
+DIAG_FIELDS = ('sum_day', 'sum_night', 'n_valid_day', 'n_valid_night',
+               'n_nan_day', 'n_nan_night', 'max_day', 'max_night')
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class RasterEngine(object):
+    '''
+    Parameters
+    ----------
+    table : numpy.ndarray
+        (13, 11) BPLUT table (``mod16_amd.utils.bplut_table``)
+    device : int
+        GPU index (Default: the current torch device)
+    dtype : str
+        'float64' (default) or 'float32'
+    math : int
+        ``_lib.MATH_FAST`` (default) or ``_lib.MATH_EXACT``
+    '''
+
+    def __init__(self, table, device=None, dtype='float64', math=_lib.MATH_FAST):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _lib.Mod16Error(
+                _lib.ERR_NO_DEVICE, 'RasterEngine needs an MI355X; there is no CPU fallback')
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.ctx = _lib.context(self.device)
+        self.ctx.set_bplut(table)
+        self.np_dtype = np.dtype(dtype)
+        self.dtype = {'float64': torch.float64, 'float32': torch.float32}[self.np_dtype.name]
+        self.math = math
+        self.bytes_per_pixel = BYTES_PER_PIXEL[self.np_dtype.name]
+
+    # ---------------------------------------------------------- helpers
+    def _dev(self):
+        return _torch().device('cuda', self.device)
+
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _check_tensor(self, t, dtype, n, what):
+        torch = _torch()
+        if not isinstance(t, torch.Tensor) or not t.is_cuda or t.device.index != self.device:
+            raise TypeError('%s must be a tensor on cuda:%d' % (what, self.device))
+        if t.dtype != dtype or not t.is_contiguous():
+            raise TypeError('%s must be contiguous %s' % (what, dtype))
+        if t.numel() != n:
+            raise ValueError('%s has %d elements, expected %d' % (what, t.numel(), n))
+        return t.data_ptr()
+
+    def empty(self, n, count=1):
+        torch = _torch()
+        return [torch.empty(n, dtype=self.dtype, device=self._dev()) for _ in range(count)]
+
+    def _marshal_drivers(self, drivers, n):
+        torch = _torch()
+        if len(drivers) != _lib.N_DRIVERS:
+            raise ValueError('expected 14 drivers')
+        keep, ptrs, strides = [], [], []
+        for k, d in enumerate(drivers):
+            if isinstance(d, torch.Tensor) and d.numel() != 1:
+                ptrs.append(self._check_tensor(d, self.dtype, n, 'driver %d' % k))
+                strides.append(1)
+                keep.append(d)
+            else:       # broadcast scalar
+                s = torch.as_tensor(d, dtype=self.dtype).reshape(1).to(self._dev())
+                keep.append(s)
+                ptrs.append(s.data_ptr())
+                strides.append(0)
+        return keep, ptrs, strides
+
+    # -------------------------------------------------------------- API
+    def synth(self, n, seed=16, step=0, pixel_offset=0, out=None):
+        '''Fill (or allocate) the class raster and the 14 driver tensors for
+        global pixels [pixel_offset, pixel_offset + n) on the device
+        (``mod16_synth_*``). Returns ``(cls, drivers)``.'''
+        torch = _torch()
+        if out is None:
+            cls = torch.empty(n, dtype=torch.uint8, device=self._dev())
+            drivers = self.empty(n, _lib.N_DRIVERS)
+        else:
+            cls, drivers = out
+        fn = self.ctx.lib.mod16_synth_f32 if self.np_dtype == np.float32 \
+            else self.ctx.lib.mod16_synth_f64
+        ptrs = [self._check_tensor(d, self.dtype, n, 'driver') for d in drivers]
+        self.ctx.check(fn(
+            self.ctx.handle, int(seed), int(step), int(pixel_offset), int(n),
+            self._check_tensor(cls, torch.uint8, n, 'cls'),
+            _lib.ptr_array(ptrs), self._stream()))
+        return cls, drivers
+
+    def run(self, cls, drivers, out_day=None, out_night=None, out_sep=None):
+        '''Enqueue the fused ET kernel on the current stream; returns
+        ``(day, night)`` tensors (allocated unless given). Asynchronous: call
+        ``check()`` (or synchronise the stream) before trusting the data.'''
+        torch = _torch()
+        n = cls.numel()
+        cptr = self._check_tensor(cls, torch.uint8, n, 'cls')
+        keep, dptr, dstride = self._marshal_drivers(drivers, n)
+        if out_day is None and out_sep is None:
+            out_day, out_night = self.empty(n, 2)
+        pd = self._check_tensor(out_day, self.dtype, n, 'out_day') if out_day is not None else None
+        pn = self._check_tensor(out_night, self.dtype, n, 'out_night') if out_night is not None else None
+        sep = None
+        if out_sep is not None:
+            sep = [self._check_tensor(t, self.dtype, n, 'out_sep') if t is not None else None
+                   for t in out_sep]
+        self.ctx.et(self.np_dtype, cptr, dptr, dstride, None, None, n, pd, pn, sep,
+                    flags=self.math, where=_lib.DEVICE, stream=self._stream())
+        return out_day, out_night
+
+    def check(self):
+        '''Synchronise and raise deferred errors (IndexError for a class code
+        >= 13, as the reference's numpy gather would).'''
+        self.ctx.check_status(self._stream())
+
+    def diagnostics(self, day, night, out=None):
+        '''Deterministic reduction of a (day, night) pair on the device ->
+        float64 tensor of 8 (``DIAG_FIELDS``), asynchronous.'''
+        torch = _torch()
+        n = day.numel()
+        if out is None:
+            out = torch.empty(8, dtype=torch.float64, device=self._dev())
+        fn = self.ctx.lib.mod16_reduce_diag_f32 if self.np_dtype == np.float32 \
+            else self.ctx.lib.mod16_reduce_diag_f64
+        self.ctx.check(fn(
+            self.ctx.handle, self._check_tensor(day, self.dtype, n, 'day'),
+            self._check_tensor(night, self.dtype, n, 'night'), n, None,
+            self._check_tensor(out, torch.float64, 8, 'out'), self._stream()))
+        return out
+
+    def time_kernel(self, cls, drivers, out_day, out_night, launches=10):
+        '''Mean milliseconds per launch of the fused kernel, measured with HIP
+        events on the stream the kernel runs on (``mod16_time_et``).'''
+        torch = _torch()
+        n = cls.numel()
+        cptr = self._check_tensor(cls, torch.uint8, n, 'cls')
+        keep, dptr, dstride = self._marshal_drivers(drivers, n)
+        ms = C.c_float(0)
+        self.ctx.check(self.ctx.lib.mod16_time_et(
+            self.ctx.handle, int(self.np_dtype == np.float32), cptr,
+            _lib.ptr_array(dptr), _lib.i64_array(dstride), None, None, n,
+            self._check_tensor(out_day, self.dtype, n, 'out_day'),
+            self._check_tensor(out_night, self.dtype, n, 'out_night'), None,
+            int(self.math), int(launches), self._stream(), C.byref(ms)))
+        return ms.value

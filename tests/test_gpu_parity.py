@@ -1,0 +1,213 @@
+"""GPU parity: the HIP path (through the C ABI, via mod16_amd) against the
+golden vectors of the reference and against the oracle on seeded inputs.
+
+Tolerances (float64): north_star asks for 1e-5 relative. The tests hold the
+worst pixel of the EXACT kernel (reference operation order) to 1e-10 and of the
+FAST kernel (production) to 1e-8, both with identical NaN and exact-zero
+masks; the worst pixels are cancellation cases (s*A_soil against the
+aerodynamic term), where one ulp of exp() is amplified, the typical pixel
+agrees to ~1e-15 (medians are asserted in test_conus_tile_1200)."""
+import numpy as np
+import pytest
+
+from oracle import mod16_oracle as oracle
+from oracle import synth
+from parity import assert_parity, rel_err
+
+pytestmark = pytest.mark.gpu
+
+RTOL = {'fast': 1e-8, 'exact': 1e-10}
+MEDIAN = {'fast': 1e-13, 'exact': 1e-14}
+SEP = ('canopy_day', 'soil_day', 'trans_day',
+       'canopy_night', 'soil_night', 'trans_night')
+
+
+@pytest.fixture(scope='module')
+def m16():
+    import mod16_amd
+    return mod16_amd
+
+
+def math_flag(m16, mode):
+    return {'fast': m16._lib.MATH_FAST, 'exact': m16._lib.MATH_EXACT}[mode]
+
+
+def model(m16, params, mode):
+    m = m16.MOD16(dict(zip(oracle.PARAM_NAMES, params)))
+    m.math = math_flag(m16, mode)
+    return m
+
+
+def check_sep(res, f, rtol, what):
+    flat = list(res[0]) + list(res[1])
+    return max(assert_parity(np.asarray(got), f[name], rtol, what + ':' + name)
+               for name, got in zip(SEP, flat))
+
+
+@pytest.mark.parametrize('mode', ['fast', 'exact'])
+def test_f1_scalar_set(m16, golden, mode):
+    f = golden('f1_tests_scalars')
+    m = model(m16, f['params'], mode)
+    day, night = m.evapotranspiration(*[float(v) for v in f['drivers']])
+    assert np.ndim(day) == 0 and np.ndim(night) == 0
+    assert_parity(np.asarray(day), f['day'], RTOL[mode], 'day')
+    assert_parity(np.asarray(night), f['night'], RTOL[mode], 'night')
+    check_sep(m.evapotranspiration(*f['drivers'], separate=True), f, RTOL[mode], 'f1')
+    # the reference's own assertion, tests/tests.py:88-90
+    lhv = lambda t: (2.501 - 0.002361 * (t - 273.15)) * 1e6
+    assert round(float(day * lhv(293) + night * lhv(290)), 1) == 41.0
+
+
+@pytest.mark.parametrize('mode', ['fast', 'exact'])
+def test_f2_verify_three_pixels(m16, golden, mode):
+    f = golden('f2_verify_3pixel')
+    m = model(m16, f['params'], mode)
+    drv = [f['drv_' + k] for k in oracle.DRIVER_NAMES]
+    res = m.evapotranspiration(*drv, f_wet=np.array((0, 0.4, 0.8)), separate=True)
+    check_sep(res, f, RTOL[mode], 'f2')
+    assert res[0][0].shape == (3,)
+
+
+@pytest.mark.parametrize('mode', ['fast', 'exact'])
+def test_f4_edge_cases(m16, golden, mode):
+    f = golden('f4_edge_cases')
+    m = model(m16, f['params'], mode)
+    drv = list(f['drivers'])
+    res = m.evapotranspiration(*drv, separate=True)
+    flat = list(res[0]) + list(res[1])
+    for i, case in enumerate(f['names']):
+        for name, got in zip(SEP, flat):
+            assert_parity(got[i:i + 1], f[name][i:i + 1], RTOL[mode],
+                          '%s:%s' % (case, name))
+    day, night = m.evapotranspiration(*drv)
+    assert_parity(day, f['day'], RTOL[mode], 'day')
+    assert_parity(night, f['night'], RTOL[mode], 'night')
+
+
+@pytest.mark.parametrize('mode', ['fast', 'exact'])
+def test_f4_invalid_classes_give_nan(m16, golden, mode):
+    f = golden('f4_edge_cases')
+    day, night = m16.evapotranspiration_raster(
+        f['cls_case_table'], f['cls_case_cls'], *list(f['cls_case_drivers']),
+        math=math_flag(m16, mode))
+    assert_parity(day, f['cls_case_day'], RTOL[mode], 'day')
+    assert_parity(night, f['cls_case_night'], RTOL[mode], 'night')
+
+
+@pytest.mark.parametrize('mode', ['fast', 'exact'])
+def test_f3_multiclass_raster(m16, golden, mode):
+    f = golden('f3_random64_f64')
+    drv = list(f['drivers'])
+    day, night = m16.evapotranspiration_raster(
+        f['table'], f['cls'], *drv, math=math_flag(m16, mode))
+    assert day.shape == (64, 64) and day.dtype == np.float64
+    e1 = assert_parity(day, f['day'], RTOL[mode], 'day')
+    e2 = assert_parity(night, f['night'], RTOL[mode], 'night')
+    res = m16.evapotranspiration_raster(
+        f['table'], f['cls'], *drv, separate=True, math=math_flag(m16, mode))
+    e3 = check_sep(res, f, RTOL[mode], 'f3')
+    print('\n[f3 %s] max rel err: day %.2e night %.2e components %.2e' % (mode, e1, e2, e3))
+
+
+@pytest.mark.parametrize('mode', ['fast', 'exact'])
+def test_f3_per_pixel_parameter_arrays(m16, golden, mode):
+    """The reference idiom itself: MOD16({k: bplut[k][cls]}) with array
+    parameters must equal the in-kernel class look-up."""
+    f = golden('f3_random64_f64')
+    params = {k: f['table'][:, j][f['cls']] for j, k in enumerate(oracle.PARAM_NAMES)}
+    m = m16.MOD16(params)
+    m.math = math_flag(m16, mode)
+    day, night = m.evapotranspiration(*list(f['drivers']))
+    assert_parity(day, f['day'], RTOL[mode], 'day')
+    assert_parity(night, f['night'], RTOL[mode], 'night')
+
+
+def test_f5_float32_raster(m16, golden):
+    """float32 in -> float32 out, float32 arithmetic; compared with the
+    reference's own float32 run. numpy-in-f32 vs f64 itself differs by up to
+    1.6e-2 at discontinuities, so: masks identical except at
+    branch flips, 99th percentile of the relative error below 1e-4."""
+    f = golden('f5_random64_f32')
+    drv = list(f['drivers'])
+    day, night = m16.evapotranspiration_raster(
+        f['table'], f['cls'], *drv)
+    assert day.dtype == np.float32 and night.dtype == np.float32
+    for got, want in ((day, f['day']), (night, f['night'])):
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        ok = np.isfinite(want) & (want != 0)
+        err = np.abs(got[ok].astype(np.float64) - want[ok]) / np.abs(want[ok])
+        assert np.percentile(err, 99) < 1e-4, np.percentile(err, 99)
+        assert np.median(err) < 5e-6, np.median(err)
+
+
+def test_class_code_out_of_range_raises(m16, golden):
+    f = golden('f3_random64_f64')
+    cls = f['cls'].copy()
+    cls[3, 5] = 13
+    with pytest.raises(IndexError):
+        m16.evapotranspiration_raster(f['table'], cls, *list(f['drivers']))
+    # the context stays usable and the flag is cleared
+    day, _ = m16.evapotranspiration_raster(f['table'], f['cls'], *list(f['drivers']))
+    assert_parity(day, f['day'], RTOL['fast'], 'day after error')
+
+
+def test_missing_parameter_is_keyerror(m16):
+    with pytest.raises(KeyError):
+        m16.MOD16({'tmin_close': -8})
+
+
+@pytest.mark.parametrize('n', [0, 1, 2, 3, 255, 257, 4099, 1000003])
+def test_ragged_sizes(m16, golden, n):
+    """Empty, odd and non-multiple-of-block sizes take the scalar tail path."""
+    f = golden('f3_random64_f64')
+    bplut = {k: f['table'][:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    cls, drv = synth.drivers((n,), seed=n)
+    day, night = m16.evapotranspiration_raster(f['table'], cls, *drv)
+    assert day.shape == (n,)
+    if n:
+        wd, wn = oracle.evapotranspiration_raster(bplut, cls, *drv)
+        assert_parity(day, wd, RTOL['fast'], 'day')
+        assert_parity(night, wn, RTOL['fast'], 'night')
+
+
+def test_broadcast_scalars_and_rows(m16, golden):
+    """Scalars (stride 0) and a (N,) row against (T, N) drivers, as the
+    reference's notebooks call it (pressure, temp_annual per site)."""
+    f = golden('f1_tests_scalars')
+    p = dict(zip(oracle.PARAM_NAMES, f['params']))
+    _, drv = synth.drivers((5, 40), seed=3, special=False)
+    drv[3] = 0                       # sw_rad_night scalar
+    drv[11] = drv[11][0]             # pressure (N,)
+    drv[7] = drv[7][0]               # temp_annual (N,)
+    drv[1] = -30.0                   # lw_net_night scalar
+    day, night = m16.MOD16(p).evapotranspiration(*drv)
+    wd, wn = oracle.evapotranspiration(p, *drv)
+    assert day.shape == (5, 40)
+    assert_parity(day, wd, RTOL['fast'], 'day')
+    assert_parity(night, wn, RTOL['fast'], 'night')
+
+
+@pytest.mark.parametrize('mode', ['fast', 'exact'])
+def test_conus_tile_1200(m16, golden, mode):
+    """BASELINE.json configs[1]: 1200 x 1200 tile, float64, vs the oracle."""
+    f = golden('f3_random64_f64')
+    bplut = {k: f['table'][:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    cls, drv = synth.drivers((1200, 1200), seed=16)
+    res = m16.evapotranspiration_raster(
+        f['table'], cls, *drv, separate=True, math=math_flag(m16, mode))
+    want = oracle.evapotranspiration_raster(bplut, cls, *drv, separate=True)
+    errs = []
+    for a, b, name in zip(list(res[0]) + list(res[1]),
+                          list(want[0]) + list(want[1]), SEP):
+        errs.append(assert_parity(a, b, RTOL[mode], name))
+        ok = np.isfinite(b) & (b != 0)
+        med = np.median(np.abs(a[ok] - b[ok]) / np.abs(b[ok]))
+        assert med < MEDIAN[mode], (name, med)
+    day, night = m16.evapotranspiration_raster(
+        f['table'], cls, *drv, math=math_flag(m16, mode))
+    wd, wn = oracle.evapotranspiration_raster(bplut, cls, *drv)
+    e_d = assert_parity(day, wd, RTOL[mode], 'day')
+    e_n = assert_parity(night, wn, RTOL[mode], 'night')
+    print('\n[1200x1200 %s] max rel err: components %.2e day %.2e night %.2e'
+          % (mode, max(errs), e_d, e_n))
+    assert max(e_d, e_n) < 1e-5   # the north_star bar
