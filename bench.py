@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""
+bench.py -- the MOD16 forward-run benchmark (BASELINE.json metric: pixels/s and
+achieved HBM GB/s on the 43200 x 21600 global ET grid, float64).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" is one pass of the hot path over the (synthetic, already
+HBM-resident) drivers of one time step: the fused ET kernel over this rank's
+row band, the deterministic diagnostics reduction of its outputs, and -- for
+N > 1 -- the RCCL all-reduce of the 8-double diagnostics vector. The global
+grid is fixed and cut into N row bands (one process per GPU), so total work is
+fixed: "scaling": "strong".
+
+Rank 0 prints ONE JSON line. Besides the contract fields it carries
+  roofline      dominant kernel (fused ET) vs the 8 TB/s HBM peak; `achieved`
+                = 129 B/pixel (float64) x pixels per launch / mean launch time,
+                timed with HIP events on the launch stream (mod16_time_et);
+  cpu_baseline  the numpy oracle (reference-shaped port) timed on this box's
+                host cores on 1200 x 1200 tiles of the same synthetic workload
+                (N = 1 only);
+  parity        GPU outputs vs the oracle on a 1200 x 1200 tile copied back.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md)
+TILE = (1200, 1200)           # BASELINE.json configs[1], the CPU sample unit
+SEED = 16
+
+
+def cpu_tile_seconds(reps):
+    """Worker of the CPU baseline: time `reps` oracle runs on one tile."""
+    import numpy as np
+    from oracle import mod16_oracle as oracle
+    from oracle import synth
+    from mod16_amd.utils import restore_bplut, bplut_table
+    from mod16_amd.models import COLLECTION61_BPLUT
+    table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    cls, drv = synth.drivers(TILE, seed=SEED + os.getpid() % 7)
+    best = 1e30
+    t_all = time.perf_counter()
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        oracle.evapotranspiration_raster(bplut, cls, *drv)
+        best = min(best, time.perf_counter() - t0)
+    return best, time.perf_counter() - t_all
+
+
+def cpu_baseline(max_workers):
+    """The oracle on host cores: one process (numpy's element-wise loops are
+    single-threaded), then a pool with one tile per core. Runs before this
+    process touches the GPU; workers are spawned, never forked."""
+    import multiprocessing as mp
+    tile_px = TILE[0] * TILE[1]
+    best1, _ = cpu_tile_seconds(3)
+    cores = max(1, min(max_workers, os.cpu_count() or 1))
+    out = {
+        'value': tile_px / best1, 'unit': 'pixels/s', 'cores': 1, 'kind': 'port',
+        'sample': '3 runs of a 1200x1200 float64 tile (best), numpy oracle incl. per-pixel BPLUT gather',
+        'seconds_per_tile': best1,
+    }
+    if cores > 1:
+        reps = 2
+        with mp.get_context('spawn').Pool(cores) as pool:
+            t0 = time.perf_counter()
+            res = pool.map(cpu_tile_seconds, [reps] * cores)
+            wall = time.perf_counter() - t0
+        busy = max(r[1] for r in res)       # excludes interpreter start-up
+        out['pool'] = {'value': cores * reps * tile_px / busy, 'cores': cores,
+                       'sample': '%d workers x %d tiles of 1200x1200' % (cores, reps),
+                       'wall_s': wall}
+    out['global_grid_seconds_1core'] = 43200 * 21600 / out['value']
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--rows', type=int, default=21600, help='global raster rows')
+    ap.add_argument('--cols', type=int, default=43200, help='global raster columns')
+    ap.add_argument('--dtype', default='float64', choices=['float64', 'float32'])
+    ap.add_argument('--math', default='fast', choices=['fast', 'exact'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--cpu-workers', type=int, default=16)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run '
+                     '--nproc-per-node %d' % (args.gpus, args.gpus))
+        args.gpus = world
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_workers)     # before any GPU initialisation
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from mod16_amd import _lib
+    from mod16_amd import dist as tiles
+    from mod16_amd.raster import RasterEngine
+    from mod16_amd.utils import restore_bplut, bplut_table
+    from mod16_amd.models import COLLECTION61_BPLUT
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
+    math = _lib.MATH_FAST if args.math == 'fast' else _lib.MATH_EXACT
+    eng = RasterEngine(table, device=local_rank, dtype=args.dtype, math=math)
+    offset, n = tiles.pixel_range(args.rows, args.cols, rank, world)
+    total = args.rows * args.cols
+
+    cls, drv = eng.synth(n, seed=SEED, step=0, pixel_offset=offset)
+    day, night = eng.empty(n, 2)
+    diag = torch.zeros(8, dtype=torch.float64, device='cuda')
+
+    def step():
+        eng.run(cls, drv, day, night)
+        eng.diagnostics(day, night, out=diag)
+        tiles.allreduce_diag(diag)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    eng.check()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel alone, HIP events on its own stream
+    kernel_ms = eng.time_kernel(cls, drv, day, night, launches=max(3, min(args.steps, 20)))
+    bpp = eng.bytes_per_pixel
+    achieved = bpp * n / (kernel_ms * 1e-3) / 1e9
+    diag_host = diag.cpu().numpy()
+
+    parity = None
+    if rank == 0 and not args.no_parity:
+        from oracle import mod16_oracle as oracle
+        m = min(n, TILE[0] * TILE[1])
+        h_cls = cls[:m].cpu().numpy()
+        h_drv = [d[:m].cpu().numpy() for d in drv]
+        bplut = {k: table[:, j].astype(h_drv[0].dtype) for j, k in enumerate(oracle.PARAM_NAMES)}
+        want = oracle.evapotranspiration_raster(bplut, h_cls, *h_drv)
+        worst, masks = 0.0, True
+        for got, ref in ((day[:m].cpu().numpy(), want[0]), (night[:m].cpu().numpy(), want[1])):
+            masks = masks and bool(np.array_equal(np.isnan(got), np.isnan(ref))
+                                   and np.array_equal(got == 0, ref == 0))
+            ok = np.isfinite(ref) & (ref != 0)
+            worst = max(worst, float(np.max(np.abs(got[ok].astype(np.float64) - ref[ok]) / np.abs(ref[ok]))))
+        parity = {'pixels': int(m), 'max_rel_err': worst, 'masks_equal': masks,
+                  'rtol_north_star': 1e-5, 'against': 'numpy oracle on the same input bits'}
+
+    if rank == 0:
+        value = total * args.steps / elapsed
+        line = {
+            'metric': 'pixels/sec, fused Penman-Monteith ET forward run (day+night), 43200x21600 global grid',
+            'value': value, 'unit': 'pixels/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f64' if args.dtype == 'float64' else 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': '%dx%d global ET grid, one timestep, %s, %d row band(s) of %d-%d rows'
+                            % (args.cols, args.rows, args.dtype, world,
+                               args.rows // world, -(-args.rows // world)),
+                'pixels': total, 'pixels_per_gpu': n, 'parallelism': 'tile-dp%d' % world,
+                'math': args.math, 'bplut': os.path.basename(COLLECTION61_BPLUT),
+                'step': 'fused ET kernel + diagnostics reduction + all-reduce(8 doubles)',
+            },
+            'roofline': {
+                'bound': 'hbm', 'kernel': 'et_kernel<%s>' % args.dtype, 'achieved': achieved,
+                'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
+                'traffic': None, 'bytes_per_pixel': bpp, 'pixels_per_launch': n,
+                'kernel_ms': kernel_ms, 'kernel_pixels_per_s': n / (kernel_ms * 1e-3),
+            },
+            'cpu_baseline': cpu,
+            'parity': parity,
+            'diagnostics': dict(zip(
+                ('sum_day', 'sum_night', 'n_valid_day', 'n_valid_night',
+                 'n_nan_day', 'n_nan_night', 'max_day', 'max_night'),
+                [float(v) for v in diag_host])),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
