@@ -135,6 +135,25 @@ MOD16_API int mod16_et_f32(mod16_ctx* ctx, const uint8_t* cls,
                  void* stream);
 
 /*
+ * Forward run and diagnostics in one pass, DEVICE pointers only: as
+ * mod16_et_* with a class raster (BPLUT parameters) and both totals, plus the
+ * diagnostics vector of mod16_reduce_diag_* written to ddiag (device, 8
+ * doubles). On the production path (dense 16-byte-aligned drivers, n a
+ * multiple of the vector width) the outputs are reduced while still in
+ * registers, so the extra 16 B/pixel read of a separate reduction is saved;
+ * otherwise the call runs the forward run and then the reduction. The sums
+ * are deterministic for a given n and device. Asynchronous on `stream`.
+ */
+MOD16_API int mod16_et_diag_f64(mod16_ctx* ctx, const uint8_t* cls,
+                      const double* const* drivers, const int64_t* dstride,
+                      int64_t n, double* out_day, double* out_night,
+                      unsigned flags, double* ddiag, void* stream);
+MOD16_API int mod16_et_diag_f32(mod16_ctx* ctx, const uint8_t* cls,
+                      const float* const* drivers, const int64_t* dstride,
+                      int64_t n, float* out_day, float* out_night,
+                      unsigned flags, double* ddiag, void* stream);
+
+/*
  * Waits for the ctx's outstanding work on `stream` and reports deferred
  * errors of DEVICE-mode calls (MOD16_ERR_CLASS_RANGE, MOD16_ERR_HIP).
  */
@@ -175,14 +194,15 @@ MOD16_API int mod16_synth_f32(mod16_ctx* ctx, uint64_t seed, int64_t step,
  * Timing aid for bench.py: runs `launches` back-to-back launches of the
  * DEVICE-mode f64/f32 forward run on `stream`, bracketed by HIP events on
  * that stream, and returns the mean milliseconds per launch in *ms.
- * Arguments as mod16_et_f64 / mod16_et_f32 (is_f32 selects), where = DEVICE.
+ * Arguments as mod16_et_f64 / mod16_et_f32 (is_f32 selects), where = DEVICE;
+ * with ddiag != NULL the launches are those of mod16_et_diag_*.
  */
 MOD16_API int mod16_time_et(mod16_ctx* ctx, int is_f32, const uint8_t* cls,
                   const void* const* drivers, const int64_t* dstride,
                   const void* const* params, const int64_t* pstride,
                   int64_t n, void* out_day, void* out_night,
-                  void* const* out_sep, unsigned flags, int launches,
-                  void* stream, float* ms);
+                  void* const* out_sep, unsigned flags, double* ddiag,
+                  int launches, void* stream, float* ms);
 
 #ifdef __cplusplus
 }

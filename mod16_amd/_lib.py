@@ -21,7 +21,9 @@ ERR_ARG, ERR_HIP, ERR_CLASS_RANGE, ERR_NOMEM, ERR_NO_DEVICE, ERR_NO_BPLUT = \
     -1, -2, -3, -4, -5, -6
 
 LIB_NAME = 'libmod16hip.so'
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# MOD16_LIB: alternative build of the same library (kernel experiments only)
+LIB_PATH = os.environ.get('MOD16_LIB') or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 
 class Mod16Error(RuntimeError):
@@ -50,6 +52,12 @@ PROTOTYPES = {
     'mod16_et_f32': (C.c_int, [
         C.c_void_p, C.c_void_p, _PP, _I64P, _PP, _I64P, C.c_int64, C.c_void_p,
         C.c_void_p, _PP, C.c_uint, C.c_int, C.c_void_p]),
+    'mod16_et_diag_f64': (C.c_int, [
+        C.c_void_p, C.c_void_p, _PP, _I64P, C.c_int64, C.c_void_p, C.c_void_p,
+        C.c_uint, C.c_void_p, C.c_void_p]),
+    'mod16_et_diag_f32': (C.c_int, [
+        C.c_void_p, C.c_void_p, _PP, _I64P, C.c_int64, C.c_void_p, C.c_void_p,
+        C.c_uint, C.c_void_p, C.c_void_p]),
     'mod16_check_status': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mod16_reduce_diag_f64': (C.c_int, [
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
@@ -65,11 +73,30 @@ PROTOTYPES = {
         _PP, C.c_void_p]),
     'mod16_time_et': (C.c_int, [
         C.c_void_p, C.c_int, C.c_void_p, _PP, _I64P, _PP, _I64P, C.c_int64,
-        C.c_void_p, C.c_void_p, _PP, C.c_uint, C.c_int, C.c_void_p,
+        C.c_void_p, C.c_void_p, _PP, C.c_uint, C.c_void_p, C.c_int, C.c_void_p,
         C.POINTER(C.c_float)]),
 }
 
 _lib = None
+
+
+def _preload_torch_hip_runtime():
+    '''PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/
+    libamdhip64.so, SONAME libamdhip64.so.7). If libmod16hip.so pulled in the
+    system copy first and torch were imported later, the process would hold two
+    HIP/HSA runtimes and the second one could not open the GPU. Loading torch's
+    copy first makes both resolve to the same runtime, in either import order.
+    torch itself is not imported here.'''
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
 def load():
@@ -82,6 +109,7 @@ def load():
             '%s is not built: run `python -c "import __graft_entry__ as g; '
             'g.build()"` (or mod16_amd/csrc/build.py) at the repo root. '
             'mod16_amd has no CPU fallback.' % LIB_PATH)
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)

@@ -26,13 +26,16 @@ constexpr int kSlots = 2;                           // double buffering
 struct mod16_ctx {
     int device = 0;
     int cus = 256;
-    int grid_mult = 8;
+    int grid_mult = 64;              // blocks per CU in the grid-stride launch (measured best)
+    bool use_dma = true;             // LDS-DMA prefetch form of the production kernel
     bool have_lut = false;
     double* lut64 = nullptr;     // device [MOD16_LUT_ROWS][kLutCols]
     float* lut32 = nullptr;
+    double* tab64 = nullptr;         // exp/log tables of FastMath<double>
     unsigned* status = nullptr;      // device status word
     unsigned* status_host = nullptr; // pinned mirror
-    double* diag_partial = nullptr;  // device [kDiagBlocks][kDiag]
+    double* diag_partial = nullptr;  // device [diag_capacity][kDiag]
+    int64_t diag_capacity = 0;       // in blocks
     double* diag_dev = nullptr;      // device [kDiag]
     double* diag_host = nullptr;     // pinned [kDiag]
     // HOST-mode staging: per slot one device slab + one stream
@@ -97,6 +100,7 @@ extern "C" int mod16_destroy(mod16_ctx* ctx) {
     if (ctx->scalars) (void)hipFree(ctx->scalars);
     if (ctx->lut64) (void)hipFree(ctx->lut64);
     if (ctx->lut32) (void)hipFree(ctx->lut32);
+    if (ctx->tab64) (void)hipFree(ctx->tab64);
     if (ctx->status) (void)hipFree(ctx->status);
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     if (ctx->diag_partial) (void)hipFree(ctx->diag_partial);
@@ -125,13 +129,29 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
         }
         ctx->cus = prop.multiProcessorCount;
         if (const char* g = getenv("MOD16_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(g));
+        if (const char* g = getenv("MOD16_NO_DMA")) ctx->use_dma = atoi(g) == 0;
         const size_t nlut = MOD16_LUT_ROWS * kLutCols;
         HIPCHK(ctx, hipMalloc(&ctx->lut64, nlut * sizeof(double)));
         HIPCHK(ctx, hipMalloc(&ctx->lut32, nlut * sizeof(float)));
+        {   // exp/log tables of FastMath<double> (mod16_math.hpp)
+            constexpr int n = FastMath<double>::kTabDoubles;
+            double t[n];
+            for (int j = 0; j < 64; ++j) t[j] = (double)exp2l((long double)j / 64.0L);
+            for (int j = 0; j < 128; ++j) {
+                const double inv = 1.0 / (1.0 + (j + 0.5) / 128.0);
+                t[64 + 2 * j] = inv;
+                t[64 + 2 * j + 1] = (double)(-logl((long double)inv));
+            }
+            // entry 0 serves x = 1 (m = 1): make log_tab(1) cancel to exactly 0
+            t[64 + 1] = -FastMath<double>::log1p_poly(std::fma(1.0, t[64], -1.0));
+            HIPCHK(ctx, hipMalloc(&ctx->tab64, sizeof t));
+            HIPCHK(ctx, hipMemcpy(ctx->tab64, t, sizeof t, hipMemcpyHostToDevice));
+        }
         HIPCHK(ctx, hipMalloc(&ctx->status, sizeof(unsigned)));
         HIPCHK(ctx, hipMemset(ctx->status, 0, sizeof(unsigned)));
         HIPCHK(ctx, hipHostMalloc(&ctx->status_host, sizeof(unsigned)));
         HIPCHK(ctx, hipMalloc(&ctx->diag_partial, sizeof(double) * kDiagBlocks * kDiag));
+        ctx->diag_capacity = kDiagBlocks;
         HIPCHK(ctx, hipMalloc(&ctx->diag_dev, sizeof(double) * kDiag));
         HIPCHK(ctx, hipHostMalloc(&ctx->diag_host, sizeof(double) * kDiag));
         HIPCHK(ctx, hipMalloc(&ctx->scalars, 32 * sizeof(double)));
@@ -179,20 +199,35 @@ extern "C" int mod16_set_bplut_f64(mod16_ctx* ctx, const double* lut) {
 template <typename T> static const T* ctx_lut(const mod16_ctx* ctx);
 template <> const double* ctx_lut<double>(const mod16_ctx* ctx) { return ctx->lut64; }
 template <> const float* ctx_lut<float>(const mod16_ctx* ctx) { return ctx->lut32; }
+template <typename T> static const T* ctx_tab(const mod16_ctx* ctx);
+template <> const double* ctx_tab<double>(const mod16_ctx* ctx) { return ctx->tab64; }
+template <> const float* ctx_tab<float>(const mod16_ctx*) { return nullptr; }
 
 template <typename T> struct VecOf;
 template <> struct VecOf<double> { static constexpr int v = 2; };
 template <> struct VecOf<float> { static constexpr int v = 4; };
 
+// Instantiated variants: the production (FAST, vectorised) kernel gets the
+// SEP / DENSE specialisations; the scalar-tail and EXACT kernels are generic.
 template <typename T, int V>
-static void launch_variant(const EtArgs<T>& a, bool lut, bool fast, int grid, hipStream_t st) {
-    if (lut) {
-        if (fast) hipLaunchKernelGGL((et_kernel<T, V, true, true>), dim3(grid), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((et_kernel<T, V, true, false>), dim3(grid), dim3(kBlock), 0, st, a);
+static void launch_variant(const EtArgs<T>& a, bool lut, bool fast, bool sep, bool dense,
+                           int grid, hipStream_t st) {
+#define MOD16_LAUNCH(LUT, FAST, SEP, DENSE) \
+    hipLaunchKernelGGL((et_kernel<T, V, LUT, FAST, SEP, DENSE>), dim3(grid), dim3(kBlock), 0, st, a)
+    if (fast && V > 1) {
+        if (lut) {
+            if (sep) { if (dense) MOD16_LAUNCH(true, true, true, true); else MOD16_LAUNCH(true, true, true, false); }
+            else     { if (dense) MOD16_LAUNCH(true, true, false, true); else MOD16_LAUNCH(true, true, false, false); }
+        } else {
+            if (sep) { if (dense) MOD16_LAUNCH(false, true, true, true); else MOD16_LAUNCH(false, true, true, false); }
+            else     { if (dense) MOD16_LAUNCH(false, true, false, true); else MOD16_LAUNCH(false, true, false, false); }
+        }
+    } else if (fast) {
+        if (lut) MOD16_LAUNCH(true, true, true, false); else MOD16_LAUNCH(false, true, true, false);
     } else {
-        if (fast) hipLaunchKernelGGL((et_kernel<T, V, false, true>), dim3(grid), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((et_kernel<T, V, false, false>), dim3(grid), dim3(kBlock), 0, st, a);
+        if (lut) MOD16_LAUNCH(true, false, true, false); else MOD16_LAUNCH(false, false, true, false);
     }
+#undef MOD16_LAUNCH
 }
 
 static int grid_for(const mod16_ctx* ctx, int64_t nvec) {
@@ -202,44 +237,82 @@ static int grid_for(const mod16_ctx* ctx, int64_t nvec) {
 }
 
 // All pointers are device pointers here.
+static int reserve_diag(mod16_ctx* ctx, int64_t blocks) {
+    if (blocks <= ctx->diag_capacity) return MOD16_OK;
+    HIPCHK(ctx, hipDeviceSynchronize());   // growing only: earlier launches may still use it
+    HIPCHK(ctx, hipFree(ctx->diag_partial));
+    ctx->diag_partial = nullptr;
+    ctx->diag_capacity = 0;
+    HIPCHK(ctx, hipMalloc(&ctx->diag_partial, sizeof(double) * blocks * kDiag));
+    ctx->diag_capacity = blocks;
+    return MOD16_OK;
+}
+
 template <typename T>
-static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st) {
+static int reduce_entry(mod16_ctx* ctx, const T* day, const T* night, int64_t n, double* diag,
+                        double* ddiag, void* stream);
+
+// ddiag != NULL: also produce the diagnostics vector (device, 8 doubles).
+template <typename T>
+static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st,
+                     double* ddiag = nullptr) {
     constexpr int V = VecOf<T>::v;
     const bool lut = a.cls != nullptr;
     const bool fast = (flags & MOD16_MATH_EXACT) == 0;
     if (a.n <= 0) return MOD16_OK;
     a.lut = ctx_lut<T>(ctx);
+    a.tab = ctx_tab<T>(ctx);
     a.status = ctx->status;
     // 16-byte vector path needs every dense pointer 16-byte aligned
     bool aligned = true;
     auto chk = [&](const void* p, size_t al) {
         if (p && (reinterpret_cast<uintptr_t>(p) % al)) aligned = false;
     };
-    for (int k = 0; k < 14; ++k) if (a.dstride[k]) chk(a.drv[k], 16);
+    for (int k = 0; k < 14; ++k) if ((a.dense_drv >> k) & 1u) chk(a.drv[k], 16);
     if (lut) chk(a.cls, V);
-    else for (int k = 0; k < 11; ++k) if (a.pstride[k]) chk(a.par[k], 16);
-    chk(a.out_day, 16);
-    chk(a.out_night, 16);
-    for (int k = 0; k < 6; ++k) chk(a.sep[k], 16);
+    else for (int k = 0; k < 11; ++k) if ((a.dense_par >> k) & 1u) chk(a.par[k], 16);
+    bool sep = false;
+    for (int k = 0; k < 8; ++k) {
+        chk(a.out[k], 16);
+        if (k >= 2 && a.out[k]) sep = true;
+    }
+    const bool dense = a.dense_drv == 0x3fffu;
     const int64_t nbody = aligned ? (a.n / V) * V : 0;
+    const bool dma = ctx->use_dma && lut && fast && !sep && dense && a.out[0] && a.out[1];
+    bool fused_diag = false;
     if (nbody) {
         EtArgs<T> b = a;
         b.n = nbody;
-        launch_variant<T, V>(b, lut, fast, grid_for(ctx, nbody / V), st);
+        const int grid = grid_for(ctx, nbody / V);
+        if (dma && ddiag && nbody == a.n) {   // outputs reduced while still in registers
+            int rc = reserve_diag(ctx, grid);
+            if (rc != MOD16_OK) return rc;
+            b.diag_partial = ctx->diag_partial;
+            hipLaunchKernelGGL((et_kernel_dma<T, true, true>), dim3(grid), dim3(kBlock), 0, st, b);
+            hipLaunchKernelGGL(diag_final_fused_kernel, dim3(1), dim3(kBlock), 0, st,
+                               ctx->diag_partial, grid, a.n, ddiag);
+            fused_diag = true;
+        } else if (dma) {
+            hipLaunchKernelGGL((et_kernel_dma<T, true, false>), dim3(grid), dim3(kBlock), 0, st, b);
+        } else {
+            launch_variant<T, V>(b, lut, fast, sep, dense, grid, st);
+        }
     }
     if (nbody < a.n) {   // ragged tail (or unaligned input): scalar variant
         EtArgs<T> t = a;
         const int64_t off = nbody;
-        for (int k = 0; k < 14; ++k) if (t.dstride[k]) t.drv[k] += off;
+        for (int k = 0; k < 14; ++k) if ((t.dense_drv >> k) & 1u) t.drv[k] += off;
         if (lut) t.cls += off;
-        else for (int k = 0; k < 11; ++k) if (t.pstride[k]) t.par[k] += off;
-        if (t.out_day) t.out_day += off;
-        if (t.out_night) t.out_night += off;
-        for (int k = 0; k < 6; ++k) if (t.sep[k]) t.sep[k] += off;
+        else for (int k = 0; k < 11; ++k) if ((t.dense_par >> k) & 1u) t.par[k] += off;
+        for (int k = 0; k < 8; ++k) if (t.out[k]) t.out[k] += off;
         t.n = a.n - off;
-        launch_variant<T, 1>(t, lut, fast, grid_for(ctx, t.n), st);
+        launch_variant<T, 1>(t, lut, fast, sep, dense, grid_for(ctx, t.n), st);
     }
     HIPCHK(ctx, hipGetLastError());
+    if (ddiag && !fused_diag) {
+        if (!a.out[0] || !a.out[1]) return fail(ctx, MOD16_ERR_ARG, "diagnostics need both out_day and out_night");
+        return reduce_entry<T>(ctx, a.out[0], a.out[1], a.n, nullptr, ddiag, st);
+    }
     return MOD16_OK;
 }
 
@@ -254,7 +327,7 @@ static int fill_args(mod16_ctx* ctx, EtArgs<T>& a, const uint8_t* cls, const T* 
         if (!drivers[k]) return fail(ctx, MOD16_ERR_ARG, "mod16_et: NULL driver array");
         if (dstride[k] != 0 && dstride[k] != 1) return fail(ctx, MOD16_ERR_ARG, "mod16_et: driver stride must be 0 or 1");
         a.drv[k] = drivers[k];
-        a.dstride[k] = dstride[k];
+        if (dstride[k]) a.dense_drv |= 1u << k;
     }
     a.cls = cls;
     if (cls) {
@@ -265,15 +338,15 @@ static int fill_args(mod16_ctx* ctx, EtArgs<T>& a, const uint8_t* cls, const T* 
             if (!params[k]) return fail(ctx, MOD16_ERR_ARG, "mod16_et: NULL parameter array");
             if (pstride[k] != 0 && pstride[k] != 1) return fail(ctx, MOD16_ERR_ARG, "mod16_et: parameter stride must be 0 or 1");
             a.par[k] = params[k];
-            a.pstride[k] = pstride[k];
+            if (pstride[k]) a.dense_par |= 1u << k;
         }
     }
-    a.out_day = out_day;
-    a.out_night = out_night;
+    a.out[0] = out_day;
+    a.out[1] = out_night;
     bool any = out_day || out_night;
     if (out_sep)
         for (int k = 0; k < 6; ++k) {
-            a.sep[k] = out_sep[k];
+            a.out[2 + k] = out_sep[k];
             any = any || out_sep[k];
         }
     if (!any) return fail(ctx, MOD16_ERR_ARG, "mod16_et: no output array given");
@@ -312,8 +385,8 @@ static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
         if (!ctx->streams[s]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->streams[s], hipStreamNonBlocking));
     // broadcast scalars live in one small device array
     T hs[32];
-    for (int k = 0; k < 14; ++k) hs[k] = h.dstride[k] ? T(0) : h.drv[k][0];
-    for (int k = 0; k < 11; ++k) hs[14 + k] = (!h.cls && !h.pstride[k]) ? h.par[k][0] : T(0);
+    for (int k = 0; k < 14; ++k) hs[k] = ((h.dense_drv >> k) & 1u) ? T(0) : h.drv[k][0];
+    for (int k = 0; k < 11; ++k) hs[14 + k] = (!h.cls && !((h.dense_par >> k) & 1u)) ? h.par[k][0] : T(0);
     HIPCHK(ctx, hipMemcpy(ctx->scalars, hs, sizeof(T) * 25, hipMemcpyHostToDevice));
     const T* dscal = static_cast<const T*>(ctx->scalars);
 
@@ -326,7 +399,7 @@ static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
         EtArgs<T> d = h;
         d.n = m;
         for (int k = 0; k < 14; ++k) {
-            if (h.dstride[k]) {
+            if ((h.dense_drv >> k) & 1u) {
                 T* dp = reinterpret_cast<T*>(base + per_arr * k);
                 HIPCHK(ctx, hipMemcpyAsync(dp, h.drv[k] + off, sizeof(T) * m, hipMemcpyHostToDevice, st));
                 d.drv[k] = dp;
@@ -340,7 +413,7 @@ static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
             d.cls = dc;
         } else {
             for (int k = 0; k < 11; ++k) {
-                if (h.pstride[k]) {
+                if ((h.dense_par >> k) & 1u) {
                     T* dp = reinterpret_cast<T*>(base + per_arr * (14 + k));
                     HIPCHK(ctx, hipMemcpyAsync(dp, h.par[k] + off, sizeof(T) * m, hipMemcpyHostToDevice, st));
                     d.par[k] = dp;
@@ -350,15 +423,11 @@ static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
             }
         }
         auto out_at = [&](int k) { return reinterpret_cast<T*>(base + per_arr * (25 + k)); };
-        d.out_day = h.out_day ? out_at(0) : nullptr;
-        d.out_night = h.out_night ? out_at(1) : nullptr;
-        for (int k = 0; k < 6; ++k) d.sep[k] = h.sep[k] ? out_at(2 + k) : nullptr;
+        for (int k = 0; k < 8; ++k) d.out[k] = h.out[k] ? out_at(k) : nullptr;
         int rc = launch_et<T>(ctx, d, flags, st);
         if (rc != MOD16_OK) return rc;
-        if (h.out_day) HIPCHK(ctx, hipMemcpyAsync(h.out_day + off, d.out_day, sizeof(T) * m, hipMemcpyDeviceToHost, st));
-        if (h.out_night) HIPCHK(ctx, hipMemcpyAsync(h.out_night + off, d.out_night, sizeof(T) * m, hipMemcpyDeviceToHost, st));
-        for (int k = 0; k < 6; ++k)
-            if (h.sep[k]) HIPCHK(ctx, hipMemcpyAsync(h.sep[k] + off, d.sep[k], sizeof(T) * m, hipMemcpyDeviceToHost, st));
+        for (int k = 0; k < 8; ++k)
+            if (h.out[k]) HIPCHK(ctx, hipMemcpyAsync(h.out[k] + off, d.out[k], sizeof(T) * m, hipMemcpyDeviceToHost, st));
     }
     for (int s = 0; s < kSlots; ++s) HIPCHK(ctx, hipStreamSynchronize(ctx->streams[s]));
     return read_status(ctx, ctx->streams[0]);
@@ -395,6 +464,31 @@ extern "C" int mod16_et_f32(mod16_ctx* ctx, const uint8_t* cls, const float* con
                            out_sep, flags, where, stream);
 }
 
+template <typename T>
+static int et_diag_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drivers,
+                         const int64_t* dstride, int64_t n, T* out_day, T* out_night,
+                         unsigned flags, double* ddiag, void* stream) {
+    if (!ctx) return MOD16_ERR_ARG;
+    if (!cls || !out_day || !out_night || !ddiag)
+        return fail(ctx, MOD16_ERR_ARG, "mod16_et_diag: cls, out_day, out_night and ddiag are required");
+    EtArgs<T> a;
+    int rc = fill_args<T>(ctx, a, cls, drivers, dstride, nullptr, nullptr, n, out_day, out_night, nullptr);
+    if (rc != MOD16_OK) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return launch_et<T>(ctx, a, flags, static_cast<hipStream_t>(stream), ddiag);
+}
+
+extern "C" int mod16_et_diag_f64(mod16_ctx* ctx, const uint8_t* cls, const double* const* drivers,
+                                 const int64_t* dstride, int64_t n, double* out_day,
+                                 double* out_night, unsigned flags, double* ddiag, void* stream) {
+    return et_diag_entry<double>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, stream);
+}
+extern "C" int mod16_et_diag_f32(mod16_ctx* ctx, const uint8_t* cls, const float* const* drivers,
+                                 const int64_t* dstride, int64_t n, float* out_day,
+                                 float* out_night, unsigned flags, double* ddiag, void* stream) {
+    return et_diag_entry<float>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, stream);
+}
+
 extern "C" int mod16_check_status(mod16_ctx* ctx, void* stream) {
     if (!ctx) return MOD16_ERR_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -405,7 +499,8 @@ extern "C" int mod16_time_et(mod16_ctx* ctx, int is_f32, const uint8_t* cls,
                              const void* const* drivers, const int64_t* dstride,
                              const void* const* params, const int64_t* pstride, int64_t n,
                              void* out_day, void* out_night, void* const* out_sep,
-                             unsigned flags, int launches, void* stream, float* ms) {
+                             unsigned flags, double* ddiag, int launches, void* stream,
+                             float* ms) {
     if (!ctx || !ms || launches <= 0) return fail(ctx, MOD16_ERR_ARG, "mod16_time_et: bad argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -415,7 +510,15 @@ extern "C" int mod16_time_et(mod16_ctx* ctx, int is_f32, const uint8_t* cls,
     int rc = MOD16_OK;
     HIPCHK(ctx, hipEventRecord(e0, st));
     for (int i = 0; i < launches && rc == MOD16_OK; ++i) {
-        if (is_f32)
+        if (ddiag && is_f32)
+            rc = mod16_et_diag_f32(ctx, cls, reinterpret_cast<const float* const*>(drivers), dstride, n,
+                                   static_cast<float*>(out_day), static_cast<float*>(out_night), flags,
+                                   ddiag, stream);
+        else if (ddiag)
+            rc = mod16_et_diag_f64(ctx, cls, reinterpret_cast<const double* const*>(drivers), dstride, n,
+                                   static_cast<double*>(out_day), static_cast<double*>(out_night), flags,
+                                   ddiag, stream);
+        else if (is_f32)
             rc = mod16_et_f32(ctx, cls, reinterpret_cast<const float* const*>(drivers), dstride,
                               reinterpret_cast<const float* const*>(params), pstride, n,
                               static_cast<float*>(out_day), static_cast<float*>(out_night),

@@ -20,16 +20,16 @@ constexpr unsigned kStatusClassRange = 1u;
 
 template <typename T> struct EtArgs {
     const T* drv[14];
-    int64_t dstride[14];
     const T* par[11];
-    int64_t pstride[11];
     const uint8_t* cls;
     const T* lut;          // device [MOD16_LUT_ROWS][kLutCols]
-    T* out_day;
-    T* out_night;
-    T* sep[6];
+    const T* tab;          // device exp/log tables, FastMath<T>::kTabDoubles values
+    T* out[8];             // day, night, then the 6 components (mod16_component)
     int64_t n;
     unsigned* status;
+    uint32_t dense_drv;    // bit k set: driver k is a dense array, else a broadcast scalar
+    uint32_t dense_par;
+    double* diag_partial;  // et_kernel_dma<.., DIAG>: [gridDim][8] per-block diagnostics
 };
 
 template <typename T, int V> struct Vec;
@@ -38,10 +38,10 @@ template <> struct Vec<double, 1> { typedef double type; };
 template <> struct Vec<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
 template <> struct Vec<float, 1> { typedef float type; };
 
-template <typename T, int V>
-__device__ __forceinline__ void load_vec(const T* __restrict__ p, int64_t stride, int64_t i,
+template <typename T, int V, bool DENSE>
+__device__ __forceinline__ void load_vec(const T* __restrict__ p, bool dense, int64_t i,
                                          T (&dst)[V]) {
-    if (stride) {   // wave-uniform (kernel argument)
+    if (DENSE || dense) {   // `dense` is wave-uniform (a kernel-argument bit)
         typedef typename Vec<T, V>::type VT;
         VT v = *reinterpret_cast<const VT*>(p + i);
         if constexpr (V == 1) {
@@ -70,20 +70,31 @@ __device__ __forceinline__ void store_vec(T* __restrict__ p, int64_t i, const T 
     }
 }
 
-template <typename T, int V, bool LUT, bool FAST>
-__global__ void __launch_bounds__(kBlock) et_kernel(const EtArgs<T> a) {
+// Template switches: V pixels per thread (16-byte accesses when V > 1), LUT =
+// parameters from the BPLUT in LDS by class code (else per-pixel / scalar
+// parameter inputs), FAST = strength-reduced arithmetic, SEP = also store the
+// six components, DENSE = every driver is a dense array (no broadcast checks).
+#ifndef MOD16_ET_WAVES
+#define MOD16_ET_WAVES 1
+#endif
+template <typename T, int V, bool LUT, bool FAST, bool SEP, bool DENSE>
+__global__ void __launch_bounds__(kBlock, MOD16_ET_WAVES) et_kernel(const EtArgs<T> a) {
+    constexpr int kTab = FastMath<T>::kTabDoubles;
     __shared__ T lut[MOD16_LUT_ROWS * kLutCols];
-    if (LUT) {
+    __shared__ __attribute__((aligned(16))) T tab[kTab > 0 ? kTab : 1];
+    if (LUT)
         for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) lut[i] = a.lut[i];
-        __syncthreads();
-    }
+    if (FAST)
+        for (int i = threadIdx.x; i < kTab; i += kBlock) tab[i] = a.tab[i];
+    __syncthreads();
     const int64_t nvec = a.n / V;
     const int64_t step = (int64_t)gridDim.x * kBlock;
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += step) {
         const int64_t i = v * V;
         T in[14][V];
 #pragma unroll
-        for (int k = 0; k < 14; ++k) load_vec<T, V>(a.drv[k], a.dstride[k], i, in[k]);
+        for (int k = 0; k < 14; ++k)
+            load_vec<T, V, DENSE>(a.drv[k], (a.dense_drv >> k) & 1u, i, in[k]);
         unsigned cbits = 0;
         T pin[11][V];
         if (LUT) {
@@ -92,9 +103,10 @@ __global__ void __launch_bounds__(kBlock) et_kernel(const EtArgs<T> a) {
             else cbits = *reinterpret_cast<const uint32_t*>(a.cls + i);
         } else {
 #pragma unroll
-            for (int k = 0; k < 11; ++k) load_vec<T, V>(a.par[k], a.pstride[k], i, pin[k]);
+            for (int k = 0; k < 11; ++k)
+                load_vec<T, V, false>(a.par[k], (a.dense_par >> k) & 1u, i, pin[k]);
         }
-        T day[V], night[V], sep[6][V];
+        T res[8][V];
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             PixelIn<T> x = {in[0][j], in[1][j], in[2][j], in[3][j], in[4][j], in[5][j], in[6][j],
@@ -139,22 +151,25 @@ __global__ void __launch_bounds__(kBlock) et_kernel(const EtArgs<T> a) {
                 p.beta = pin[10][j];
                 if (FAST) p.derive();
             }
-            PixelOut<T> o = FAST ? et_pixel_fast<T>(x, p) : et_pixel_exact<T>(x, p);
+            PixelOut<T> o = FAST ? et_pixel_fast<T>(x, p, tab) : et_pixel_exact<T>(x, p);
             // mod16/__init__.py:792: (canopy + soil) + transpiration
-            day[j] = (o.canopy_d + o.soil_d) + o.trans_d;
-            night[j] = (o.canopy_n + o.soil_n) + o.trans_n;
-            sep[0][j] = o.canopy_d;
-            sep[1][j] = o.soil_d;
-            sep[2][j] = o.trans_d;
-            sep[3][j] = o.canopy_n;
-            sep[4][j] = o.soil_n;
-            sep[5][j] = o.trans_n;
+            res[0][j] = (o.canopy_d + o.soil_d) + o.trans_d;
+            res[1][j] = (o.canopy_n + o.soil_n) + o.trans_n;
+            if (SEP) {
+                res[2][j] = o.canopy_d;
+                res[3][j] = o.soil_d;
+                res[4][j] = o.trans_d;
+                res[5][j] = o.canopy_n;
+                res[6][j] = o.soil_n;
+                res[7][j] = o.trans_n;
+            }
+#ifdef MOD16_SCHED_BARRIER
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
-        if (a.out_day) store_vec<T, V>(a.out_day, i, day);
-        if (a.out_night) store_vec<T, V>(a.out_night, i, night);
 #pragma unroll
-        for (int k = 0; k < 6; ++k)
-            if (a.sep[k]) store_vec<T, V>(a.sep[k], i, sep[k]);
+        for (int k = 0; k < (SEP ? 8 : 2); ++k)
+            if (a.out[k]) store_vec<T, V>(a.out[k], i, res[k]);
     }
 }
 
@@ -224,6 +239,216 @@ __global__ void __launch_bounds__(kBlock) diag_final_kernel(const double* partia
         diag_merge(acc, o);
     }
     diag_block_reduce(acc, out);
+}
+
+// ---------------------------------------------------------------- LDS-DMA form
+// Production kernel for dense multi-class rasters (class raster + BPLUT, totals
+// only). Same arithmetic as et_kernel<.., LUT, FAST, !SEP, DENSE>; what differs
+// is how the drivers reach the registers. At ~200 VGPRs only two waves fit a
+// SIMD, too few to hide HBM latency behind other waves, and there is no room
+// for a second register set to prefetch into. So each wave owns a 15 KiB LDS
+// slot and streams the NEXT iteration's 14 driver vectors (+ class bytes) into
+// it with global_load_lds (LDS-DMA, no VGPR destination) while it computes the
+// current one: issue -> compute(i) -> counted vmcnt -> ds_read_b128 -> issue ...
+// The slot is private to the wave that fills it, so no barrier is involved:
+// the wave's own counted s_waitcnt vmcnt orders its ds_reads behind its DMA.
+#ifndef MOD16_DMA_AUX
+#define MOD16_DMA_AUX 0      // cache-policy bits of the LDS-DMA loads (2 = nt)
+#endif
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// DIAG: also reduce the outputs into per-block diagnostics partials (kDiag
+// doubles per block, same fields as diag_partial_kernel) while they are still in
+// registers, which saves the separate 16 B/pixel reduction pass.
+template <typename T, bool FAST, bool DIAG>
+__global__ void __launch_bounds__(kBlock) et_kernel_dma(const EtArgs<T> a) {
+    constexpr int V = 16 / (int)sizeof(T);
+    constexpr int kSlot = 15 * 1024;   // 14 x (64 lanes x 16 B) + class bytes
+    constexpr int kTab = FastMath<T>::kTabDoubles;
+    __shared__ T lut[MOD16_LUT_ROWS * kLutCols];
+    __shared__ __attribute__((aligned(16))) T tab[kTab > 0 ? kTab : 1];
+    __shared__ __attribute__((aligned(16))) char stage[(kBlock / 64) * kSlot];
+    for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) lut[i] = a.lut[i];
+    for (int i = threadIdx.x; i < kTab; i += kBlock) tab[i] = a.tab[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* const ws = stage + wave * kSlot;
+    const int64_t nvec = a.n / V;
+#ifndef MOD16_CHUNK_RUN
+#define MOD16_CHUNK_RUN 1    // consecutive 256-vector chunks a block takes before striding
+#endif
+    // chunk c covers vectors [c * 256, (c + 1) * 256); block b takes chunks
+    // (b * RUN + r) + it * gridDim * RUN, r = 0..RUN-1
+    const int64_t nchunk = (nvec + kBlock - 1) / kBlock;
+    const int64_t cstride = (int64_t)gridDim.x * MOD16_CHUNK_RUN;
+    int64_t cbase = (int64_t)blockIdx.x * MOD16_CHUNK_RUN;
+    int run = 0;
+    auto vec_of = [&](int64_t cb, int r) { return (cb + r) * kBlock + threadIdx.x; };
+    auto advance = [&](int64_t& cb, int& r) {
+        if (++r == MOD16_CHUNK_RUN) { r = 0; cb += cstride; }
+    };
+    int64_t v = vec_of(cbase, run);
+#define MOD16_VEND nvec
+    double dsum_d = 0, dsum_n = 0, dmax_d = -__builtin_huge_val(), dmax_n = -__builtin_huge_val();
+    unsigned nan_d = 0, nan_n = 0;   // wave-uniform NaN counts (ballot + popcount)
+
+    auto issue = [&](int64_t vv) {
+#pragma unroll
+        for (int k = 0; k < 14; ++k)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.drv[k] + vv * V), (lptr_t)(ws + k * 1024),
+                                             16, 0, MOD16_DMA_AUX);
+        if constexpr (V == 2)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.cls + vv * 2), (lptr_t)(ws + 14 * 1024), 2, 0, MOD16_DMA_AUX);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.cls + vv * 4), (lptr_t)(ws + 14 * 1024), 4, 0, MOD16_DMA_AUX);
+    };
+    if (v < MOD16_VEND) issue(v);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first fill: nothing to overlap with
+#pragma nounroll
+    for (; cbase + run < nchunk; ) {
+        // this iteration's DMA was issued before the previous iteration's two
+        // stores: all but the two youngest vector-memory operations must be done
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        // The slot is read with ds_read_b128 in one asm statement that also
+        // waits for the data (lgkmcnt(0)): as ordinary LDS loads hipcc would
+        // put a full s_waitcnt vmcnt(0) in front of them (it pairs them with the
+        // LDS-DMA), which would also wait for the two stores just issued. The
+        // returned reads are what allows the refill below (WAR on the slot).
+        typedef typename Vec<T, V>::type VT;
+        VT in[14];
+        unsigned cbits;
+        {
+            const unsigned base = (unsigned)(uintptr_t)(lptr_t)ws + lane * 16u;
+            const unsigned caddr = (unsigned)(uintptr_t)(lptr_t)ws + 14u * 1024u + lane * 4u;   // sub-dword LDS-DMA lands one dword per lane
+            if constexpr (V == 2) {
+                asm volatile(
+                    "ds_read_b128 %0, %15\n\tds_read_b128 %1, %15 offset:1024\n\t"
+                    "ds_read_b128 %2, %15 offset:2048\n\tds_read_b128 %3, %15 offset:3072\n\t"
+                    "ds_read_b128 %4, %15 offset:4096\n\tds_read_b128 %5, %15 offset:5120\n\t"
+                    "ds_read_b128 %6, %15 offset:6144\n\tds_read_b128 %7, %15 offset:7168\n\t"
+                    "ds_read_b128 %8, %15 offset:8192\n\tds_read_b128 %9, %15 offset:9216\n\t"
+                    "ds_read_b128 %10, %15 offset:10240\n\tds_read_b128 %11, %15 offset:11264\n\t"
+                    "ds_read_b128 %12, %15 offset:12288\n\tds_read_b128 %13, %15 offset:13312\n\t"
+                    "ds_read_u16 %14, %16\n\ts_waitcnt lgkmcnt(0)"
+                    : "=&v"(in[0]), "=&v"(in[1]), "=&v"(in[2]), "=&v"(in[3]), "=&v"(in[4]),
+                      "=&v"(in[5]), "=&v"(in[6]), "=&v"(in[7]), "=&v"(in[8]), "=&v"(in[9]),
+                      "=&v"(in[10]), "=&v"(in[11]), "=&v"(in[12]), "=&v"(in[13]), "=&v"(cbits)
+                    : "v"(base), "v"(caddr)
+                    : "memory");
+            } else {
+                asm volatile(
+                    "ds_read_b128 %0, %15\n\tds_read_b128 %1, %15 offset:1024\n\t"
+                    "ds_read_b128 %2, %15 offset:2048\n\tds_read_b128 %3, %15 offset:3072\n\t"
+                    "ds_read_b128 %4, %15 offset:4096\n\tds_read_b128 %5, %15 offset:5120\n\t"
+                    "ds_read_b128 %6, %15 offset:6144\n\tds_read_b128 %7, %15 offset:7168\n\t"
+                    "ds_read_b128 %8, %15 offset:8192\n\tds_read_b128 %9, %15 offset:9216\n\t"
+                    "ds_read_b128 %10, %15 offset:10240\n\tds_read_b128 %11, %15 offset:11264\n\t"
+                    "ds_read_b128 %12, %15 offset:12288\n\tds_read_b128 %13, %15 offset:13312\n\t"
+                    "ds_read_b32 %14, %16\n\ts_waitcnt lgkmcnt(0)"
+                    : "=&v"(in[0]), "=&v"(in[1]), "=&v"(in[2]), "=&v"(in[3]), "=&v"(in[4]),
+                      "=&v"(in[5]), "=&v"(in[6]), "=&v"(in[7]), "=&v"(in[8]), "=&v"(in[9]),
+                      "=&v"(in[10]), "=&v"(in[11]), "=&v"(in[12]), "=&v"(in[13]), "=&v"(cbits)
+                    : "v"(base), "v"(caddr)
+                    : "memory");
+            }
+        }
+        int64_t cb_n = cbase;
+        int run_n = run;
+        advance(cb_n, run_n);
+        const int64_t vn = vec_of(cb_n, run_n);
+        if (vn < MOD16_VEND) issue(vn);
+        asm volatile("" ::: "memory");
+
+        if (v < nvec) {   // only the last chunk is ragged
+            VT day, night;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                PixelIn<T> x = {in[0][j], in[1][j], in[2][j], in[3][j], in[4][j], in[5][j], in[6][j],
+                                in[7][j], in[8][j], in[9][j], in[10][j], in[11][j], in[12][j],
+                                in[13][j]};
+                unsigned c = (cbits >> (8 * j)) & 0xffu;
+                if (c >= 13u) {
+                    atomicOr(a.status, kStatusClassRange);
+                    c = 13u;
+                }
+                const T* l = lut + c;
+                ClassPar<T> p;
+                p.tmin_close = l[0 * kLutCols];
+                p.tmin_open = l[1 * kLutCols];
+                p.vpd_open = l[2 * kLutCols];
+                p.vpd_close = l[3 * kLutCols];
+                p.gl_sh = l[4 * kLutCols];
+                p.gl_wv = l[5 * kLutCols];
+                p.g_cut = l[6 * kLutCols];
+                p.csl = l[7 * kLutCols];
+                p.rbl_min = l[8 * kLutCols];
+                p.rbl_max = l[9 * kLutCols];
+                p.beta = l[10 * kLutCols];
+                p.inv_dtmin = l[11 * kLutCols];
+                p.inv_dvpd = l[12 * kLutCols];
+                p.rbl_slope = l[13 * kLutCols];
+                p.inv_beta = l[14 * kLutCols];
+                PixelOut<T> o = FAST ? et_pixel_fast<T>(x, p, tab) : et_pixel_exact<T>(x, p);
+                day[j] = (o.canopy_d + o.soil_d) + o.trans_d;
+                night[j] = (o.canopy_n + o.soil_n) + o.trans_n;
+                if (DIAG) {
+                    const double d = (double)day[j], g = (double)night[j];
+                    const bool dn = d != d, gn = g != g;
+                    nan_d += (unsigned)__builtin_popcountll(__ballot(dn));
+                    nan_n += (unsigned)__builtin_popcountll(__ballot(gn));
+                    dsum_d += dn ? 0.0 : d;
+                    dsum_n += gn ? 0.0 : g;
+                    dmax_d = __builtin_fmax(dmax_d, d);    // maxNum: skips NaN
+                    dmax_n = __builtin_fmax(dmax_n, g);
+                }
+            }
+#ifdef MOD16_NT_STORE
+            __builtin_nontemporal_store(day, reinterpret_cast<VT*>(a.out[0] + v * V));
+            __builtin_nontemporal_store(night, reinterpret_cast<VT*>(a.out[1] + v * V));
+#else
+            *reinterpret_cast<VT*>(a.out[0] + v * V) = day;
+            *reinterpret_cast<VT*>(a.out[1] + v * V) = night;
+#endif
+        }
+        cbase = cb_n;
+        run = run_n;
+        v = vn;
+    }
+    if (DIAG) {
+        // counts: every lane of a wave holds the wave's total; let lane 0 carry it
+        const bool lead = lane == 0;
+        double acc[kDiag] = {dsum_d, dsum_n, 0.0, 0.0, lead ? (double)nan_d : 0.0,
+                             lead ? (double)nan_n : 0.0, dmax_d, dmax_n};
+        diag_block_reduce(acc, a.diag_partial + (int64_t)blockIdx.x * kDiag);
+    }
+}
+
+// Sum of the per-block partials of et_kernel_dma<.., DIAG> in block order;
+// n_valid = n - n_nan.
+__global__ void __launch_bounds__(kBlock) diag_final_fused_kernel(const double* partial,
+                                                                  int nblocks, int64_t n,
+                                                                  double* out) {
+    double acc[kDiag] = {0, 0, 0, 0, 0, 0, -__builtin_huge_val(), -__builtin_huge_val()};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+        double o[kDiag];
+        for (int k = 0; k < kDiag; ++k) o[k] = partial[(int64_t)b * kDiag + k];
+        diag_merge(acc, o);
+    }
+    __shared__ double res[kDiag];
+    diag_block_reduce(acc, res);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = res[0];
+        out[1] = res[1];
+        out[2] = (double)n - res[4];
+        out[3] = (double)n - res[5];
+        out[4] = res[4];
+        out[5] = res[5];
+        out[6] = res[6];
+        out[7] = res[7];
+    }
 }
 
 // --------------------------------------------------------- synthetic fields

@@ -4,9 +4,9 @@
 //   ExactMath<T>  IEEE divide, ocml exp/pow -- used by the kernel variant that
 //                 keeps the reference's operation order (MOD16_MATH_EXACT);
 //   FastMath<T>   hardware reciprocal / reciprocal-square-root seeds refined by
-//                 Newton steps, range-reduced polynomial exp and log. Relative
-//                 error of each primitive is ~1e-14 (f64), far inside the
-//                 1e-5 parity budget; the f64 VALU rate, not HBM, is what a
+//                 one Newton step, table-driven exp and log (tables in LDS).
+//                 Relative error of each primitive is ~1e-14 (f64), far inside
+//                 the 1e-5 parity budget; the f64 VALU rate, not HBM, is what a
 //                 straight IEEE transcription of this pixel stack is bound by
 //                 (DESIGN.md "Arithmetic budget").
 #pragma once
@@ -47,81 +47,75 @@ template <> struct FastMath<double> {
     static __device__ __forceinline__ T div(T a, T b) { return a * rcp(b); }
 
     // x^(-7/4) for the r_corr term (mod16/__init__.py:771). Seed y = x^(-1/4)
-    // from v_rsq_f64 + v_sqrt_f64, two Newton steps on y^-4 = x, then y^7.
+    // from v_rsq_f64 + v_sqrt_f64 (relative error <= 5.3e-8, measured seeds
+    // 2^-24.2 and 2^-25.3), one Newton step on y^-4 = x (error 2.5 e^2 = 7e-15),
+    // then y^7 (5e-14).
     static __device__ __forceinline__ T pow_m1p75(T x) {
         T y = __builtin_amdgcn_sqrt(__builtin_amdgcn_rsq(x));
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            T y2 = y * y;
-            T t = x * (y2 * y2);
-            y = y * __builtin_fma(-0.25, t, 1.25);
-        }
         T y2 = y * y;
+        T t = x * (y2 * y2);
+        y = y * __builtin_fma(-0.25, t, 1.25);
+        y2 = y * y;
         T y4 = y2 * y2;
         return (y4 * y2) * y;
     }
 
-    // e^x, |rel err| < 1e-15 over the finite range; exp(-inf) = 0,
-    // exp(+inf) = inf, exp(NaN) = NaN.
-    static __device__ __forceinline__ T exp(T x) {
-        T xc = __builtin_fmin(__builtin_fmax(x, -746.0), 710.0);
-        T k = __builtin_rint(xc * 1.4426950408889634);
-        T r = __builtin_fma(k, -6.93147180369123816490e-01, xc);
-        r = __builtin_fma(k, -1.90821492927058770002e-10, r);
-        // Taylor to r^12 on |r| <= ln2/2: truncation 1.7e-16
-        T p = 1.0 / 479001600.0;
-        p = __builtin_fma(p, r, 1.0 / 39916800.0);
-        p = __builtin_fma(p, r, 1.0 / 3628800.0);
-        p = __builtin_fma(p, r, 1.0 / 362880.0);
-        p = __builtin_fma(p, r, 1.0 / 40320.0);
-        p = __builtin_fma(p, r, 1.0 / 5040.0);
-        p = __builtin_fma(p, r, 1.0 / 720.0);
-        p = __builtin_fma(p, r, 1.0 / 120.0);
-        p = __builtin_fma(p, r, 1.0 / 24.0);
+    // ---- table-driven exp / log (tables in LDS, filled by the library)
+    // tb[0..63]      = 2^(j/64)
+    // tb[64 + 2j..]  = { 1/c_j rounded, -log(1/c_j) },  c_j = 1 + (j + 1/2)/128
+    static constexpr int kTabDoubles = 64 + 2 * 128;
+
+    // e^x for finite x (no clamp: a huge |x| saturates through v_cvt_i32 and
+    // v_ldexp to 0 or inf; NaN -> NaN; +-inf -> NaN, callers clamp where -inf
+    // can occur). 12 f64-rate operations, relative error ~2e-16.
+    static __device__ __forceinline__ T exp_tab(T x, const T* tb) {
+        T kf = __builtin_rint(x * 92.33248261689366);               // 64 / ln 2
+        T r = __builtin_fma(kf, -0x1.62e42fee00000p-7, x);          // ln2/64, 32-bit head
+        r = __builtin_fma(kf, -0x1.a39ef35793c76p-39, r);
+        T p = __builtin_fma(r, 1.0 / 120.0, 1.0 / 24.0);            // |r| <= ln2/128
         p = __builtin_fma(p, r, 1.0 / 6.0);
         p = __builtin_fma(p, r, 0.5);
         p = __builtin_fma(p, r, 1.0);
         p = __builtin_fma(p, r, 1.0);
-        T v = __builtin_amdgcn_ldexp(p, (int)k);
-        return (x == x) ? v : x;
+        int ki = (int)kf;
+        return __builtin_amdgcn_ldexp(tb[ki & 63] * p, ki >> 6);
     }
 
-    // ln(x) for x >= 0 (x is a relative humidity in [0, 1] here):
-    // log(0) = -inf, log(NaN) = NaN. |rel err| ~ 1e-15.
-    static __device__ __forceinline__ T log(T x) {
-        T m = __builtin_amdgcn_frexp_mant(x);          // [0.5, 1)
-        int e = __builtin_amdgcn_frexp_exp(x);
-        bool lo = m < 0.70710678118654752440;
-        m = lo ? m + m : m;                             // [sqrt(.5), sqrt(2))
-        e = lo ? e - 1 : e;
-        T f = m - 1.0;
-        T s = f * rcp(2.0 + f);
-        T z = s * s;
-        // atanh series: log(m) = 2s (1 + z/3 + z^2/5 + ...), z <= 0.0295
-        T p = 1.0 / 21.0;
-        p = __builtin_fma(p, z, 1.0 / 19.0);
-        p = __builtin_fma(p, z, 1.0 / 17.0);
-        p = __builtin_fma(p, z, 1.0 / 15.0);
-        p = __builtin_fma(p, z, 1.0 / 13.0);
-        p = __builtin_fma(p, z, 1.0 / 11.0);
-        p = __builtin_fma(p, z, 1.0 / 9.0);
-        p = __builtin_fma(p, z, 1.0 / 7.0);
-        p = __builtin_fma(p, z, 1.0 / 5.0);
-        p = __builtin_fma(p, z, 1.0 / 3.0);
-        T sz = s * z;
-        T lm = __builtin_fma(sz, p, s);                 // s + s z p
-        lm = lm + lm;
+    // ln(x) for x > 0 normal (x is a relative humidity in (0, 1] here);
+    // log(1) is exactly 0 by construction of table entry 0; x = 0 -> -inf.
+    // Absolute error ~1e-16 (what matters: the result feeds exp(y log x)).
+    static __device__ __forceinline__ T log_tab(T x, const T* tb) {
+        const unsigned hi = (unsigned)__double2hiint(x);
+        const int e = (int)(hi >> 20) - 1023;
+        const unsigned j = (hi >> 13) & 127u;
+        const T m = __hiloint2double((int)((hi & 0x000fffffu) | 0x3ff00000u), __double2loint(x));
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2 ent = *reinterpret_cast<const d2*>(tb + 64 + 2 * j);
+        T r = __builtin_fma(m, ent[0], -1.0);                        // |r| <= 1/256
+        T l1p = log1p_poly(r);
         T ed = (T)e;
-        T v = __builtin_fma(ed, 6.93147180369123816490e-01, lm);
-        v = __builtin_fma(ed, 1.90821492927058770002e-10, v);
+        T v = __builtin_fma(ed, 0x1.62e42fefa2000p-1, ent[1]);      // ln2, 40-bit head
+        v = v + l1p;
+        v = __builtin_fma(ed, 7.371002565167799e-13, v);
         return (x == 0.0) ? -__builtin_huge_val() : v;
     }
+    // r - r^2/2 + ... - r^6/6 ; the host evaluates the same sequence (std::fma)
+    // to make table entry 0 cancel exactly at x = 1
+    static __host__ __device__ __forceinline__ T log1p_poly(T r) {
+        T p = __builtin_fma(r, -1.0 / 6.0, 1.0 / 5.0);
+        p = __builtin_fma(p, r, -0.25);
+        p = __builtin_fma(p, r, 1.0 / 3.0);
+        p = __builtin_fma(p, r, -0.5);
+        return __builtin_fma(r * r, p, r);
+    }
 
-    // x^y for x in [0, 1] (rh ** (vpd / beta), mod16/__init__.py:861)
-    static __device__ __forceinline__ T pow01(T x, T y) {
-        T v = exp(y * log(x));
-        // 1 ** y = 1 for every y incl. inf and NaN (C pow); y == 0 -> 1
-        return (x == 1.0 || y == 0.0) ? 1.0 : v;
+    // x^y for x in [0, 1] (rh ** (vpd / beta), mod16/__init__.py:861).
+    // C pow semantics kept for: 0^y = 0 (y > 0), 1^y = 1 for every y incl. inf
+    // and NaN (log_tab(1) = 0 exactly and y is clamped finite), x^0 = 1.
+    static __device__ __forceinline__ T pow01_tab(T x, T y, const T* tb) {
+        T yc = __builtin_fmin(y, 1e300);
+        T t = __builtin_fmax(yc * log_tab(x, tb), -746.0);
+        return exp_tab(t, tb);
     }
 };
 
@@ -149,8 +143,11 @@ template <> struct FastMath<float> {
         T y4 = y2 * y2;
         return (y4 * y2) * y;
     }
+    static constexpr int kTabDoubles = 0;
     static __device__ __forceinline__ T exp(T x) { return ::expf(x); }
     static __device__ __forceinline__ T log(T x) { return ::logf(x); }
+    static __device__ __forceinline__ T exp_tab(T x, const T*) { return ::expf(x); }
+    static __device__ __forceinline__ T pow01_tab(T x, T y, const T*) { return pow01(x, y); }
     static __device__ __forceinline__ T pow01(T x, T y) {
         T v = ::expf(y * ::logf(x));
         return (x == 1.0f || y == 0.0f) ? 1.0f : v;

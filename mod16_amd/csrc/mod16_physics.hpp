@@ -251,14 +251,18 @@ template <typename T> struct PixelShared {
 
 template <typename T, bool DAY>
 __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<T>& p,
-                                            const PixelShared<T>& sh, T t, T vpd, T rad_net,
-                                            T rad_soil, T& canopy, T& soil, T& trans) {
+                                            const PixelShared<T>& sh, const T* tb, T t, T vpd,
+                                            T rad_net, T rad_soil, T& canopy, T& soil,
+                                            T& trans) {
     typedef FastMath<T> M;
     const T tiny = K<T>::tiny;
     const T cp = K<T>::cp;
     // -- humidity, :646-673 and :763-764
     T tc = t - K<T>::t0;
-    T esat = T(1e3 * 0.6108) * M::exp((T(17.27) * tc) * M::rcp(tc + T(237.3)));
+    // tc * 0 is NaN for a NaN (or infinite) temperature and 0 otherwise: it
+    // carries the NaN that exp_tab's integer path would drop
+    T esat = __builtin_fma(T(1e3 * 0.6108),
+                           M::exp_tab((T(17.27) * tc) * M::rcp(tc + T(237.3)), tb), tc * T(0));
     T avp = esat - vpd;
     T rh = avp * M::rcp(esat);
     rh = (avp < T(0)) ? T(0) : ((rh > T(1)) ? T(1) : rh);
@@ -305,11 +309,11 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
         T num = __builtin_fma((s * rad_soil), r_tot, (rcfv * sh.omf) * w);
         T den = r_tot * __builtin_fma(sh.k_p, w, slhv);
         T q = num * M::rcp(den);                                   // numer/denom/lhv
-        T sat = q * fwet;
-        T unsat = q * omw;
-        T pw = M::pow01(rh, vpd * p.inv_beta);                     // :861
-        T e = (sat < T(0)) ? T(0) : sat;
-        soil = e + ((unsat < T(0)) ? T(0) : unsat * pw);
+        T pw = M::pow01_tab(rh, vpd * p.inv_beta, tb);             // :861
+        // sat = q fwet and unsat = q (1 - fwet) with 0 <= fwet <= 1: both
+        // clamps of :858-861 fire exactly when q < 0 (NaN falls through)
+        T e = q * __builtin_fma(omw, pw, fwet);
+        soil = (q < T(0)) ? T(0) : e;
     }
     // -- transpiration, :1152-1258, with g_canopy = P1 / S1 kept as a ratio
     {
@@ -338,8 +342,16 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
 }
 
 template <typename T>
-__device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const ClassPar<T>& p) {
+__device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const ClassPar<T>& p,
+                                                     const T* tb) {
     PixelOut<T> o;
+#ifdef MOD16_TRIVIAL_BODY   // experiment: memory pattern only, no arithmetic
+    o.canopy_d = x.lw_d + x.sw_d + x.alb + x.t_d + x.t_ann + x.vpd_d + x.pa;
+    o.soil_d = p.beta; o.trans_d = x.fpar;
+    o.canopy_n = x.lw_n + x.sw_n + x.t_n + x.tmin + x.vpd_n + x.lai;
+    o.soil_n = p.csl; o.trans_n = p.gl_sh;
+    return o;
+#endif
     PixelShared<T> sh;
     sh.oma = T(1) - x.alb;
     sh.omf = T(1) - x.fpar;
@@ -369,9 +381,9 @@ __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const 
     T tm = x.tmin - K<T>::t0;
     sh.m_tmin = (tm >= p.tmin_open) ? T(1)
                 : ((tm < p.tmin_close) ? T(0) : (tm - p.tmin_close) * p.inv_dtmin);
-    period_fast<T, true>(x, p, sh, x.t_d, x.vpd_d, a_d, rs_d, o.canopy_d, o.soil_d, o.trans_d);
+    period_fast<T, true>(x, p, sh, tb, x.t_d, x.vpd_d, a_d, rs_d, o.canopy_d, o.soil_d, o.trans_d);
     T rn_n = __builtin_fma(x.sw_n, sh.oma, x.lw_n);
-    period_fast<T, false>(x, p, sh, x.t_n, x.vpd_n, rn_n, rs_n, o.canopy_n, o.soil_n, o.trans_n);
+    period_fast<T, false>(x, p, sh, tb, x.t_n, x.vpd_n, rn_n, rs_n, o.canopy_n, o.soil_n, o.trans_n);
     return o;
 }
 

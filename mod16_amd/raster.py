@@ -110,10 +110,13 @@ class RasterEngine(object):
             _lib.ptr_array(ptrs), self._stream()))
         return cls, drivers
 
-    def run(self, cls, drivers, out_day=None, out_night=None, out_sep=None):
+    def run(self, cls, drivers, out_day=None, out_night=None, out_sep=None, diag=None):
         '''Enqueue the fused ET kernel on the current stream; returns
-        ``(day, night)`` tensors (allocated unless given). Asynchronous: call
-        ``check()`` (or synchronise the stream) before trusting the data.'''
+        ``(day, night)`` tensors (allocated unless given). With ``diag`` (a
+        float64 tensor of 8 on the device) the diagnostics vector
+        (``DIAG_FIELDS``) is produced in the same pass (``mod16_et_diag_*``).
+        Asynchronous: call ``check()`` (or synchronise the stream) before
+        trusting the data.'''
         torch = _torch()
         n = cls.numel()
         cptr = self._check_tensor(cls, torch.uint8, n, 'cls')
@@ -122,6 +125,16 @@ class RasterEngine(object):
             out_day, out_night = self.empty(n, 2)
         pd = self._check_tensor(out_day, self.dtype, n, 'out_day') if out_day is not None else None
         pn = self._check_tensor(out_night, self.dtype, n, 'out_night') if out_night is not None else None
+        if diag is not None:
+            if out_sep is not None:
+                raise ValueError('diag and out_sep cannot be combined')
+            fn = self.ctx.lib.mod16_et_diag_f32 if self.np_dtype == np.float32 \
+                else self.ctx.lib.mod16_et_diag_f64
+            self.ctx.check(fn(
+                self.ctx.handle, cptr, _lib.ptr_array(dptr), _lib.i64_array(dstride), n,
+                pd, pn, int(self.math),
+                self._check_tensor(diag, torch.float64, 8, 'diag'), self._stream()))
+            return out_day, out_night
         sep = None
         if out_sep is not None:
             sep = [self._check_tensor(t, self.dtype, n, 'out_sep') if t is not None else None
@@ -150,8 +163,9 @@ class RasterEngine(object):
             self._check_tensor(out, torch.float64, 8, 'out'), self._stream()))
         return out
 
-    def time_kernel(self, cls, drivers, out_day, out_night, launches=10):
-        '''Mean milliseconds per launch of the fused kernel, measured with HIP
+    def time_kernel(self, cls, drivers, out_day, out_night, launches=10, diag=None):
+        '''Mean milliseconds per launch of the fused kernel (with ``diag``: of
+        the kernel that also reduces the diagnostics), measured with HIP
         events on the stream the kernel runs on (``mod16_time_et``).'''
         torch = _torch()
         n = cls.numel()
@@ -163,5 +177,7 @@ class RasterEngine(object):
             _lib.ptr_array(dptr), _lib.i64_array(dstride), None, None, n,
             self._check_tensor(out_day, self.dtype, n, 'out_day'),
             self._check_tensor(out_night, self.dtype, n, 'out_night'), None,
-            int(self.math), int(launches), self._stream(), C.byref(ms)))
+            int(self.math),
+            self._check_tensor(diag, torch.float64, 8, 'diag') if diag is not None else None,
+            int(launches), self._stream(), C.byref(ms)))
         return ms.value

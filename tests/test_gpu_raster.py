@@ -1,0 +1,141 @@
+"""GPU tests of the device-resident path (RasterEngine over the C ABI in
+DEVICE mode): on-device generator, zero-copy forward run, diagnostics."""
+import numpy as np
+import pytest
+
+from oracle import mod16_oracle as oracle
+from parity import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    from mod16_amd.raster import RasterEngine
+    from mod16_amd.utils import restore_bplut, bplut_table
+    from mod16_amd.models import COLLECTION61_BPLUT
+    table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
+    return torch, RasterEngine, table
+
+
+def to_np(ts):
+    return [t.cpu().numpy() for t in ts]
+
+
+def test_generator_is_tiling_invariant(env):
+    """Any split of the raster over ranks sees the same field."""
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table)
+    n = 300000
+    cls, drv = eng.synth(n, seed=16)
+    parts = [eng.synth(m, seed=16, pixel_offset=off) for off, m in ((0, 100001), (100001, 199999))]
+    assert torch.equal(cls, torch.cat([p[0] for p in parts]))
+    for k in range(14):
+        a = drv[k]
+        b = torch.cat([p[1][k] for p in parts])
+        assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0)), k
+    # the field is what SURVEY.md section 8d prescribes
+    h = to_np(drv)
+    c = cls.cpu().numpy()
+    assert set(np.unique(c)) <= set(range(13)) and (c == 0).any() and (c == 11).any()
+    assert (h[3] == 0).all()                                 # sw_rad_night
+    assert 254 < np.nanmin(h[5]) and np.nanmax(h[5]) < 306   # temp_day
+    assert (h[5] - h[6] >= 0).all() and (h[6] - h[8] >= 0).all()
+    assert np.isnan(h[12]).mean() > 0.002 and (h[12] == 0).any() and (h[12] == 1).any()
+    assert (h[13] == 0).any() and np.isnan(h[13]).any()
+    # different seed / step -> different field; land cover stays
+    cls2, drv2 = eng.synth(n, seed=16, step=1)
+    assert torch.equal(cls, cls2) and not torch.equal(drv[5], drv2[5])
+
+
+@pytest.mark.parametrize('dtype,rtol', [('float64', 1e-8)])
+def test_device_run_matches_oracle_and_host_path(env, dtype, rtol):
+    torch, RasterEngine, table = env
+    import mod16_amd
+    eng = RasterEngine(table, dtype=dtype)
+    n = 1200 * 1200
+    cls, drv = eng.synth(n, seed=7)
+    day, night = eng.run(cls, drv)
+    eng.check()
+    h_cls, h_drv = cls.cpu().numpy(), to_np(drv)
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    wd, wn = oracle.evapotranspiration_raster(bplut, h_cls, *h_drv)
+    assert_parity(day.cpu().numpy(), wd, rtol, 'day')
+    assert_parity(night.cpu().numpy(), wn, rtol, 'night')
+    # numpy-in/numpy-out path gives bit-identical results (same kernel)
+    hd, hn = mod16_amd.evapotranspiration_raster(table, h_cls, *h_drv)
+    assert np.array_equal(hd, day.cpu().numpy(), equal_nan=True)
+    assert np.array_equal(hn, night.cpu().numpy(), equal_nan=True)
+    # components on request
+    sep = eng.empty(n, 6)
+    eng.run(cls, drv, out_sep=sep)
+    ws = oracle.evapotranspiration_raster(bplut, h_cls, *h_drv, separate=True)
+    for got, want in zip(to_np(sep), list(ws[0]) + list(ws[1])):
+        assert_parity(got, want, rtol, 'component')
+
+
+def test_exact_and_fast_kernels_agree_on_device(env):
+    """Size-independent cross-check used at full raster sizes: the production
+    kernel against the reference-order kernel, compared on the GPU."""
+    torch, RasterEngine, table = env
+    from mod16_amd import _lib
+    n = 4 * 1000 * 1000
+    fast = RasterEngine(table)
+    exact = RasterEngine(table, math=_lib.MATH_EXACT)
+    cls, drv = fast.synth(n, seed=3)
+    d1, n1 = fast.run(cls, drv)
+    d2, n2 = exact.run(cls, drv)
+    fast.check()
+    for a, b in ((d1, d2), (n1, n2)):
+        assert torch.equal(torch.isnan(a), torch.isnan(b))
+        assert torch.equal(a == 0, b == 0)
+        ok = torch.isfinite(b) & (b != 0)
+        rel = ((a[ok] - b[ok]).abs() / b[ok].abs())
+        assert float(rel.max()) < 1e-7 and float(rel.median()) < 1e-13
+
+
+def test_diagnostics_fused_standalone_numpy(env):
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table)
+    for n in (2 * 123457, 1200 * 1200 + 1):    # even: in-kernel reduction; odd: fallback
+        cls, drv = eng.synth(n, seed=5)
+        day, night = eng.empty(n, 2)
+        fused = torch.zeros(8, dtype=torch.float64, device='cuda')
+        eng.run(cls, drv, day, night, diag=fused)
+        alone = eng.diagnostics(day, night)
+        eng.check()
+        d, g = day.cpu().numpy(), night.cpu().numpy()
+        want = np.array([np.nansum(d), np.nansum(g), (~np.isnan(d)).sum(), (~np.isnan(g)).sum(),
+                         np.isnan(d).sum(), np.isnan(g).sum(), np.nanmax(d), np.nanmax(g)])
+        for got in (fused.cpu().numpy(), alone.cpu().numpy()):
+            np.testing.assert_allclose(got[:2], want[:2], rtol=1e-12)
+            assert np.array_equal(got[2:], want[2:]), (got, want)
+        # deterministic: a second launch gives the same bits
+        again = torch.zeros(8, dtype=torch.float64, device='cuda')
+        eng.run(cls, drv, day, night, diag=again)
+        assert torch.equal(fused, again)
+
+
+def test_deferred_class_range_error(env):
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table)
+    cls, drv = eng.synth(4096, seed=1)
+    cls[77] = 200
+    day, night = eng.run(cls, drv)
+    with pytest.raises(IndexError):
+        eng.check()
+    assert bool(torch.isnan(day[77])) and bool(torch.isnan(night[77]))
+    eng.check()      # flag cleared
+
+
+def test_scalar_driver_on_device(env):
+    """sw_rad_night = 0 as a broadcast scalar instead of a dense array."""
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table)
+    cls, drv = eng.synth(50000, seed=2)
+    d1, n1 = eng.run(cls, drv)
+    d2, n2 = eng.run(cls, drv[:3] + [0.0] + drv[4:])
+    eng.check()
+    assert torch.equal(torch.nan_to_num(d1), torch.nan_to_num(d2))
+    assert torch.equal(torch.nan_to_num(n1), torch.nan_to_num(n2))

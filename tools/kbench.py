@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Kernel-only timing of the fused ET kernel for one or more builds of the
+library (interleaved rounds in one process per build are not possible with
+ctypes-loaded same-named symbols, so each build runs in a child process).
+
+  python tools/kbench.py [--rows 4320] [--launches 10] [--rounds 3] lib1.so lib2.so ...
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def child(args):
+    sys.path.insert(0, ROOT)
+    import torch
+    from mod16_amd import _lib
+    from mod16_amd.raster import RasterEngine
+    from mod16_amd.utils import restore_bplut, bplut_table
+    from mod16_amd.models import COLLECTION61_BPLUT
+    table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
+    math = _lib.MATH_EXACT if args.math == 'exact' else _lib.MATH_FAST
+    eng = RasterEngine(table, dtype=args.dtype, math=math)
+    n = args.rows * 43200
+    if args.stagger:
+        # experiment: offset the arrays' base addresses against each other
+        pad = args.stagger * 16 // 8
+        bufs = [torch.empty(n + pad, dtype=eng.dtype, device='cuda') for _ in range(16)]
+        views = [b[(k * args.stagger // 8) % (pad + 1):][:n] for k, b in enumerate(bufs)]
+        drv, (day, night) = views[:14], views[14:]
+        cls = torch.empty(n, dtype=torch.uint8, device='cuda')
+        eng.synth(n, seed=16, out=(cls, drv))
+    else:
+        cls, drv = eng.synth(n, seed=16)
+        day, night = eng.empty(n, 2)
+    eng.time_kernel(cls, drv, day, night, launches=2)
+    ms = [eng.time_kernel(cls, drv, day, night, launches=args.launches) for _ in range(args.rounds)]
+    best = min(ms)
+    print(json.dumps({'lib': os.path.basename(_lib.LIB_PATH), 'ms': ms, 'best_ms': best,
+                      'gpix_s': n / best / 1e6, 'GBps': eng.bytes_per_pixel * n / best / 1e6,
+                      'frac_8TBs': eng.bytes_per_pixel * n / best / 1e6 / 8000}))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rows', type=int, default=4320)
+    ap.add_argument('--launches', type=int, default=10)
+    ap.add_argument('--rounds', type=int, default=3)
+    ap.add_argument('--dtype', default='float64')
+    ap.add_argument('--math', default='fast')
+    ap.add_argument('--child', action='store_true')
+    ap.add_argument('--stagger', type=int, default=0, help='bytes between successive array bases (mod allocation)')
+    ap.add_argument('libs', nargs='*')
+    args = ap.parse_args()
+    if args.child:
+        return child(args)
+    libs = args.libs or [os.path.join(ROOT, 'mod16_amd', 'libmod16hip.so')]
+    for lib in libs:
+        env = dict(os.environ, MOD16_LIB=os.path.abspath(lib))
+        subprocess.run([sys.executable, __file__, '--child', '--rows', str(args.rows),
+                        '--launches', str(args.launches), '--rounds', str(args.rounds),
+                        '--dtype', args.dtype, '--math', args.math, '--stagger', str(args.stagger)], env=env, check=False)
+
+
+if __name__ == '__main__':
+    main()

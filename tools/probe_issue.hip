@@ -3,6 +3,7 @@
 // hipcc --offload-arch=gfx950 -O3 tools/probe_issue.hip -o tools/bin/probe_issue
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 #define REP8(x) x x x x x x x x
 #define BODY(NAME, ASM, ...)                                                          \
@@ -77,8 +78,10 @@ template <typename K> float time_it(K k, double* out, int iters, int blocks) {
     float ms; hipEventElapsedTime(&ms, e0, e1); return ms;
 }
 
-int main() {
-    const int iters = 1000, blocks = 256 * 8;
+int main(int argc, char** argv) {
+    const int per_cu = argc > 1 ? atoi(argv[1]) : 8;   // 256-thread blocks per CU = waves per SIMD
+    const int iters = 1000, blocks = 256 * per_cu;
+    printf("waves per SIMD: %d\n", per_cu);
     double* out; hipMalloc(&out, (size_t)blocks * 256 * 8);
     // wave-instructions issued per SIMD: blocks*4 waves / 1024 SIMDs * iters * 32
     const double wi_per_simd = (double)blocks * 4 / 1024 * iters * 32;
