@@ -1,0 +1,86 @@
+"""The C-ABI library: it loads, exports every function include/mod16_hip.h
+declares, and the ctypes prototypes cover exactly that set. No compute call is
+made here (no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, 'include', 'mod16_hip.h')
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'MOD16_API\s+[\w\s\*]+?\b(mod16_\w+)\s*\(', text)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from mod16_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    assert len(names) >= 16
+    for must in ('mod16_create', 'mod16_destroy', 'mod16_set_bplut_f64', 'mod16_et_f64',
+                 'mod16_et_f32', 'mod16_et_diag_f64', 'mod16_reduce_diag_f64',
+                 'mod16_synth_f64', 'mod16_check_status', 'mod16_strerror'):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(lib):
+    cdll = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(cdll, name), 'libmod16hip.so does not export %s' % name
+
+
+def test_ctypes_prototypes_match_the_header(lib):
+    assert sorted(lib.PROTOTYPES) == declared_functions()
+    loaded = lib.load()
+    assert loaded.mod16_version() == 1
+    assert loaded.mod16_strerror(0) == b'ok'
+    assert b'class' in loaded.mod16_strerror(lib.ERR_CLASS_RANGE)
+    assert loaded.mod16_strerror(-99) == b'unknown status'
+
+
+def test_enums_agree_with_python_constants(lib):
+    text = open(HEADER).read()
+    for name, value in (('MOD16_ERR_ARG', lib.ERR_ARG), ('MOD16_ERR_HIP', lib.ERR_HIP),
+                        ('MOD16_ERR_CLASS_RANGE', lib.ERR_CLASS_RANGE),
+                        ('MOD16_ERR_NO_DEVICE', lib.ERR_NO_DEVICE),
+                        ('MOD16_ERR_NO_BPLUT', lib.ERR_NO_BPLUT)):
+        assert re.search(r'%s\s*=\s*%d\b' % (name, value), text), name
+    assert re.search(r'#define MOD16_N_DRIVERS 14', text) and lib.N_DRIVERS == 14
+    assert re.search(r'#define MOD16_N_PARAMS 11', text) and lib.N_PARAMS == 11
+    assert re.search(r'#define MOD16_N_CLASSES 13', text) and lib.N_CLASSES == 13
+
+
+def test_no_device_fails_loudly(lib):
+    """Without an MI355X the product path raises; it never computes on the CPU."""
+    if lib.device_count() > 0:
+        pytest.skip('a GPU is present')
+    handle = ctypes.c_void_p()
+    assert lib.load().mod16_create(0, ctypes.byref(handle)) == lib.ERR_NO_DEVICE
+    assert not handle.value
+    import mod16_amd
+    model = mod16_amd.MOD16(dict.fromkeys(mod16_amd.MOD16.required_parameters, 1.0))
+    with pytest.raises(lib.Mod16Error, match='no CPU fallback'):
+        model.evapotranspiration(*([1.0] * 14))
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under mod16_amd/ may import it."""
+    pkg = os.path.join(ROOT, 'mod16_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp', '.h')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f

@@ -1,0 +1,60 @@
+"""Tile sharding over ranks, on the CPU: band arithmetic, and a world_size-2
+gloo run in which each rank computes its row band (with the oracle) and the
+diagnostics vectors are all-reduced -- the N > 1 structure of bench.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from mod16_amd import dist as tiles
+
+
+@pytest.mark.parametrize('rows,world', [(21600, 1), (21600, 2), (21600, 8), (10, 3), (7, 8)])
+def test_bands_tile_the_raster(rows, world):
+    edges = [tiles.band(rows, r, world) for r in range(world)]
+    assert edges[0][0] == 0 and edges[-1][1] == rows
+    for (a0, a1), (b0, b1) in zip(edges, edges[1:]):
+        assert a1 == b0 and a0 <= a1
+    sizes = [b - a for a, b in edges]
+    assert max(sizes) - min(sizes) <= 1
+    off = [tiles.pixel_range(rows, 43200, r, world) for r in range(world)]
+    assert sum(n for _, n in off) == rows * 43200
+    assert all(o == e[0] * 43200 for (o, _), e in zip(off, edges))
+    with pytest.raises(ValueError):
+        tiles.band(rows, world, world)
+
+
+def test_global_grid_bands_are_vector_aligned():
+    """Every band of the 43200 x 21600 grid starts on a 16-byte boundary and
+    has an even pixel count for 1, 2, 4 and 8 GPUs (the fused path needs it)."""
+    for world in (1, 2, 4, 8):
+        for r in range(world):
+            off, n = tiles.pixel_range(tiles.GLOBAL_ROWS, tiles.GLOBAL_COLS, r, world)
+            assert off % 2 == 0 and n % 4 == 0
+            assert n == tiles.GLOBAL_ROWS // world * tiles.GLOBAL_COLS
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_gloo_bands_and_allreduce(tmp_path):
+    out = tmp_path / 'result.json'
+    env = dict(os.environ, MOD16_DIST_OUT=str(out), OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
+           os.path.join(ROOT, 'tests', 'dist_worker.py')]
+    proc = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    res = json.loads(out.read_text())
+    assert res['world'] == 2
+    np.testing.assert_allclose(res['reduced'][:2], res['global'][:2], rtol=1e-12)
+    assert res['reduced'][2:] == res['global'][2:]
+    assert res['bands_identical_to_global']

@@ -1,0 +1,102 @@
+"""Host-side logic of the drop-in surface (no GPU): BPLUT parsing against the
+reference's own parse (golden), model construction, marshalling rules."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+import mod16_amd
+from mod16_amd import models, utils
+
+
+def test_restore_bplut_matches_reference_parse(golden):
+    tables = golden('bplut_tables')
+    assert len(tables.files) == 5
+    for fn in tables.files:
+        got = utils.restore_bplut(os.path.join(utils.DATA_DIR, fn))
+        assert list(got) == list(utils.BPLUT_FIELD_LOOKUP.values())
+        table = np.stack([got[k] for k in mod16_amd.MOD16.required_parameters], 1)
+        assert np.array_equal(table, tables[fn], equal_nan=True), fn
+        assert np.isnan(got['beta']).all()              # no beta row in any file
+        assert np.isnan(got['gl_sh'][[0, 11]]).all()    # codes that are not PFTs
+    # buffers work as paths do
+    path = os.path.join(utils.DATA_DIR, tables.files[0])
+    a = utils.restore_bplut(io.StringIO(open(path).read()))
+    assert np.array_equal(a['csl'], utils.restore_bplut(path)['csl'], equal_nan=True)
+
+
+def test_write_bplut_round_trip(tmp_path):
+    src = utils.restore_bplut(models.COLLECTION61_BPLUT)
+    src['beta'] = np.where(np.isnan(src['csl']), np.nan, 250.0)
+    out = tmp_path / 'bplut.csv'
+    utils.write_bplut(src, str(out))
+    back = utils.restore_bplut(str(out))
+    for k in src:
+        assert np.array_equal(src[k], back[k], equal_nan=True), k
+
+
+def test_collection61_parameters(golden):
+    want = golden('collection61_params')['table']
+    for pft in mod16_amd.PFT_VALID:
+        m = models.MOD16Collection61(pft)
+        got = [getattr(m, k) for k in mod16_amd.MOD16.required_parameters]
+        assert np.array_equal(got, want[pft]), pft
+        assert m.beta == 250 and m.params['beta'] == 250
+    with pytest.raises(AssertionError):
+        models.MOD16Collection61(11)
+    assert models.PFT_ALL['Croplands (CRO)'] == 12 and len(models.PFT_ALL) == 11
+
+
+def test_constructor_contract():
+    p = dict.fromkeys(mod16_amd.MOD16.required_parameters, 2.0)
+    m = mod16_amd.MOD16(p)
+    assert m.params is p and m.csl == 2.0
+    del p['beta']
+    with pytest.raises(KeyError):
+        mod16_amd.MOD16(p)
+    assert mod16_amd.MOD16.required_parameters == [
+        'tmin_close', 'tmin_open', 'vpd_open', 'vpd_close', 'gl_sh', 'gl_wv',
+        'g_cuticular', 'csl', 'rbl_min', 'rbl_max', 'beta']
+    assert mod16_amd.PFT_VALID == (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12)
+    assert mod16_amd.SPECIFIC_HEAT_CAPACITY_AIR == 1013
+    assert mod16_amd.STEFAN_BOLTZMANN == 5.67e-8
+
+
+def test_bplut_table_layout():
+    src = utils.restore_bplut(models.COLLECTION61_BPLUT)
+    t = utils.bplut_table(src, beta=250)
+    assert t.shape == (13, 11) and t.flags.c_contiguous
+    assert t[7, 3] == 4400 and t[12, 7] == 0.0055          # vpd_close OSH, csl CRO
+    assert np.isnan(t[0]).all() and np.isnan(t[11]).all()  # beta only where a PFT exists
+    assert (t[[1, 5, 12], 10] == 250).all()
+    assert np.isnan(utils.bplut_table(src)[:, 10]).all()
+
+
+def test_pft_dominant():
+    pft_map = np.array([[1, 1, 2, 0], [11, 0, 0, 0], [4, 5, 5, 5], [7, 7, 7, 7]])
+    got = utils.pft_dominant(pft_map)
+    assert got.dtype == np.float32 and list(got) == [1, 0, 5, 7]
+    got = utils.pft_dominant(pft_map, site_list=['a', 'US-A10', 'CA-SF2', 'US-NGC'])
+    assert list(got) == [1, 0, 3, 3]
+
+
+def test_result_dtype_follows_numpy_rules():
+    f32, f64 = np.float32, np.float64
+    rd = mod16_amd._result_dtype
+    assert rd([np.ones(3, f32), 1.0, 2]) == f32           # Python scalars are weak
+    assert rd([np.ones(3, f32), np.float64(1.0)]) == f64  # numpy float64 scalar is not
+    assert rd([np.ones(3, f32), np.ones(3, f64)]) == f64
+    assert rd([np.ones(3, np.int64), np.ones(3, f32)]) == f64
+    assert rd([1.0, 2.0]) == f64
+
+
+def test_marshal_strides_and_broadcast():
+    shape = (4, 5)
+    vals = [3.0, np.arange(5.0), np.ones(shape), np.float32(2)]
+    keep, ptrs, strides = mod16_amd._marshal(vals, shape, np.float64)
+    assert strides == [0, 1, 1, 0]
+    assert keep[1].shape == shape and keep[1].flags.c_contiguous
+    assert np.array_equal(keep[1][2], np.arange(5.0))
+    assert all(k.dtype == np.float64 for k in keep)
+    assert ptrs[2] == keep[2].ctypes.data
