@@ -35,6 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md)
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r01c_pmc_hbm_traffic.json')
 TILE = (1200, 1200)           # BASELINE.json configs[1], the CPU sample unit
 SEED = 16
 
@@ -83,6 +84,21 @@ def cpu_baseline(max_workers):
                        'wall_s': wall}
     out['global_grid_seconds_1core'] = 43200 * 21600 / out['value']
     return out
+
+
+def pmc_traffic(pixels_per_launch, dtype):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
+    PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected separately, see the file);
+    counters cannot be read from inside this process, so the figure applies
+    only when this run launches the same kernel on the same pixel count."""
+    try:
+        with open(PMC_TRAFFIC) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if rec.get('pixels_per_launch') == pixels_per_launch and rec.get('dtype') == dtype:
+        return rec['traffic_bytes_per_launch']
+    return None
 
 
 def main():
@@ -203,7 +219,9 @@ def main():
             'roofline': {
                 'bound': 'hbm', 'kernel': 'et_kernel_dma<%s, fast, diag>' % args.dtype, 'achieved': achieved,
                 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
-                'traffic': None, 'bytes_per_pixel': bpp, 'pixels_per_launch': n,
+                'traffic': pmc_traffic(n, args.dtype) if args.math == 'fast' else None,
+                'traffic_source': os.path.relpath(PMC_TRAFFIC, ROOT), 'traffic_unit': 'bytes per launch',
+                'bytes_per_pixel': bpp, 'pixels_per_launch': n,
                 'kernel_ms': kernel_ms, 'kernel_pixels_per_s': n / (kernel_ms * 1e-3),
             },
             'cpu_baseline': cpu,

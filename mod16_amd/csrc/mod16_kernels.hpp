@@ -252,8 +252,13 @@ __global__ void __launch_bounds__(kBlock) diag_final_kernel(const double* partia
 // current one: issue -> compute(i) -> counted vmcnt -> ds_read_b128 -> issue ...
 // The slot is private to the wave that fills it, so no barrier is involved:
 // the wave's own counted s_waitcnt vmcnt orders its ds_reads behind its DMA.
+// Every byte is touched once, so both directions use the non-temporal policy
+// (nt): +3-4 % on the 14-read + 2-write stream mix (profiles/r01_probe_streams*).
 #ifndef MOD16_DMA_AUX
-#define MOD16_DMA_AUX 0      // cache-policy bits of the LDS-DMA loads (2 = nt)
+#define MOD16_DMA_AUX 2      // cache-policy bits of the LDS-DMA loads (2 = nt)
+#endif
+#ifndef MOD16_PLAIN_STORE
+#define MOD16_NT_STORE 1
 #endif
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;

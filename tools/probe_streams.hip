@@ -21,8 +21,12 @@ __global__ void __launch_bounds__(256) stream_kernel(Args a) {
         if (CLS) s[0] += (double)a.cls[v];
 #pragma unroll
         for (int w = 0; w < W; ++w) {
-            if (NT & 2) __builtin_nontemporal_store(s + (double)w, &a.out[w][v]);
-            else a.out[w][v] = s + (double)w;
+            d2 val = s + (double)w;
+            if ((NT & 12) == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(&a.out[w][v]), "v"(val) : "memory");
+            else if ((NT & 12) == 8) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(&a.out[w][v]), "v"(val) : "memory");
+            else if ((NT & 12) == 12) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(&a.out[w][v]), "v"(val) : "memory");
+            else if (NT & 2) __builtin_nontemporal_store(val, &a.out[w][v]);
+            else a.out[w][v] = val;
         }
         if (W == 0 && s[0] == 1.2345e300) a.out[0][v] = s;   // keep the loads alive
     }
@@ -47,7 +51,7 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 4; ++k) hipMalloc((void**)&a.out[k], nvec * 16);
     hipMalloc((void**)&a.cls, nvec * 2); hipMemset((void*)a.cls, 1, nvec * 2);
     a.nvec = nvec;
-    for (int grid : {256 * 8, 256 * 64}) {
+    for (int grid : {256 * 64}) {
         run<1, 1, false>(a, grid, "1R+1W (copy)");
         run<1, 0, false>(a, grid, "1R");
         run<2, 0, false>(a, grid, "2R");
@@ -61,6 +65,9 @@ int main(int argc, char** argv) {
         run<14, 2, false, 1>(a, grid, "14R+2W nt-load");
         run<14, 2, false, 3>(a, grid, "14R+2W nt-both");
         run<1, 1, false, 3>(a, grid, "1R+1W nt-both");
+        run<14, 2, false, 5>(a, grid, "14R nt + 2W sc1");
+        run<14, 2, false, 9>(a, grid, "14R nt + 2W sc0sc1");
+        run<14, 2, false, 13>(a, grid, "14R nt + 2W sc0sc1nt");
         run<7, 1, false>(a, grid, "7R+1W");
         run<0, 2, false>(a, grid, "2W");
         run<0, 4, false>(a, grid, "4W");
