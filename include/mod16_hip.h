@@ -154,6 +154,54 @@ MOD16_API int mod16_et_diag_f32(mod16_ctx* ctx, const uint8_t* cls,
                       unsigned flags, double* ddiag, void* stream);
 
 /*
+ * The sub-methods of the reference's class surface (mod16/__init__.py:384-673,
+ * :795-1258, :1261-1397), reference operation order. `method` selects one;
+ * `in` holds MOD16_METHOD_MAX_IN pointers in the order of the reference
+ * signature (table below), NULL = optional argument not given (then computed as
+ * the reference does); istride 0 = broadcast scalar, 1 = dense; `params` as in
+ * mod16_et_* (may be NULL for the static / module-level methods); `out` holds 2
+ * pointers (second NULL unless the method returns a pair); `alpha` is used by
+ * POT_TRANSPIRATION only. `where` as in mod16_et_*.
+ *
+ *   SVP                 temp_k                                     :1340
+ *   SVP_SLOPE           temp_k, s?                                 :1370
+ *   LHV                 temp_k                                     :121
+ *   PSYCHROMETRIC       pressure, temp_k                           :1261
+ *   RADIATION_NET       sw_rad, sw_albedo, temp_k                  :1293
+ *   AIR_DENSITY         temp_k, pressure, rhumidity                :384
+ *   AIR_PRESSURE        elevation_m                                :414
+ *   VPD                 qv10m, pressure, tmean                     :604
+ *   RHUMIDITY           temp_k, vpd                                :646
+ *   POT_SOIL_EVAP       pressure, temp_k, vpd, fpar, rad_soil, r_corr?, lhv?, rh?, f_wet? -> (sat, unsat)  :449
+ *   POT_TRANSPIRATION   lw_net, sw_rad, sw_albedo, pressure, temp_k, vpd, fpar, rh?, f_wet?       :546
+ *   EVAP_SOIL           pressure, temp_k, vpd, fpar, rad_soil, r_corr?, lhv?, rh?, f_wet?         :795
+ *   EVAP_WET_CANOPY     pressure, temp_k, vpd, lai, fpar, rad_canopy, lhv?, rh?, f_wet?           :866
+ *   RADIATION_SOIL      lw_d, lw_n, sw_d, sw_n, albedo, t_d, t_n, t_annual, fpar -> (day, night)  :963
+ *   SOIL_HEAT_FLUX      rad_net_day, rad_net_night, t_d, t_n, t_annual -> (day, night)            :1055
+ *   SURFACE_CONDUCTANCE tmin, vpd_day                              :1121
+ *   TRANSPIRATION_DAY / _NIGHT  pressure, temp_k, vpd, lai, fpar, rad_canopy, tmin, r_corr?, lhv?, rh?, f_wet?  :1152
+ */
+#define MOD16_METHOD_MAX_IN 13
+enum mod16_method {
+    MOD16_M_SVP = 0, MOD16_M_SVP_SLOPE, MOD16_M_LHV, MOD16_M_PSYCHROMETRIC,
+    MOD16_M_RADIATION_NET, MOD16_M_AIR_DENSITY, MOD16_M_AIR_PRESSURE, MOD16_M_VPD,
+    MOD16_M_RHUMIDITY, MOD16_M_POT_SOIL_EVAP, MOD16_M_POT_TRANSPIRATION,
+    MOD16_M_EVAP_SOIL, MOD16_M_EVAP_WET_CANOPY, MOD16_M_RADIATION_SOIL,
+    MOD16_M_SOIL_HEAT_FLUX, MOD16_M_SURFACE_CONDUCTANCE,
+    MOD16_M_TRANSPIRATION_DAY, MOD16_M_TRANSPIRATION_NIGHT, MOD16_M_COUNT
+};
+MOD16_API int mod16_method_f64(mod16_ctx* ctx, int method,
+                     const double* const* in, const int64_t* istride,
+                     const double* const* params, const int64_t* pstride,
+                     int64_t n, double* const* out, double alpha, int where,
+                     void* stream);
+MOD16_API int mod16_method_f32(mod16_ctx* ctx, int method,
+                     const float* const* in, const int64_t* istride,
+                     const float* const* params, const int64_t* pstride,
+                     int64_t n, float* const* out, float alpha, int where,
+                     void* stream);
+
+/*
  * Waits for the ctx's outstanding work on `stream` and reports deferred
  * errors of DEVICE-mode calls (MOD16_ERR_CLASS_RANGE, MOD16_ERR_HIP).
  */

@@ -11,6 +11,10 @@ kernel on gfx950 through ``libmod16hip.so`` (C ABI: ``include/mod16_hip.h``).
 There is no CPU fallback: without the library or without an MI355X the
 forward run raises.
 
+The sub-methods of the class (``evaporation_soil``, ``transpiration``,
+``radiation_soil`` ...) and the module functions (``svp``, ``svp_slope`` ...) run
+on the GPU too (``mod16_method_*``, reference operation order).
+
 Two ways in:
 
 - ``MOD16(params).evapotranspiration(*drivers)`` -- numpy in, numpy out, as
@@ -122,6 +126,47 @@ def _forward(cls, drivers, params, separate, flags, device):
     return (outs[0], outs[1])
 
 
+def _call_method(method, inputs, params=None, nout=1, alpha=1.26, device=0):
+    '''Runs one sub-method of the class surface on the GPU (``mod16_method_*``,
+    reference operation order). ``inputs`` follows the reference signature,
+    ``None`` = optional argument not given; ``params`` maps parameter name ->
+    value for the parameters the method uses.'''
+    ctx = _lib.context(device)
+    present = [v for v in inputs if v is not None]
+    params = dict((k, v) for k, v in (params or {}).items() if v is not None)
+    pvals = list(params.values())
+    dtype = _result_dtype(present + pvals)
+    shape = np.broadcast_shapes(*[np.shape(v) for v in present + pvals])
+    n = int(np.prod(shape, dtype=np.int64))
+    keep, ptrs, strides = _marshal(present, shape, dtype)
+    it = iter(zip(ptrs, strides))
+    iptr, istr = [], []
+    for v in list(inputs) + [None] * (_lib.METHOD_MAX_IN - len(inputs)):
+        ptr, st = next(it) if v is not None else (None, 0)
+        iptr.append(ptr)
+        istr.append(st)
+    pptr = pstr = None
+    if params:
+        keep_p, pp, ps = _marshal(pvals, shape, dtype)
+        by_name = dict(zip(params.keys(), zip(pp, ps)))
+        pptr = [by_name.get(k, (None, 0))[0] for k in MOD16.required_parameters]
+        pstr = [by_name.get(k, (None, 0))[1] for k in MOD16.required_parameters]
+    outs = [np.empty(shape, dtype) for _ in range(nout)]
+    if n:
+        ctx.method(dtype, method, iptr, istr, pptr, pstr, n,
+                   [o.ctypes.data for o in outs] + [None] * (2 - nout), alpha=alpha)
+    if not shape:
+        outs = [o[()] for o in outs]
+    return outs[0] if nout == 1 else tuple(outs)
+
+
+def _check_tiny(tiny):
+    if tiny != 1e-7:
+        raise NotImplementedError(
+            'the GPU kernels fix tiny = 1e-7 (the reference default, '
+            'mod16/__init__.py:869, :1157)')
+
+
 class MOD16(object):
     r'''
     The MODIS MxD16 Evapotranspiration model on MI355X. Same construction as
@@ -223,6 +268,147 @@ class MOD16(object):
         return _forward(
             None, drivers, self._param_values(), separate, self.math,
             self.device)
+
+
+    # ---- the rest of the reference's class surface, on the GPU as well
+    #      (mod16_method_*: reference operation order, IEEE divide / pow)
+    def _p(self, *names):
+        return dict((k, getattr(self, k)) for k in names)
+
+    @staticmethod
+    def _et(*args, **kwargs):
+        raise NotImplementedError(
+            'the vectorised calibration path MOD16._et / _evapotranspiration '
+            '(reference mod16/__init__.py:162-382, W m-2, different clamps) is '
+            'not part of the forward-run engine yet (DESIGN.md section 9)')
+
+    _evapotranspiration = _et
+
+    @staticmethod
+    def air_density(temp_k, pressure, rhumidity):
+        'Air density [kg m-3], reference mod16/__init__.py:384-412.'
+        return _call_method(_lib.M_AIR_DENSITY, [temp_k, pressure, rhumidity])
+
+    @staticmethod
+    def air_pressure(elevation_m):
+        'Air pressure [Pa] from elevation [m], reference :414-447.'
+        return _call_method(_lib.M_AIR_PRESSURE, [elevation_m])
+
+    @staticmethod
+    def potential_soil_evaporation(
+            pressure, temp_k, vpd, fpar, rad_soil, r_corr=None, lhv=None,
+            rhumidity=None, f_wet=None, vpd_open=None, vpd_close=None,
+            rbl_min=None, rbl_max=None):
+        '''(evaporation from the saturated fraction, potential evaporation
+        from the unsaturated fraction) [W m-2], reference :449-544.'''
+        return _call_method(
+            _lib.M_POT_SOIL_EVAP,
+            [pressure, temp_k, vpd, fpar, rad_soil, r_corr, lhv, rhumidity, f_wet],
+            dict(vpd_open=vpd_open, vpd_close=vpd_close, rbl_min=rbl_min,
+                 rbl_max=rbl_max), nout=2)
+
+    @staticmethod
+    def potential_transpiration(
+            lw_net, sw_rad, sw_albedo, pressure, temp_k, vpd, fpar,
+            rhumidity=None, f_wet=None, alpha=1.26):
+        'Priestley-Taylor potential transpiration [W m-2], reference :546-602.'
+        return _call_method(
+            _lib.M_POT_TRANSPIRATION,
+            [lw_net, sw_rad, sw_albedo, pressure, temp_k, vpd, fpar, rhumidity,
+             f_wet], alpha=alpha)
+
+    @staticmethod
+    def vpd(qv10m, pressure, tmean):
+        'Vapor pressure deficit [Pa] from specific humidity, reference :604-644.'
+        return _call_method(_lib.M_VPD, [qv10m, pressure, tmean])
+
+    @staticmethod
+    def rhumidity(temp_k, vpd):
+        'Relative humidity on [0, 1] from VPD, reference :646-673.'
+        return _call_method(_lib.M_RHUMIDITY, [temp_k, vpd])
+
+    def evaporation_soil(
+            self, pressure, temp_k, vpd, fpar, rad_soil, r_corr=None, lhv=None,
+            rhumidity=None, f_wet=None):
+        'Bare-soil evaporation [kg m-2 s-1], reference :795-864.'
+        return _call_method(
+            _lib.M_EVAP_SOIL,
+            [pressure, temp_k, vpd, fpar, rad_soil, r_corr, lhv, rhumidity, f_wet],
+            self._p('vpd_open', 'vpd_close', 'rbl_min', 'rbl_max', 'beta'),
+            device=self.device)
+
+    def evaporation_wet_canopy(
+            self, pressure, temp_k, vpd, lai, fpar, rad_canopy, lhv=None,
+            rhumidity=None, f_wet=None, tiny=1e-7):
+        'Wet-canopy evaporation [kg m-2 s-1], reference :866-961.'
+        _check_tiny(tiny)
+        return _call_method(
+            _lib.M_EVAP_WET_CANOPY,
+            [pressure, temp_k, vpd, lai, fpar, rad_canopy, lhv, rhumidity, f_wet],
+            self._p('gl_sh', 'gl_wv'), device=self.device)
+
+    def radiation_soil(
+            self, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night, sw_albedo,
+            temp_day, temp_night, temp_annual, fpar):
+        'Net radiation received by the soil (day, night) [W m-2], reference :963-1053.'
+        return _call_method(
+            _lib.M_RADIATION_SOIL,
+            [lw_net_day, lw_net_night, sw_rad_day, sw_rad_night, sw_albedo,
+             temp_day, temp_night, temp_annual, fpar],
+            self._p('tmin_close'), nout=2, device=self.device)
+
+    def soil_heat_flux(
+            self, rad_net_day, rad_net_night, temp_day, temp_night, temp_annual):
+        'Soil heat flux [day, night] [W m-2], reference :1055-1119.'
+        return list(_call_method(
+            _lib.M_SOIL_HEAT_FLUX,
+            [rad_net_day, rad_net_night, temp_day, temp_night, temp_annual],
+            self._p('tmin_close'), nout=2, device=self.device))
+
+    def surface_conductance(self, tmin, vpd_day):
+        'Surface conductance [m s-1], reference :1121-1150.'
+        return _call_method(
+            _lib.M_SURFACE_CONDUCTANCE, [tmin, vpd_day],
+            self._p('tmin_close', 'tmin_open', 'vpd_open', 'vpd_close', 'csl'),
+            device=self.device)
+
+    def transpiration(
+            self, pressure, temp_k, vpd, lai, fpar, rad_canopy, tmin,
+            r_corr=None, lhv=None, rhumidity=None, f_wet=None, daytime=True,
+            tiny=1e-7):
+        'Plant transpiration [kg m-2 s-1], reference :1152-1258.'
+        _check_tiny(tiny)
+        return _call_method(
+            _lib.M_TRANSPIRATION_DAY if daytime else _lib.M_TRANSPIRATION_NIGHT,
+            [pressure, temp_k, vpd, lai, fpar, rad_canopy, tmin, r_corr, lhv,
+             rhumidity, f_wet],
+            self._p('tmin_close', 'tmin_open', 'vpd_open', 'vpd_close', 'gl_sh',
+                    'g_cuticular', 'csl'), device=self.device)
+
+
+def latent_heat_vaporization(temp_k):
+    'Latent heat of vaporization [J kg-1], reference mod16/__init__.py:121.'
+    return _call_method(_lib.M_LHV, [temp_k])
+
+
+def psychrometric_constant(pressure, temp_k):
+    'Psychrometric constant [Pa K-1], reference :1261-1290.'
+    return _call_method(_lib.M_PSYCHROMETRIC, [pressure, temp_k])
+
+
+def radiation_net(sw_rad, sw_albedo, temp_k):
+    'DEPRECATED in the reference (:1293-1337); net radiation [W m-2].'
+    return _call_method(_lib.M_RADIATION_NET, [sw_rad, sw_albedo, temp_k])
+
+
+def svp(temp_k):
+    'Saturation vapor pressure [Pa], reference :1340-1367.'
+    return _call_method(_lib.M_SVP, [temp_k])
+
+
+def svp_slope(temp_k, s=None):
+    'Slope of the saturation vapor pressure curve [Pa K-1], reference :1370-1397.'
+    return _call_method(_lib.M_SVP_SLOPE, [temp_k, s])
 
 
 def evapotranspiration_raster(

@@ -16,6 +16,12 @@ N_COMPONENTS = 6
 HOST, DEVICE = 0, 1
 MATH_FAST, MATH_EXACT = 0, 1
 
+METHOD_MAX_IN = 13
+(M_SVP, M_SVP_SLOPE, M_LHV, M_PSYCHROMETRIC, M_RADIATION_NET, M_AIR_DENSITY,
+ M_AIR_PRESSURE, M_VPD, M_RHUMIDITY, M_POT_SOIL_EVAP, M_POT_TRANSPIRATION,
+ M_EVAP_SOIL, M_EVAP_WET_CANOPY, M_RADIATION_SOIL, M_SOIL_HEAT_FLUX,
+ M_SURFACE_CONDUCTANCE, M_TRANSPIRATION_DAY, M_TRANSPIRATION_NIGHT) = range(18)
+
 OK = 0
 ERR_ARG, ERR_HIP, ERR_CLASS_RANGE, ERR_NOMEM, ERR_NO_DEVICE, ERR_NO_BPLUT = \
     -1, -2, -3, -4, -5, -6
@@ -58,6 +64,12 @@ PROTOTYPES = {
     'mod16_et_diag_f32': (C.c_int, [
         C.c_void_p, C.c_void_p, _PP, _I64P, C.c_int64, C.c_void_p, C.c_void_p,
         C.c_uint, C.c_void_p, C.c_void_p]),
+    'mod16_method_f64': (C.c_int, [
+        C.c_void_p, C.c_int, _PP, _I64P, _PP, _I64P, C.c_int64, _PP, C.c_double,
+        C.c_int, C.c_void_p]),
+    'mod16_method_f32': (C.c_int, [
+        C.c_void_p, C.c_int, _PP, _I64P, _PP, _I64P, C.c_int64, _PP, C.c_float,
+        C.c_int, C.c_void_p]),
     'mod16_check_status': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mod16_reduce_diag_f64': (C.c_int, [
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
@@ -203,6 +215,17 @@ class Context:
             int(n), out_day, out_night,
             ptr_array(out_sep) if out_sep is not None else None,
             int(flags), int(where), stream))
+
+    def method(self, dtype, method, inputs, istride, params, pstride, n, outs,
+               alpha=1.26, where=HOST, stream=None):
+        '''Thin wrapper of mod16_method_f64 / _f32 (raw addresses or None).'''
+        fn = self.lib.mod16_method_f32 if np.dtype(dtype) == np.float32 \
+            else self.lib.mod16_method_f64
+        self.check(fn(
+            self.handle, int(method), ptr_array(inputs), i64_array(istride),
+            ptr_array(params) if params is not None else None,
+            i64_array(pstride) if pstride is not None else None,
+            int(n), ptr_array(outs), float(alpha), int(where), stream))
 
     def check_status(self, stream=None):
         self.check(self.lib.mod16_check_status(self.handle, stream))

@@ -1,0 +1,137 @@
+// The sub-methods of the reference's MOD16 class surface as one generic gfx950
+// kernel (reference operation order, IEEE divide / ocml exp, pow): the public
+// methods mod16/__init__.py:384-673, :795-1258 and module functions :1261-1397
+// that user code and the reference's own tests call directly. These are not
+// the hot path (the fused kernels are); they exist so that the whole class
+// surface computes on the GPU and shares its device functions with the EXACT
+// fused kernel.
+#pragma once
+#include "mod16_kernels.hpp"
+
+namespace mod16 {
+
+constexpr int kMethodMaxIn = 13;
+
+template <typename T> struct MethodArgs {
+    const T* in[kMethodMaxIn];
+    const T* par[11];
+    T* out[2];
+    int64_t n;
+    uint32_t dense_in, present_in, dense_par;
+    int method;
+    T alpha;
+};
+
+// Input slots per method (order of the reference signatures; "?" = optional,
+// absent -> computed as the reference does):
+//  0 SVP                 temp_k
+//  1 SVP_SLOPE           temp_k, s?
+//  2 LHV                 temp_k
+//  3 PSYCHROMETRIC       pressure, temp_k
+//  4 RADIATION_NET       sw_rad, sw_albedo, temp_k
+//  5 AIR_DENSITY         temp_k, pressure, rhumidity
+//  6 AIR_PRESSURE        elevation_m
+//  7 VPD                 qv10m, pressure, tmean
+//  8 RHUMIDITY           temp_k, vpd
+//  9 POT_SOIL_EVAP       pressure, temp_k, vpd, fpar, rad_soil, r_corr?, lhv?, rh?, f_wet?   -> sat, unsat
+// 10 POT_TRANSPIRATION   lw_net, sw_rad, sw_albedo, pressure, temp_k, vpd, fpar, rh?, f_wet?   (alpha)
+// 11 EVAP_SOIL           pressure, temp_k, vpd, fpar, rad_soil, r_corr?, lhv?, rh?, f_wet?
+// 12 EVAP_WET_CANOPY     pressure, temp_k, vpd, lai, fpar, rad_canopy, lhv?, rh?, f_wet?
+// 13 RADIATION_SOIL      lw_d, lw_n, sw_d, sw_n, albedo, t_d, t_n, t_annual, fpar           -> day, night
+// 14 SOIL_HEAT_FLUX      rad_net_day, rad_net_night, t_d, t_n, t_annual                      -> day, night
+// 15 SURFACE_CONDUCTANCE tmin, vpd_day
+// 16 TRANSPIRATION_DAY   pressure, temp_k, vpd, lai, fpar, rad_canopy, tmin, r_corr?, lhv?, rh?, f_wet?
+// 17 TRANSPIRATION_NIGHT same
+template <typename T>
+__global__ void __launch_bounds__(kBlock) method_kernel(const MethodArgs<T> a) {
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += step) {
+        auto has = [&](int k) { return (a.present_in >> k) & 1u; };
+        auto in = [&](int k) { return ((a.dense_in >> k) & 1u) ? a.in[k][i] : a.in[k][0]; };
+        auto par = [&](int k) { return ((a.dense_par >> k) & 1u) ? a.par[k][i] : a.par[k][0]; };
+        ClassPar<T> p;
+        p.tmin_close = par(0); p.tmin_open = par(1); p.vpd_open = par(2); p.vpd_close = par(3);
+        p.gl_sh = par(4); p.gl_wv = par(5); p.g_cut = par(6); p.csl = par(7);
+        p.rbl_min = par(8); p.rbl_max = par(9); p.beta = par(10);
+        T o0 = T(0), o1 = T(0);
+        // shared defaults of the optional arguments (:502-509, :926-931, :1216-1223)
+        auto rh_or = [&](int k, T t, T vpd) { return has(k) ? in(k) : rh_exact(t, vpd); };
+        auto fwet_or = [&](int k, T rh) { return has(k) ? in(k) : fwet_exact(rh); };
+        auto lhv_or = [&](int k, T t) { return has(k) ? in(k) : lhv_exact(t); };
+        auto rcorr_or = [&](int k, T pa, T t) { return has(k) ? in(k) : rcorr_exact(pa, t); };
+        switch (a.method) {
+            case 0: o0 = svp_exact(in(0)); break;
+            case 1: {
+#pragma clang fp contract(off)
+                T t = in(0);
+                T s = has(1) ? in(1) : svp_exact(t);
+                T d = (T(239.0) + t) - K<T>::t0;
+                o0 = (T(17.38 * 239.0) * s) / (d * d);
+                break;
+            }
+            case 2: o0 = lhv_exact(in(0)); break;
+            case 3: o0 = gamma_exact(in(0), in(1)); break;
+            case 4: o0 = radiation_net_exact(in(0), in(1), in(2)); break;
+            case 5: o0 = rho_exact(in(0), in(1), in(2)); break;
+            case 6: o0 = air_pressure_exact(in(0)); break;
+            case 7: o0 = vpd_exact(in(0), in(1), in(2)); break;
+            case 8: o0 = rh_exact(in(0), in(1)); break;
+            case 9: {
+                T pa = in(0), t = in(1), vpd = in(2);
+                T rh = rh_or(7, t, vpd);
+                pot_soil_exact(p, pa, t, vpd, in(3), in(4), rcorr_or(5, pa, t), rh, fwet_or(8, rh),
+                               o0, o1);
+                break;
+            }
+            case 10: {
+                T t = in(4), vpd = in(5);
+                T rh = rh_or(7, t, vpd);
+                o0 = pot_transpiration_exact(in(0), in(1), in(2), in(3), t, in(6), fwet_or(8, rh),
+                                             a.alpha);
+                break;
+            }
+            case 11: {
+                T pa = in(0), t = in(1), vpd = in(2);
+                T rh = rh_or(7, t, vpd);
+                o0 = soil_exact(p, pa, t, vpd, in(3), in(4), rcorr_or(5, pa, t), lhv_or(6, t), rh,
+                                fwet_or(8, rh));
+                break;
+            }
+            case 12: {
+                T pa = in(0), t = in(1), vpd = in(2);
+                T rh = rh_or(7, t, vpd);
+                o0 = wet_canopy_exact(p, pa, t, vpd, in(3), in(4), in(5), lhv_or(6, t), rh,
+                                      fwet_or(8, rh));
+                break;
+            }
+            case 13: {
+                PixelIn<T> x = {in(0), in(1), in(2), in(3), in(4), in(5), in(6), in(7), T(0), T(0),
+                                T(0), T(0), in(8), T(0)};
+                rad_soil_exact(x, p, o0, o1);
+                break;
+            }
+            case 14: soil_heat_flux_exact(p, in(0), in(1), in(2), in(3), in(4), o0, o1); break;
+            case 15: {
+#pragma clang fp contract(off)
+                o0 = p.csl * ramp_up_exact(in(0) - K<T>::t0, p.tmin_close, p.tmin_open) *
+                     ramp_down_exact(in(1), p.vpd_open, p.vpd_close);
+                break;
+            }
+            case 16:
+            case 17: {
+                T pa = in(0), t = in(1), vpd = in(2);
+                T rh = rh_or(9, t, vpd);
+                T rc = rcorr_or(7, pa, t), lhv = lhv_or(8, t), fw = fwet_or(10, rh);
+                o0 = (a.method == 16)
+                         ? transpiration_exact<T, true>(p, pa, t, vpd, in(3), in(4), in(5), in(6), rc, lhv, rh, fw)
+                         : transpiration_exact<T, false>(p, pa, t, vpd, in(3), in(4), in(5), in(6), rc, lhv, rh, fw);
+                break;
+            }
+            default: break;
+        }
+        if (a.out[0]) a.out[0][i] = o0;
+        if (a.out[1]) a.out[1][i] = o1;
+    }
+}
+
+}  // namespace mod16

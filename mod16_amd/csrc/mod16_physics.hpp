@@ -139,10 +139,11 @@ __device__ __forceinline__ T wet_canopy_exact(const ClassPar<T>& p, T pa, T t, T
     return ((fwet <= tiny) || (lai <= tiny)) ? T(0) : evap;       // :961
 }
 
-// potential_soil_evaporation + evaporation_soil, :449-544, :795-864
+// potential_soil_evaporation, :449-544
 template <typename T>
-__device__ __forceinline__ T soil_exact(const ClassPar<T>& p, T pa, T t, T vpd, T fpar,
-                                        T rad_soil, T r_corr, T lhv, T rh, T fwet) {
+__device__ __forceinline__ void pot_soil_exact(const ClassPar<T>& p, T pa, T t, T vpd, T fpar,
+                                               T rad_soil, T r_corr, T rh, T fwet, T& sat,
+                                               T& unsat) {
 #pragma clang fp contract(off)
     T s = svp_slope_exact(t);
     T rho = rho_exact(t, pa, rh);
@@ -156,11 +157,68 @@ __device__ __forceinline__ T soil_exact(const ClassPar<T>& p, T pa, T t, T vpd, 
     T r_as = (r_tot * r_r) / (r_tot + r_r);                       // :535
     T numer = (s * rad_soil) + (rho * K<T>::cp * (T(1) - fpar) * (vpd / r_as));
     T denom = s + gamma * (r_tot / r_as);
-    T sat = (numer * fwet) / denom;                               // :541-543
-    T unsat = (numer * (T(1) - fwet)) / denom;
+    sat = (numer * fwet) / denom;                                 // :541-543
+    unsat = (numer * (T(1) - fwet)) / denom;
+}
+
+// evaporation_soil, :795-864
+template <typename T>
+__device__ __forceinline__ T soil_exact(const ClassPar<T>& p, T pa, T t, T vpd, T fpar,
+                                        T rad_soil, T r_corr, T lhv, T rh, T fwet) {
+#pragma clang fp contract(off)
+    T sat, unsat;
+    pot_soil_exact(p, pa, t, vpd, fpar, rad_soil, r_corr, rh, fwet, sat, unsat);
     T e = (sat < T(0)) ? T(0) : sat;                              // :858-861
     e = e + ((unsat < T(0)) ? T(0) : unsat * ExactMath<T>::pow(rh, vpd / p.beta));
     return e / lhv;                                               // :864
+}
+
+// soil_heat_flux, :1055-1119
+template <typename T>
+__device__ __forceinline__ void soil_heat_flux_exact(const ClassPar<T>& p, T a_d, T a_n, T t_d,
+                                                     T t_n, T t_ann, T& g_d, T& g_n) {
+#pragma clang fp contract(off)
+    bool cond = (t_ann < T(273.15 + 25.0)) && (t_ann >= (K<T>::t0 + p.tmin_close)) &&
+                ((t_d - t_n) >= T(5));
+    g_d = cond ? (T(4.73) * (t_d - K<T>::t0)) - T(20.87) : T(0);
+    g_d = (__builtin_fabs(g_d) > (T(0.39) * __builtin_fabs(a_d))) ? T(0.39) * a_d : g_d;
+    g_n = cond ? (T(4.73) * (t_n - K<T>::t0)) - T(20.87) : T(0);
+    g_n = (__builtin_fabs(g_n) > (T(0.39) * __builtin_fabs(a_n))) ? T(0.39) * a_n : g_n;
+}
+
+// MOD16.potential_transpiration, :546-602
+template <typename T>
+__device__ __forceinline__ T pot_transpiration_exact(T lw, T sw, T alb, T pa, T t, T fpar,
+                                                     T fwet, T alpha) {
+#pragma clang fp contract(off)
+    T rad_c = fpar * (sw * (T(1) - alb) + lw);
+    T s = svp_slope_exact(t);
+    T gamma = gamma_exact(pa, t);
+    return (alpha * (s * rad_c) * (T(1) - fwet)) / (s + gamma);
+}
+
+// MOD16.vpd, :604-644 (note: its own SVP constants)
+template <typename T> __device__ __forceinline__ T vpd_exact(T qv, T pa, T tmean) {
+#pragma clang fp contract(off)
+    T tc = tmean - K<T>::t0;
+    T avp = (qv * pa) / (T(0.622) + (T(0.379) * qv));
+    T sv = T(610.7) * ExactMath<T>::exp((T(17.38) * tc) / (T(239) + tc));
+    return sv - avp;
+}
+
+// MOD16.air_pressure, :414-447
+template <typename T> __device__ __forceinline__ T air_pressure_exact(T elev) {
+#pragma clang fp contract(off)
+    T ratio = T(1) - ((T(0.0065) * elev) / T(288.15));
+    return T(101325.0) * ExactMath<T>::pow(ratio, T(9.80665 / (0.0065 * (8.3143 / 28.9644e-3))));
+}
+
+// radiation_net (deprecated), :1293-1337
+template <typename T> __device__ __forceinline__ T radiation_net_exact(T sw, T alb, T t) {
+#pragma clang fp contract(off)
+    T tc = t - K<T>::t0;
+    T emis_a = T(1) - T(0.26) * ExactMath<T>::exp(T(-7.77e-4) * (tc * tc));
+    return sw * (T(1) - alb) + T(5.67e-8) * (emis_a - T(0.97)) * ExactMath<T>::pow(t, T(4));
 }
 
 // mod17.linear_constraint (reference README.md:351-369)

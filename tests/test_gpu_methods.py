@@ -1,0 +1,230 @@
+"""The reference's own unit tests (tests/tests.py:64-232), restated against
+mod16_amd on the GPU -- same inputs, same rounding, same expected numbers --
+followed by full-precision parity of every sub-method with golden vectors made
+by the reference (tests/golden/f6_submethods.npz, f1_tests_scalars.npz)."""
+import numpy as np
+import pytest
+
+from oracle import mod16_oracle as oracle
+from parity import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def m16():
+    import mod16_amd
+    return mod16_amd
+
+
+class Setup:
+    """tests/tests.py:19-62 (setUp)"""
+    params = dict(gl_sh=0.01, gl_wv=0.01, g_cuticular=1e-5, tmin_close=-8, tmin_open=8,
+                  vpd_open=650, vpd_close=3000, rbl_min=60, rbl_max=90, csl=2.4e-3, beta=250)
+    pressure = 100e3
+    temp_k = 273.15 + 30
+    tmin = 285
+    vpd = 1000
+    lai = 1.5
+    fpar = 0.5
+    rad_canopy = 5000
+    rad_soil = 5000
+    r_corr = (101300 / pressure) * (temp_k / 293.15)**1.75
+    _pressure = np.arange(98e3, 103e3, 1e3)
+    _temp_k = 273.15 + np.array([0, 10, 20, 30, 40])
+    _vpd = np.arange(0, 5000, 1000)
+    _lai = np.arange(0.5, 3, 0.5)
+    _fpar = np.array([0.1, 0.3, 0.5, 0.7, 0.9])
+    _rad_canopy = np.arange(3e3, 8e3, 1e3)
+
+
+S = Setup
+
+
+def test_et_instance_interface(m16):                      # tests.py:64-90
+    model = m16.MOD16(S.params)
+    day, night = model.evapotranspiration(
+        -50, -30, 150, 0, 0.3, 293, 290, 285, 285, 1000, 500, S.pressure, S.fpar, S.lai)
+    lhv_day = m16.latent_heat_vaporization(293)
+    lhv_night = m16.latent_heat_vaporization(290)
+    assert round(float((day * lhv_day) + (night * lhv_night)), 1) == 41.0
+
+
+def test_evaporation_soil(m16):                           # tests.py:92-98
+    model = m16.MOD16(S.params)
+    evap = 60 * 60 * model.evaporation_soil(
+        S.pressure, S.temp_k, S.vpd, S.fpar, S.rad_soil, S.r_corr)
+    assert evap.round(3) == 3.102
+
+
+def test_evaporation_soil_by_fpar(m16):                   # tests.py:100-111
+    model = m16.MOD16(S.params)
+    evap = 60 * 60 * model.evaporation_soil(
+        S.pressure, S.temp_k, S.vpd, S._fpar, S.rad_soil, S.r_corr)
+    assert np.equal(evap.round(3), np.array([3.128, 3.115, 3.102, 3.089, 3.076])).all()
+
+
+def test_transpiration_daytime(m16):                      # tests.py:113-121
+    model = m16.MOD16(S.params)
+    trans = 60 * 60 * model.transpiration(
+        S.pressure, S.temp_k, S.vpd, S.lai, S.fpar, S.rad_canopy, S.tmin, S.r_corr,
+        daytime=True)
+    assert trans.round(3) == 1.248
+
+
+def test_transpiration_nighttime(m16):                    # tests.py:123-132
+    model = m16.MOD16(S.params)
+    trans = 60 * 60 * model.transpiration(
+        S.pressure, S.temp_k, S.vpd, S.lai, S.fpar, S.rad_canopy, S.tmin, S.r_corr,
+        daytime=False)
+    assert trans.round(3) == 0.011
+
+
+def test_wet_canopy_evaporation(m16):                     # tests.py:134-141
+    model = m16.MOD16(S.params)
+    evap = model.evaporation_wet_canopy(
+        S.pressure, S.temp_k, S.vpd, S.lai, S.fpar, S.rad_canopy).round(6)
+    assert evap == 4.49e-4
+
+
+@pytest.mark.parametrize('arg,values,expected', [        # tests.py:143-201
+    ('pressure', S._pressure, [1.623, 1.62, 1.618, 1.615, 1.612]),
+    ('temp_k', S._temp_k, [0., 0., 0., 1.618, 3.222]),
+    ('vpd', S._vpd, [5.382, 1.618, 0, 0, 0]),
+    ('lai', S._lai, [1.174, 1.478, 1.618, 1.699, 1.752]),
+    ('fpar', S._fpar, [1.611, 1.615, 1.618, 1.621, 1.624]),
+    ('rad_canopy', S._rad_canopy, [0.974, 1.296, 1.618, 1.94, 2.262]),
+])
+def test_wet_canopy_evaporation_sweeps(m16, arg, values, expected):
+    model = m16.MOD16(S.params)
+    kw = dict(pressure=S.pressure, temp_k=S.temp_k, vpd=S.vpd, lai=S.lai, fpar=S.fpar,
+              rad_canopy=S.rad_canopy)
+    kw[arg] = values
+    evap = 60 * 60 * model.evaporation_wet_canopy(**kw)
+    assert np.equal(evap.round(3), np.array(expected)).all()
+
+
+def test_psychrometric_constant(m16):                     # tests.py:203-215
+    pressure = np.array((100e3, 80e3, 100e3, 80e3))
+    temp_k = 273.15 + np.array((10, 10, 25, 25))
+    answer = [65.74, 52.59, 66.69, 53.35]
+    for i in range(0, 4):
+        assert answer[i] == m16.psychrometric_constant(pressure[i], temp_k[i]).round(2)
+    assert 54.55 == np.round(m16.psychrometric_constant(81.8e3, 25 + 273.15), 2)
+
+
+def test_radiation_net(m16):                              # tests.py:217-226
+    swrad = np.array((500, 5000, 500, 5000, 500, 5000, 500, 5000))
+    albedo = np.array((0.4, 0.4, 0.8, 0.8, 0.4, 0.4, 0.8, 0.8))
+    temp_k = 273.15 + np.array((10, 10, 10, 10, 25, 25, 25, 25))
+    answer = [223.3, 2923.3, 23.3, 923.3, 241.8, 2941.8, 41.8, 941.8]
+    for i in range(0, 8):
+        assert answer[i] == m16.radiation_net(swrad[i], albedo[i], temp_k[i]).round(1)
+
+
+def test_svp_slope(m16):                                  # tests.py:228-232
+    assert 82.3 == m16.svp_slope(273.15 + 10).round(1)
+    assert 144.8 == m16.svp_slope(273.15 + 20).round(1)
+    assert 188.8 == m16.svp_slope(273.15 + 25).round(1)
+
+
+def test_notebook_cell_12(m16):
+    """MOD16Collection61(12).evaporation_soil(101e3, 293.15, 1000, 0.5, 100)
+    = 5.083295223395212e-06 in the reference's forward-run notebook."""
+    from mod16_amd.models import MOD16Collection61
+    got = MOD16Collection61(12).evaporation_soil(101e3, 293.15, 1000, 0.5, 100)
+    assert abs(float(got) / 5.083295223395212e-06 - 1) < 1e-13
+
+
+# ---------------------------------------------------------- full precision
+RTOL = 2e-13   # exp / pow differ from glibc by an ulp; everything else is IEEE-exact
+
+
+def test_submethods_against_reference_vectors(m16, golden):
+    f = golden('f6_submethods')
+    m = m16.MOD16(dict(zip(oracle.PARAM_NAMES, f['params'])))
+    (lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_a, tmin, vpd_d, vpd_n, pa, fpar, lai) = \
+        list(f['drivers'])
+    chk = lambda got, name: assert_parity(np.asarray(got), f[name], RTOL, name)
+    chk(m16.svp(t_d), 'svp')
+    chk(m16.svp_slope(t_d), 'svp_slope')
+    chk(m16.svp_slope(t_d, f['svp']), 'svp_slope')
+    chk(m16.latent_heat_vaporization(t_d), 'lhv')
+    chk(m16.psychrometric_constant(pa, t_d), 'psychrometric_constant')
+    chk(m16.MOD16.rhumidity(t_d, vpd_d), 'rhumidity')
+    chk(m16.MOD16.air_density(t_d, pa, f['rhumidity']), 'air_density')
+    g = m.soil_heat_flux(sw_d * (1 - alb) + lw_d, lw_n, t_d, t_n, t_a)
+    assert isinstance(g, list)
+    chk(g[0], 'soil_heat_flux_day')
+    chk(g[1], 'soil_heat_flux_night')
+    rs = m.radiation_soil(lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_a, fpar)
+    assert isinstance(rs, tuple)
+    chk(rs[0], 'radiation_soil_day')
+    chk(rs[1], 'radiation_soil_night')
+    chk(m.surface_conductance(tmin, vpd_d), 'surface_conductance')
+    rad_c = f['rad_canopy']
+    chk(m.evaporation_wet_canopy(pa, t_d, vpd_d, lai, fpar, rad_c), 'evaporation_wet_canopy')
+    chk(m.evaporation_soil(pa, t_d, vpd_d, fpar, f['radiation_soil_day']), 'evaporation_soil')
+    sat, unsat = m16.MOD16.potential_soil_evaporation(
+        pa, t_d, vpd_d, fpar, f['radiation_soil_day'], vpd_open=m.vpd_open,
+        vpd_close=m.vpd_close, rbl_min=m.rbl_min, rbl_max=m.rbl_max)
+    chk(sat, 'potential_soil_sat')
+    chk(unsat, 'potential_soil_unsat')
+    chk(m.transpiration(pa, t_d, vpd_d, lai, fpar, rad_c, tmin), 'transpiration_day')
+    chk(m.transpiration(pa, t_n, vpd_n, lai, fpar, fpar * lw_n, tmin, daytime=False),
+        'transpiration_night')
+    # optional arguments given explicitly change nothing
+    lhv = f['lhv']
+    rh = f['rhumidity']
+    fw = np.where(rh < 0.7, 0, rh**4)
+    chk(m.evaporation_soil(pa, t_d, vpd_d, fpar, f['radiation_soil_day'], None, lhv, rh, fw),
+        'evaporation_soil')
+    chk(m.transpiration(pa, t_d, vpd_d, lai, fpar, rad_c, tmin, None, lhv, rh, fw),
+        'transpiration_day')
+
+
+def test_component_known_answers(m16, golden):
+    f = golden('f1_tests_scalars')
+    m = m16.MOD16(dict(zip(oracle.PARAM_NAMES, f['params'])))
+    got = m.evaporation_soil(S.pressure, S.temp_k, S.vpd, S.fpar, S.rad_soil, S.r_corr)
+    assert np.ndim(got) == 0
+    assert_parity(np.asarray(got), f['kat_evaporation_soil'], RTOL, 'soil')
+    assert_parity(np.asarray(m.transpiration(
+        S.pressure, S.temp_k, S.vpd, S.lai, S.fpar, S.rad_canopy, S.tmin, S.r_corr)),
+        f['kat_transpiration_day'], RTOL, 'trans day')
+    assert_parity(np.asarray(m.transpiration(
+        S.pressure, S.temp_k, S.vpd, S.lai, S.fpar, S.rad_canopy, S.tmin, S.r_corr,
+        daytime=False)), f['kat_transpiration_night'], RTOL, 'trans night')
+    assert_parity(np.asarray(m.evaporation_wet_canopy(
+        S.pressure, S.temp_k, S.vpd, S.lai, S.fpar, S.rad_canopy)),
+        f['kat_wet_canopy'], RTOL, 'canopy')
+
+
+def test_static_helpers(m16):
+    """air_pressure, vpd, potential_transpiration: closed forms of the
+    reference (mod16/__init__.py:414-447, :604-644, :546-602)."""
+    elev = np.array([0.0, 500.0, 1500.0, 4000.0])
+    want = 101325.0 * np.power(1 - (0.0065 * elev) / 288.15, m16.AIR_PRESSURE_RATE)
+    assert_parity(m16.MOD16.air_pressure(elev), want, RTOL, 'air_pressure')
+    qv, pa, tm = np.array([0.004, 0.012]), np.array([95e3, 101e3]), np.array([283.15, 300.0])
+    want = 610.7 * np.exp((17.38 * (tm - 273.15)) / (239 + (tm - 273.15))) - \
+        (qv * pa) / (0.622 + (0.379 * qv))
+    assert_parity(m16.MOD16.vpd(qv, pa, tm), want, RTOL, 'vpd')
+    lw, sw, alb, fpar, vpd = -60.0, 300.0, 0.15, 0.6, np.array([400.0, 1500.0])
+    t = np.array([290.0, 300.0])
+    rh = oracle.rhumidity(t, vpd)
+    fw = oracle.wet_fraction(rh)
+    s = oracle.svp_slope(t)
+    want = (1.26 * (s * (fpar * (sw * (1 - alb) + lw))) * (1 - fw)) / \
+        (s + oracle.psychrometric_constant(pa, t))
+    assert_parity(m16.MOD16.potential_transpiration(lw, sw, alb, pa, t, vpd, fpar), want,
+                  RTOL, 'pet')
+
+
+def test_unsupported_corners(m16):
+    m = m16.MOD16(S.params)
+    with pytest.raises(NotImplementedError):
+        m.transpiration(S.pressure, S.temp_k, S.vpd, S.lai, S.fpar, S.rad_canopy, S.tmin,
+                        tiny=1e-6)
+    with pytest.raises(NotImplementedError):
+        m16.MOD16._et([1] * 11, *([1.0] * 14))
