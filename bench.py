@@ -189,8 +189,12 @@ def main():
         m = min(n, TILE[0] * TILE[1])
         h_cls = cls[:m].cpu().numpy()
         h_drv = [d[:m].cpu().numpy() for d in drv]
-        bplut = {k: table[:, j].astype(h_drv[0].dtype) for j, k in enumerate(oracle.PARAM_NAMES)}
-        want = oracle.evapotranspiration_raster(bplut, h_cls, *h_drv)
+        # float32 data: the kernel widens, computes in float64 and rounds once,
+        # so the checker is the float64 oracle on the widened inputs
+        bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+        want = oracle.evapotranspiration_raster(
+            bplut, h_cls, *[d.astype(np.float64) for d in h_drv])
+        want = [w.astype(h_drv[0].dtype) for w in want]
         worst, masks = 0.0, True
         for got, ref in ((day[:m].cpu().numpy(), want[0]), (night[:m].cpu().numpy(), want[1])):
             masks = masks and bool(np.array_equal(np.isnan(got), np.isnan(ref))

@@ -200,9 +200,7 @@ extern "C" int mod16_set_bplut_f64(mod16_ctx* ctx, const double* lut) {
 template <typename T> static const T* ctx_lut(const mod16_ctx* ctx);
 template <> const double* ctx_lut<double>(const mod16_ctx* ctx) { return ctx->lut64; }
 template <> const float* ctx_lut<float>(const mod16_ctx* ctx) { return ctx->lut32; }
-template <typename T> static const T* ctx_tab(const mod16_ctx* ctx);
-template <> const double* ctx_tab<double>(const mod16_ctx* ctx) { return ctx->tab64; }
-template <> const float* ctx_tab<float>(const mod16_ctx*) { return nullptr; }
+
 
 template <typename T> struct VecOf;
 template <> struct VecOf<double> { static constexpr int v = 2; };
@@ -262,7 +260,8 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
     const bool fast = (flags & MOD16_MATH_EXACT) == 0;
     if (a.n <= 0) return MOD16_OK;
     a.lut = ctx_lut<T>(ctx);
-    a.tab = ctx_tab<T>(ctx);
+    a.lut64 = ctx->lut64;
+    a.tab = ctx->tab64;
     a.status = ctx->status;
     // 16-byte vector path needs every dense pointer 16-byte aligned
     bool aligned = true;

@@ -10,6 +10,7 @@
 // different banks and lanes of one class broadcast.
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 #include "mod16_physics.hpp"
 
 namespace mod16 {
@@ -22,8 +23,9 @@ template <typename T> struct EtArgs {
     const T* drv[14];
     const T* par[11];
     const uint8_t* cls;
-    const T* lut;          // device [MOD16_LUT_ROWS][kLutCols]
-    const T* tab;          // device exp/log tables, FastMath<T>::kTabDoubles values
+    const T* lut;          // device [MOD16_LUT_ROWS][kLutCols], EXACT arithmetic (type T)
+    const double* lut64;   // the same table in float64, FAST arithmetic
+    const double* tab;     // device exp/log tables, FastMath<double>::kTabDoubles values
     T* out[8];             // day, night, then the 6 components (mod16_component)
     int64_t n;
     unsigned* status;
@@ -79,11 +81,18 @@ __device__ __forceinline__ void store_vec(T* __restrict__ p, int64_t i, const T 
 #endif
 template <typename T, int V, bool LUT, bool FAST, bool SEP, bool DENSE>
 __global__ void __launch_bounds__(kBlock, MOD16_ET_WAVES) et_kernel(const EtArgs<T> a) {
-    constexpr int kTab = FastMath<T>::kTabDoubles;
-    __shared__ T lut[MOD16_LUT_ROWS * kLutCols];
-    __shared__ __attribute__((aligned(16))) T tab[kTab > 0 ? kTab : 1];
+    // FAST always computes in float64 (float32 data are widened on load and
+    // the result rounded once on store); EXACT computes in the data type, as
+    // numpy does for the reference code.
+    typedef typename std::conditional<FAST, double, T>::type C;
+    constexpr int kTab = FAST ? FastMath<double>::kTabDoubles : 1;
+    __shared__ C lut[MOD16_LUT_ROWS * kLutCols];
+    __shared__ __attribute__((aligned(16))) double tab[kTab];
     if (LUT)
-        for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) lut[i] = a.lut[i];
+        for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) {
+            if constexpr (FAST) lut[i] = a.lut64[i];
+            else lut[i] = a.lut[i];
+        }
     if (FAST)
         for (int i = threadIdx.x; i < kTab; i += kBlock) tab[i] = a.tab[i];
     __syncthreads();
@@ -109,17 +118,17 @@ __global__ void __launch_bounds__(kBlock, MOD16_ET_WAVES) et_kernel(const EtArgs
         T res[8][V];
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            PixelIn<T> x = {in[0][j], in[1][j], in[2][j], in[3][j], in[4][j], in[5][j], in[6][j],
-                            in[7][j], in[8][j], in[9][j], in[10][j], in[11][j], in[12][j],
-                            in[13][j]};
-            ClassPar<T> p;
+            PixelIn<C> x = {(C)in[0][j], (C)in[1][j], (C)in[2][j], (C)in[3][j], (C)in[4][j],
+                            (C)in[5][j], (C)in[6][j], (C)in[7][j], (C)in[8][j], (C)in[9][j],
+                            (C)in[10][j], (C)in[11][j], (C)in[12][j], (C)in[13][j]};
+            ClassPar<C> p;
             if (LUT) {
                 unsigned c = (cbits >> (8 * j)) & 0xffu;
                 if (c >= 13u) {   // numpy would raise IndexError: flag it, give NaN
                     atomicOr(a.status, kStatusClassRange);
                     c = 13u;
                 }
-                const T* l = lut + c;
+                const C* l = lut + c;
                 p.tmin_close = l[0 * kLutCols];
                 p.tmin_open = l[1 * kLutCols];
                 p.vpd_open = l[2 * kLutCols];
@@ -138,30 +147,32 @@ __global__ void __launch_bounds__(kBlock, MOD16_ET_WAVES) et_kernel(const EtArgs
                     p.inv_beta = l[14 * kLutCols];
                 }
             } else {
-                p.tmin_close = pin[0][j];
-                p.tmin_open = pin[1][j];
-                p.vpd_open = pin[2][j];
-                p.vpd_close = pin[3][j];
-                p.gl_sh = pin[4][j];
-                p.gl_wv = pin[5][j];
-                p.g_cut = pin[6][j];
-                p.csl = pin[7][j];
-                p.rbl_min = pin[8][j];
-                p.rbl_max = pin[9][j];
-                p.beta = pin[10][j];
+                p.tmin_close = (C)pin[0][j];
+                p.tmin_open = (C)pin[1][j];
+                p.vpd_open = (C)pin[2][j];
+                p.vpd_close = (C)pin[3][j];
+                p.gl_sh = (C)pin[4][j];
+                p.gl_wv = (C)pin[5][j];
+                p.g_cut = (C)pin[6][j];
+                p.csl = (C)pin[7][j];
+                p.rbl_min = (C)pin[8][j];
+                p.rbl_max = (C)pin[9][j];
+                p.beta = (C)pin[10][j];
                 if (FAST) p.derive();
             }
-            PixelOut<T> o = FAST ? et_pixel_fast<T>(x, p, tab) : et_pixel_exact<T>(x, p);
+            PixelOut<C> o;
+            if constexpr (FAST) o = et_pixel_fast<double>(x, p, tab);
+            else o = et_pixel_exact<T>(x, p);
             // mod16/__init__.py:792: (canopy + soil) + transpiration
-            res[0][j] = (o.canopy_d + o.soil_d) + o.trans_d;
-            res[1][j] = (o.canopy_n + o.soil_n) + o.trans_n;
+            res[0][j] = (T)((o.canopy_d + o.soil_d) + o.trans_d);
+            res[1][j] = (T)((o.canopy_n + o.soil_n) + o.trans_n);
             if (SEP) {
-                res[2][j] = o.canopy_d;
-                res[3][j] = o.soil_d;
-                res[4][j] = o.trans_d;
-                res[5][j] = o.canopy_n;
-                res[6][j] = o.soil_n;
-                res[7][j] = o.trans_n;
+                res[2][j] = (T)o.canopy_d;
+                res[3][j] = (T)o.soil_d;
+                res[4][j] = (T)o.trans_d;
+                res[5][j] = (T)o.canopy_n;
+                res[6][j] = (T)o.soil_n;
+                res[7][j] = (T)o.trans_n;
             }
 #ifdef MOD16_SCHED_BARRIER
             __builtin_amdgcn_sched_barrier(0);
@@ -270,11 +281,14 @@ template <typename T, bool FAST, bool DIAG>
 __global__ void __launch_bounds__(kBlock) et_kernel_dma(const EtArgs<T> a) {
     constexpr int V = 16 / (int)sizeof(T);
     constexpr int kSlot = 15 * 1024;   // 14 x (64 lanes x 16 B) + class bytes
-    constexpr int kTab = FastMath<T>::kTabDoubles;
-    __shared__ T lut[MOD16_LUT_ROWS * kLutCols];
-    __shared__ __attribute__((aligned(16))) T tab[kTab > 0 ? kTab : 1];
+    // arithmetic is float64 for both data types (float32 is widened on load,
+    // rounded once on store)
+    static_assert(FAST, "the LDS-DMA kernel is the FAST production kernel");
+    constexpr int kTab = FastMath<double>::kTabDoubles;
+    __shared__ double lut[MOD16_LUT_ROWS * kLutCols];
+    __shared__ __attribute__((aligned(16))) double tab[kTab];
     __shared__ __attribute__((aligned(16))) char stage[(kBlock / 64) * kSlot];
-    for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) lut[i] = a.lut[i];
+    for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) lut[i] = a.lut64[i];
     for (int i = threadIdx.x; i < kTab; i += kBlock) tab[i] = a.tab[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -370,16 +384,18 @@ __global__ void __launch_bounds__(kBlock) et_kernel_dma(const EtArgs<T> a) {
             VT day, night;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                PixelIn<T> x = {in[0][j], in[1][j], in[2][j], in[3][j], in[4][j], in[5][j], in[6][j],
-                                in[7][j], in[8][j], in[9][j], in[10][j], in[11][j], in[12][j],
-                                in[13][j]};
+                PixelIn<double> x = {(double)in[0][j], (double)in[1][j], (double)in[2][j],
+                                     (double)in[3][j], (double)in[4][j], (double)in[5][j],
+                                     (double)in[6][j], (double)in[7][j], (double)in[8][j],
+                                     (double)in[9][j], (double)in[10][j], (double)in[11][j],
+                                     (double)in[12][j], (double)in[13][j]};
                 unsigned c = (cbits >> (8 * j)) & 0xffu;
                 if (c >= 13u) {
                     atomicOr(a.status, kStatusClassRange);
                     c = 13u;
                 }
-                const T* l = lut + c;
-                ClassPar<T> p;
+                const double* l = lut + c;
+                ClassPar<double> p;
                 p.tmin_close = l[0 * kLutCols];
                 p.tmin_open = l[1 * kLutCols];
                 p.vpd_open = l[2 * kLutCols];
@@ -395,9 +411,9 @@ __global__ void __launch_bounds__(kBlock) et_kernel_dma(const EtArgs<T> a) {
                 p.inv_dvpd = l[12 * kLutCols];
                 p.rbl_slope = l[13 * kLutCols];
                 p.inv_beta = l[14 * kLutCols];
-                PixelOut<T> o = FAST ? et_pixel_fast<T>(x, p, tab) : et_pixel_exact<T>(x, p);
-                day[j] = (o.canopy_d + o.soil_d) + o.trans_d;
-                night[j] = (o.canopy_n + o.soil_n) + o.trans_n;
+                PixelOut<double> o = et_pixel_fast<double>(x, p, tab);
+                day[j] = (T)((o.canopy_d + o.soil_d) + o.trans_d);
+                night[j] = (T)((o.canopy_n + o.soil_n) + o.trans_n);
                 if (DIAG) {
                     const double d = (double)day[j], g = (double)night[j];
                     const bool dn = d != d, gn = g != g;

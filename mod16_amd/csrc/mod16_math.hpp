@@ -24,7 +24,7 @@ template <> __device__ __forceinline__ float ExactMath<float>::exp(float x) { re
 template <> __device__ __forceinline__ double ExactMath<double>::pow(double x, double y) { return ::pow(x, y); }
 template <> __device__ __forceinline__ float ExactMath<float>::pow(float x, float y) { return ::powf(x, y); }
 
-template <typename T> struct FastMath;
+template <typename T> struct FastMath;   // float64 only: FAST kernels always compute in float64
 
 // ---------------------------------------------------------------- float64
 template <> struct FastMath<double> {
@@ -116,41 +116,6 @@ template <> struct FastMath<double> {
         T yc = __builtin_fmin(y, 1e300);
         T t = __builtin_fmax(yc * log_tab(x, tb), -746.0);
         return exp_tab(t, tb);
-    }
-};
-
-// ---------------------------------------------------------------- float32
-template <> struct FastMath<float> {
-    typedef float T;
-    static __device__ __forceinline__ T rcp(T x) {
-        T r = __builtin_amdgcn_rcpf(x);
-        T e = __builtin_fmaf(-x, r, 1.0f);
-        return __builtin_fmaf(r, e, r);
-    }
-    static __device__ __forceinline__ T rcp_safe(T x) {
-        T r0 = __builtin_amdgcn_rcpf(x);
-        T e = __builtin_fmaf(-x, r0, 1.0f);
-        T r1 = __builtin_fmaf(r0, e, r0);
-        return (r1 == r1) ? r1 : r0;
-    }
-    static __device__ __forceinline__ T div(T a, T b) { return a * rcp(b); }
-    static __device__ __forceinline__ T pow_m1p75(T x) {
-        T y = __builtin_amdgcn_sqrtf(__builtin_amdgcn_rsqf(x));
-        T y2 = y * y;
-        T t = x * (y2 * y2);
-        y = y * __builtin_fmaf(-0.25f, t, 1.25f);
-        y2 = y * y;
-        T y4 = y2 * y2;
-        return (y4 * y2) * y;
-    }
-    static constexpr int kTabDoubles = 0;
-    static __device__ __forceinline__ T exp(T x) { return ::expf(x); }
-    static __device__ __forceinline__ T log(T x) { return ::logf(x); }
-    static __device__ __forceinline__ T exp_tab(T x, const T*) { return ::expf(x); }
-    static __device__ __forceinline__ T pow01_tab(T x, T y, const T*) { return pow01(x, y); }
-    static __device__ __forceinline__ T pow01(T x, T y) {
-        T v = ::expf(y * ::logf(x));
-        return (x == 1.0f || y == 0.0f) ? 1.0f : v;
     }
 };
 

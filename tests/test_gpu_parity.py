@@ -123,10 +123,10 @@ def test_f3_per_pixel_parameter_arrays(m16, golden, mode):
 
 
 def test_f5_float32_raster(m16, golden):
-    """float32 in -> float32 out, float32 arithmetic; compared with the
-    reference's own float32 run. numpy-in-f32 vs f64 itself differs by up to
-    1.6e-2 at discontinuities, so: masks identical except at
-    branch flips, 99th percentile of the relative error below 1e-4."""
+    """float32 in -> float32 out (float64 arithmetic inside); compared with
+    the reference's own all-float32 run, whose own error against float64 is
+    median 2e-7, p99 1.4e-5, max 1.6e-2: NaN masks identical,
+    99th percentile of the relative difference below 1e-4."""
     f = golden('f5_random64_f32')
     drv = list(f['drivers'])
     day, night = m16.evapotranspiration_raster(
@@ -138,6 +138,42 @@ def test_f5_float32_raster(m16, golden):
         err = np.abs(got[ok].astype(np.float64) - want[ok]) / np.abs(want[ok])
         assert np.percentile(err, 99) < 1e-4, np.percentile(err, 99)
         assert np.median(err) < 5e-6, np.median(err)
+
+
+def test_f5_float32_exact_follows_reference_float32(m16, golden):
+    """MATH_EXACT on float32 data does float32 arithmetic in the reference's
+    operation order, like numpy does for the reference: masks identical, the
+    bulk of the pixels within a few float32 ulps."""
+    f = golden('f5_random64_f32')
+    day, night = m16.evapotranspiration_raster(
+        f['table'], f['cls'], *list(f['drivers']), math=m16._lib.MATH_EXACT)
+    for got, want in ((day, f['day']), (night, f['night'])):
+        assert got.dtype == np.float32
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert np.array_equal(got == 0, want == 0)
+        ok = np.isfinite(want) & (want != 0)
+        err = np.abs(got[ok].astype(np.float64) - want[ok]) / np.abs(want[ok])
+        assert np.median(err) < 2e-7 and np.percentile(err, 99) < 2e-5, \
+            (np.median(err), np.percentile(err, 99))
+
+
+def test_float32_storage_float64_arithmetic(m16):
+    """BASELINE.json configs[4] (tolerance check): the production float32
+    kernel widens on load, computes in float64 and rounds once on store, so on
+    float32-representable inputs it equals the float64 kernel up to that one
+    rounding (2^-24), with identical masks."""
+    cls, drv32 = synth.drivers((700, 900), seed=5, dtype=np.float32)
+    f = np.load(__import__('os').path.join(__import__('conftest').GOLDEN, 'f3_random64_f64.npz'))
+    d32, n32 = m16.evapotranspiration_raster(f['table'], cls, *drv32)
+    d64, n64 = m16.evapotranspiration_raster(
+        f['table'], cls, *[d.astype(np.float64) for d in drv32])
+    assert d32.dtype == np.float32 and d64.dtype == np.float64
+    for a, b in ((d32, d64), (n32, n64)):
+        want = b.astype(np.float32)
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert np.array_equal(a, want, equal_nan=True)      # exactly the rounded float64 result
+        ok = np.isfinite(b) & (b != 0)
+        assert np.max(np.abs(a[ok] - b[ok]) / np.abs(b[ok])) <= 2.0**-24 * 1.0001
 
 
 def test_class_code_out_of_range_raises(m16, golden):

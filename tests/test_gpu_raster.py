@@ -139,3 +139,38 @@ def test_scalar_driver_on_device(env):
     eng.check()
     assert torch.equal(torch.nan_to_num(d1), torch.nan_to_num(d2))
     assert torch.equal(torch.nan_to_num(n1), torch.nan_to_num(n2))
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_band_sharding_composes_to_the_global_run(env, world):
+    """BASELINE.json configs[2] on one device: the raster cut into `world` row
+    bands (what N ranks do) gives bit-identical outputs to the single run, and
+    the per-band diagnostics add up to the global ones."""
+    torch, RasterEngine, table = env
+    from mod16_amd import dist as tiles
+    eng = RasterEngine(table)
+    rows, cols = 2700 // 9 * world // world * 8, 1440     # small stand-in for 21600 x 43200
+    n = rows * cols
+    cls, drv = eng.synth(n, seed=16)
+    gdiag = torch.zeros(8, dtype=torch.float64, device='cuda')
+    gday, gnight = eng.run(cls, drv, diag=gdiag)
+    day_parts, night_parts, diags = [], [], []
+    for r in range(world):
+        off, m = tiles.pixel_range(rows, cols, r, world)
+        bcls, bdrv = eng.synth(m, seed=16, pixel_offset=off)      # each rank makes its own band
+        assert torch.equal(bcls, cls[off:off + m])
+        d = torch.zeros(8, dtype=torch.float64, device='cuda')
+        bd, bn = eng.run(bcls, bdrv, diag=d)
+        day_parts.append(bd)
+        night_parts.append(bn)
+        diags.append(d.clone())
+    eng.check()
+    assert torch.equal(torch.nan_to_num(torch.cat(day_parts), nan=-1.0),
+                       torch.nan_to_num(gday, nan=-1.0))
+    assert torch.equal(torch.nan_to_num(torch.cat(night_parts), nan=-1.0),
+                       torch.nan_to_num(gnight, nan=-1.0))
+    tot = torch.stack(diags)
+    g = gdiag.cpu().numpy()
+    np.testing.assert_allclose(tot[:, :2].sum(0).cpu().numpy(), g[:2], rtol=1e-12)
+    assert np.array_equal(tot[:, 2:6].sum(0).cpu().numpy(), g[2:6])
+    assert np.array_equal(tot[:, 6:].max(0).values.cpu().numpy(), g[6:])
