@@ -113,6 +113,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--cpu-workers', type=int, default=16)
+    ap.add_argument('--time-steps', type=int, default=0,
+                    help='also time a streamed series of this many steps (BASELINE configs[3])')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -204,6 +206,35 @@ def main():
         parity = {'pixels': int(m), 'max_rel_err': worst, 'masks_equal': masks,
                   'rtol_north_star': 1e-5, 'against': 'numpy oracle on the same input bits'}
 
+    series = None
+    if args.time_steps > 0:
+        # configs[3]: drivers of step s+1 produced on a second stream into a
+        # two-slot ring while the kernel works on step s (producer = the
+        # on-device generator standing in for an ingest stage)
+        del cls, drv, day, night
+        torch.cuda.empty_cache()
+        bufs = eng.alloc_series(n)
+        eng.run_series(n, 2, seed=SEED, pixel_offset=offset, buffers=bufs)   # warm-up
+        fence()
+        t0 = time.perf_counter()
+        sdiag, _, _ = eng.run_series(n, args.time_steps, seed=SEED, pixel_offset=offset,
+                                     buffers=bufs)
+        if world > 1:
+            for s in range(args.time_steps):
+                tiles.allreduce_diag(sdiag[s])
+        fence()
+        t_series = time.perf_counter() - t0
+        eng.check()
+        if world > 1:
+            t = torch.tensor([t_series], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_series = float(t.item())
+        series = {'steps': args.time_steps, 'seconds': t_series,
+                  'pixels_per_s': total * args.time_steps / t_series,
+                  'note': 'includes producing every step\'s 14 driver arrays on the device '
+                          '(113 B/pixel written by the generator on a second stream)',
+                  'sum_day_first_last': [float(sdiag[0, 0]), float(sdiag[-1, 0])]}
+
     if rank == 0:
         value = total * args.steps / elapsed
         line = {
@@ -229,6 +260,7 @@ def main():
                 'kernel_ms': kernel_ms, 'kernel_pixels_per_s': n / (kernel_ms * 1e-3),
             },
             'cpu_baseline': cpu,
+            'series': series,
             'parity': parity,
             'diagnostics': dict(zip(
                 ('sum_day', 'sum_night', 'n_valid_day', 'n_valid_night',

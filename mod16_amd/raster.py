@@ -143,6 +143,58 @@ class RasterEngine(object):
                     flags=self.math, where=_lib.DEVICE, stream=self._stream())
         return out_day, out_night
 
+    def alloc_series(self, n):
+        '''Device buffers of ``run_series``: class raster, the two-slot driver
+        ring and two output pairs.'''
+        torch = _torch()
+        return {'cls': torch.empty(n, dtype=torch.uint8, device=self._dev()),
+                'ring': [self.empty(n, _lib.N_DRIVERS) for _ in range(2)],
+                'outs': [self.empty(n, 2) for _ in range(2)]}
+
+    def run_series(self, n, steps, seed=16, pixel_offset=0, on_step=None, buffers=None):
+        '''A time series streamed through HBM (BASELINE.json configs[3]): the
+        drivers of step s + 1 are produced on a second HIP stream into the
+        other half of a two-slot ring while the fused kernel works on step s.
+        Here the producer is the on-device generator (``mod16_synth_*``), the
+        stand-in for an ingest stage; the ring, the two streams and the event
+        hand-off are what a real ingest would use. Returns ``(diag, day,
+        night)``: the [steps, 8] diagnostics series and the outputs of the
+        last step. ``on_step(s, day, night)`` is called (compute stream
+        current) after step s has been enqueued, e.g. to accumulate.'''
+        torch = _torch()
+        dev = self._dev()
+        compute = torch.cuda.current_stream(self.device)
+        ingest = torch.cuda.Stream(device=dev)
+        buffers = buffers or self.alloc_series(n)
+        cls, ring, outs = buffers['cls'], buffers['ring'], buffers['outs']
+        diag = torch.zeros(steps, 8, dtype=torch.float64, device=dev)
+        filled = [torch.cuda.Event() for _ in range(steps)]
+        consumed = [torch.cuda.Event() for _ in range(steps)]
+        ingest.wait_stream(compute)
+
+        def produce(s):
+            with torch.cuda.stream(ingest):
+                if s >= 2:
+                    ingest.wait_event(consumed[s - 2])      # slot is free again
+                self.synth(n, seed=seed, step=s, pixel_offset=pixel_offset,
+                           out=(cls, ring[s % 2]))
+                filled[s].record(ingest)
+
+        for s in range(min(2, steps)):
+            produce(s)
+        day = night = None
+        for s in range(steps):
+            compute.wait_event(filled[s])
+            day, night = outs[s % 2]
+            self.run(cls, ring[s % 2], day, night, diag=diag[s])
+            consumed[s].record(compute)
+            if on_step is not None:
+                on_step(s, day, night)
+            if s + 2 < steps:
+                produce(s + 2)
+        compute.wait_stream(ingest)
+        return diag, day, night
+
     def check(self):
         '''Synchronise and raise deferred errors (IndexError for a class code
         >= 13, as the reference's numpy gather would).'''
