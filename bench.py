@@ -205,6 +205,36 @@ def main():
             worst = max(worst, float(np.max(np.abs(got[ok].astype(np.float64) - ref[ok]) / np.abs(ref[ok]))))
         parity = {'pixels': int(m), 'max_rel_err': worst, 'masks_equal': masks,
                   'rtol_north_star': 1e-5, 'against': 'numpy oracle on the same input bits'}
+    if not args.no_parity and args.math == 'fast':
+        # every pixel of the band: the production kernel against the kernel that
+        # keeps the reference's operation order (IEEE divide / pow), on the device
+        exact = RasterEngine(table, device=local_rank, dtype=args.dtype, math=_lib.MATH_EXACT)
+        eday, enight = exact.run(cls, drv)
+        exact.check()
+        full = {'pixels': int(n), 'nan_masks_equal': True, 'zero_masks_equal': True,
+                'max_rel_err': 0.0, 'n_rel_err_gt_1e-9': 0, 'n_rel_err_gt_1e-5': 0}
+        for got, ref in ((day, eday), (night, enight)):
+            full['nan_masks_equal'] &= bool(torch.equal(torch.isnan(got), torch.isnan(ref)))
+            full['zero_masks_equal'] &= bool(torch.equal(got == 0, ref == 0))
+            err = (got - ref).abs_().div_(ref.abs())
+            err = torch.nan_to_num_(err, nan=0.0, posinf=0.0)     # masked pixels: 0/0, x/0
+            full['max_rel_err'] = max(full['max_rel_err'], float(err.max()))
+            full['n_rel_err_gt_1e-9'] += int((err > 1e-9).sum())
+            full['n_rel_err_gt_1e-5'] += int((err > 1e-5).sum())
+            del err
+        del eday, enight
+        if world > 1:
+            t = torch.tensor([full['max_rel_err'], -float(full['nan_masks_equal']),
+                              -float(full['zero_masks_equal'])], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            c = torch.tensor([full['n_rel_err_gt_1e-9'], full['n_rel_err_gt_1e-5'], n],
+                             dtype=torch.float64, device='cuda')
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            full.update(max_rel_err=float(t[0]), nan_masks_equal=bool(t[1] == -1),
+                        zero_masks_equal=bool(t[2] == -1), pixels=int(c[2]))
+            full['n_rel_err_gt_1e-9'], full['n_rel_err_gt_1e-5'] = int(c[0]), int(c[1])
+        if parity is not None:
+            parity['full_grid_fast_vs_exact_kernel'] = full
 
     series = None
     if args.time_steps > 0:
