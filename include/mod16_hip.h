@@ -202,6 +202,26 @@ MOD16_API int mod16_method_f32(mod16_ctx* ctx, int method,
                      void* stream);
 
 /*
+ * The vectorised calibration path MOD16._evapotranspiration (reference
+ * mod16/__init__.py:195-382; MOD16._et :162-193 is out_day + out_night):
+ * latent heat flux [W m-2] for day and night, reference operation order. It
+ * is a different algorithm from mod16_et_* (other clamps, tmin_open in the
+ * soil-heat-flux condition, transpiration switched for the whole array on
+ * any(g_surf > 0)). `rcorr` = NULL or two arrays (day, night), the reference's
+ * `r_corr_list`; strides as elsewhere. HOST or DEVICE; synchronous in HOST.
+ */
+MOD16_API int mod16_et_static_f64(mod16_ctx* ctx, const double* const* drivers,
+                        const int64_t* dstride, const double* const* params,
+                        const int64_t* pstride, const double* const* rcorr,
+                        const int64_t* rstride, int64_t n, double* out_day,
+                        double* out_night, int where, void* stream);
+MOD16_API int mod16_et_static_f32(mod16_ctx* ctx, const float* const* drivers,
+                        const int64_t* dstride, const float* const* params,
+                        const int64_t* pstride, const float* const* rcorr,
+                        const int64_t* rstride, int64_t n, float* out_day,
+                        float* out_night, int where, void* stream);
+
+/*
  * Waits for the ctx's outstanding work on `stream` and reports deferred
  * errors of DEVICE-mode calls (MOD16_ERR_CLASS_RANGE, MOD16_ERR_HIP).
  */

@@ -276,13 +276,63 @@ class MOD16(object):
         return dict((k, getattr(self, k)) for k in names)
 
     @staticmethod
-    def _et(*args, **kwargs):
-        raise NotImplementedError(
-            'the vectorised calibration path MOD16._et / _evapotranspiration '
-            '(reference mod16/__init__.py:162-382, W m-2, different clamps) is '
-            'not part of the forward-run engine yet (DESIGN.md section 9)')
+    def _evapotranspiration(
+            params, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
+            sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
+            vpd_night, pressure, fpar, lai, f_wet=None, tiny=1e-7,
+            r_corr_list=None):
+        '''
+        The vectorised calibration interface (reference
+        mod16/__init__.py:195-382): ``params`` is the list of the 11
+        parameters in ``MOD16.required_parameters`` order (scalars or (1 x N)
+        arrays), the drivers are (T x N) arrays. Returns ``[day, night]``
+        latent heat flux [W m-2]. Note that this is, in the reference too, a
+        numerically different algorithm from ``MOD16.evapotranspiration()``;
+        ``f_wet`` is ignored as in the reference (:282).
+        '''
+        _check_tiny(tiny)
+        drivers = [lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
+                   sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
+                   vpd_night, pressure, fpar, lai]
+        params = list(params)
+        if len(params) != 11:
+            raise IndexError('params must hold the 11 parameters in '
+                             'MOD16.required_parameters order')
+        rc = list(r_corr_list) if r_corr_list is not None else []
+        values = drivers + params + rc
+        dtype = _result_dtype(values)
+        shape = np.broadcast_shapes(*[np.shape(v) for v in values])
+        n = int(np.prod(shape, dtype=np.int64))
+        keep_d, dptr, dstr = _marshal(drivers, shape, dtype)
+        keep_p, pptr, pstr = _marshal(params, shape, dtype)
+        keep_r, rptr, rstr = _marshal(rc, shape, dtype) if rc else (None, None, None)
+        day, night = np.empty(shape, dtype), np.empty(shape, dtype)
+        ctx = _lib.context(0)
+        if n:
+            fn = ctx.lib.mod16_et_static_f32 if dtype == np.float32 \
+                else ctx.lib.mod16_et_static_f64
+            ctx.check(fn(
+                ctx.handle, _lib.ptr_array(dptr), _lib.i64_array(dstr),
+                _lib.ptr_array(pptr), _lib.i64_array(pstr),
+                _lib.ptr_array(rptr) if rc else None,
+                _lib.i64_array(rstr) if rc else None, n, day.ctypes.data,
+                night.ctypes.data, _lib.HOST, None))
+        if not shape:
+            return [day[()], night[()]]
+        return [day, night]
 
-    _evapotranspiration = _et
+    @staticmethod
+    def _et(params, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
+            sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
+            vpd_night, pressure, fpar, lai, f_wet=None, tiny=1e-7,
+            r_corr_list=None):
+        '''Total (day + night) latent heat flux [W m-2], for calibration
+        (reference mod16/__init__.py:162-193).'''
+        day, night = MOD16._evapotranspiration(
+            params, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
+            sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
+            vpd_night, pressure, fpar, lai, r_corr_list=r_corr_list)
+        return np.add(day, night)
 
     @staticmethod
     def air_density(temp_k, pressure, rhumidity):

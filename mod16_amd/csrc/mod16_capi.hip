@@ -35,6 +35,7 @@ struct mod16_ctx {
     double* tab64 = nullptr;         // exp/log tables of FastMath<double>
     unsigned* status = nullptr;      // device status word
     unsigned* status_host = nullptr; // pinned mirror
+    unsigned* static_flag = nullptr; // device word of mod16_et_static_*
     double* diag_partial = nullptr;  // device [diag_capacity][kDiag]
     int64_t diag_capacity = 0;       // in blocks
     double* diag_dev = nullptr;      // device [kDiag]
@@ -104,6 +105,7 @@ extern "C" int mod16_destroy(mod16_ctx* ctx) {
     if (ctx->tab64) (void)hipFree(ctx->tab64);
     if (ctx->status) (void)hipFree(ctx->status);
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
+    if (ctx->static_flag) (void)hipFree(ctx->static_flag);
     if (ctx->diag_partial) (void)hipFree(ctx->diag_partial);
     if (ctx->diag_dev) (void)hipFree(ctx->diag_dev);
     if (ctx->diag_host) (void)hipHostFree(ctx->diag_host);
@@ -655,6 +657,109 @@ extern "C" int mod16_method_f32(mod16_ctx* ctx, int method, const float* const* 
                                 const int64_t* pstride, int64_t n, float* const* out, float alpha,
                                 int where, void* stream) {
     return method_entry<float>(ctx, method, in, istride, params, pstride, n, out, alpha, where, stream);
+}
+
+// ------------------------------------------- vectorised calibration path (N2)
+template <typename T>
+static int static_entry(mod16_ctx* ctx, const T* const* drivers, const int64_t* dstride,
+                        const T* const* params, const int64_t* pstride, const T* const* rcorr,
+                        const int64_t* rstride, int64_t n, T* out_day, T* out_night, int where,
+                        void* stream) {
+    if (!ctx) return MOD16_ERR_ARG;
+    if (!drivers || !dstride || !params || !pstride || !out_day || !out_night || n < 0)
+        return fail(ctx, MOD16_ERR_ARG, "mod16_et_static: bad argument");
+    StaticArgs<T> a;
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < 14; ++k) {
+        if (!drivers[k]) return fail(ctx, MOD16_ERR_ARG, "mod16_et_static: NULL driver");
+        a.drv[k] = drivers[k];
+        if (dstride[k]) a.dense_drv |= 1u << k;
+    }
+    for (int k = 0; k < 11; ++k) {
+        if (!params[k]) return fail(ctx, MOD16_ERR_ARG, "mod16_et_static: NULL parameter");
+        a.par[k] = params[k];
+        if (pstride[k]) a.dense_par |= 1u << k;
+    }
+    if (rcorr) {
+        if (!rcorr[0] || !rcorr[1] || !rstride) return fail(ctx, MOD16_ERR_ARG, "mod16_et_static: r_corr_list needs two arrays");
+        for (int k = 0; k < 2; ++k) {
+            a.rc[k] = rcorr[k];
+            if (rstride[k]) a.dense_rc |= 1u << k;
+        }
+    }
+    a.out[0] = out_day;
+    a.out[1] = out_night;
+    a.n = n;
+    if (n == 0) return MOD16_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->static_flag) HIPCHK(ctx, hipMalloc(&ctx->static_flag, sizeof(unsigned)));
+    a.flag = ctx->static_flag;
+    auto grid_of = [&](int64_t m) {
+        return (int)std::max<int64_t>(1, std::min<int64_t>((m + kBlock - 1) / kBlock, (int64_t)ctx->cus * 8));
+    };
+    if (where == MOD16_DEVICE) {
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        HIPCHK(ctx, hipMemsetAsync(a.flag, 0, sizeof(unsigned), st));
+        hipLaunchKernelGGL((static_flag_kernel<T>), dim3(grid_of(n)), dim3(kBlock), 0, st, a);
+        hipLaunchKernelGGL((static_kernel<T>), dim3(grid_of(n)), dim3(kBlock), 0, st, a);
+        HIPCHK(ctx, hipGetLastError());
+        return MOD16_OK;
+    }
+    if (where != MOD16_HOST) return fail(ctx, MOD16_ERR_ARG, "mod16_et_static: bad `where`");
+    // HOST: the whole-array branch needs every pixel before any output, so the
+    // inputs are made resident once (calibration-sized arrays, not rasters)
+    constexpr int kArr = 14 + 11 + 2 + 2;
+    const size_t per_arr = (((size_t)n * sizeof(T)) + 255) / 256 * 256;
+    void* buf = nullptr;
+    HIPCHK(ctx, hipMalloc(&buf, per_arr * kArr));
+    if (!ctx->streams[0]) {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking);
+        if (e != hipSuccess) { (void)hipFree(buf); ctx->err = "hipStreamCreate failed"; return MOD16_ERR_HIP; }
+    }
+    hipStream_t st = ctx->streams[0];
+    char* base = static_cast<char*>(buf);
+    StaticArgs<T> d = a;
+    int slot = 0;
+    int rc_status = MOD16_OK;
+    auto up = [&](const T* src, bool dense) -> const T* {
+        T* dp = reinterpret_cast<T*>(base + per_arr * slot++);
+        hipError_t e = hipMemcpyAsync(dp, src, sizeof(T) * (dense ? n : 1), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) rc_status = MOD16_ERR_HIP;
+        return dp;
+    };
+    for (int k = 0; k < 14; ++k) d.drv[k] = up(a.drv[k], (a.dense_drv >> k) & 1u);
+    for (int k = 0; k < 11; ++k) d.par[k] = up(a.par[k], (a.dense_par >> k) & 1u);
+    for (int k = 0; k < 2; ++k) d.rc[k] = a.rc[k] ? up(a.rc[k], (a.dense_rc >> k) & 1u) : nullptr;
+    slot = 27;
+    d.out[0] = reinterpret_cast<T*>(base + per_arr * slot++);
+    d.out[1] = reinterpret_cast<T*>(base + per_arr * slot++);
+    if (rc_status == MOD16_OK) {
+        (void)hipMemsetAsync(d.flag, 0, sizeof(unsigned), st);
+        hipLaunchKernelGGL((static_flag_kernel<T>), dim3(grid_of(n)), dim3(kBlock), 0, st, d);
+        hipLaunchKernelGGL((static_kernel<T>), dim3(grid_of(n)), dim3(kBlock), 0, st, d);
+        if (hipGetLastError() != hipSuccess) rc_status = MOD16_ERR_HIP;
+        if (hipMemcpyAsync(out_day, d.out[0], sizeof(T) * n, hipMemcpyDeviceToHost, st) != hipSuccess) rc_status = MOD16_ERR_HIP;
+        if (hipMemcpyAsync(out_night, d.out[1], sizeof(T) * n, hipMemcpyDeviceToHost, st) != hipSuccess) rc_status = MOD16_ERR_HIP;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) rc_status = MOD16_ERR_HIP;
+    (void)hipFree(buf);
+    if (rc_status != MOD16_OK) ctx->err = "mod16_et_static: HIP call failed";
+    return rc_status;
+}
+
+extern "C" int mod16_et_static_f64(mod16_ctx* ctx, const double* const* drivers,
+                                   const int64_t* dstride, const double* const* params,
+                                   const int64_t* pstride, const double* const* rcorr,
+                                   const int64_t* rstride, int64_t n, double* out_day,
+                                   double* out_night, int where, void* stream) {
+    return static_entry<double>(ctx, drivers, dstride, params, pstride, rcorr, rstride, n, out_day, out_night, where, stream);
+}
+extern "C" int mod16_et_static_f32(mod16_ctx* ctx, const float* const* drivers,
+                                   const int64_t* dstride, const float* const* params,
+                                   const int64_t* pstride, const float* const* rcorr,
+                                   const int64_t* rstride, int64_t n, float* out_day,
+                                   float* out_night, int where, void* stream) {
+    return static_entry<float>(ctx, drivers, dstride, params, pstride, rcorr, rstride, n, out_day, out_night, where, stream);
 }
 
 // ------------------------------------------------------------- diagnostics

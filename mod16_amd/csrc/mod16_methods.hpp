@@ -134,4 +134,60 @@ __global__ void __launch_bounds__(kBlock) method_kernel(const MethodArgs<T> a) {
     }
 }
 
+// ---- the vectorised calibration path, MOD16._evapotranspiration (:195-382)
+template <typename T> struct StaticArgs {
+    const T* drv[14];
+    const T* par[11];
+    const T* rc[2];          // optional r_corr_list (day, night), NULL = compute
+    T* out[2];
+    int64_t n;
+    uint32_t dense_drv, dense_par, dense_rc;
+    unsigned* flag;          // device word: bit 0 = any(g_surf > 0) in the day period
+};
+
+template <typename T>
+__device__ __forceinline__ void static_load(const StaticArgs<T>& a, int64_t i, PixelIn<T>& x,
+                                            ClassPar<T>& p) {
+    auto d = [&](int k) { return ((a.dense_drv >> k) & 1u) ? a.drv[k][i] : a.drv[k][0]; };
+    auto q = [&](int k) { return ((a.dense_par >> k) & 1u) ? a.par[k][i] : a.par[k][0]; };
+    x = {d(0), d(1), d(2), d(3), d(4), d(5), d(6), d(7), d(8), d(9), d(10), d(11), d(12), d(13)};
+    p.tmin_close = q(0); p.tmin_open = q(1); p.vpd_open = q(2); p.vpd_close = q(3);
+    p.gl_sh = q(4); p.gl_wv = q(5); p.g_cut = q(6); p.csl = q(7);
+    p.rbl_min = q(8); p.rbl_max = q(9); p.beta = q(10);
+}
+
+// pass 1: does any pixel have g_surf > 0 (the reference's whole-array branch)?
+template <typename T>
+__global__ void __launch_bounds__(kBlock) static_flag_kernel(const StaticArgs<T> a) {
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    bool any = false;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += step) {
+#pragma clang fp contract(off)
+        PixelIn<T> x;
+        ClassPar<T> p;
+        static_load(a, i, x, p);
+        T rc = a.rc[0] ? (((a.dense_rc >> 0) & 1u) ? a.rc[0][i] : a.rc[0][0]) : rcorr_exact(x.pa, x.t_d);
+        any = any || ((gsurf_static(p, x.tmin, x.vpd_d) / rc) > T(0));
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(a.flag, 1u);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) static_kernel(const StaticArgs<T> a) {
+    const bool any_gs = (*a.flag & 1u) != 0;
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += step) {
+        PixelIn<T> x;
+        ClassPar<T> p;
+        static_load(a, i, x, p);
+        const bool has_rc = a.rc[0] != nullptr;
+        T rc_d = has_rc ? (((a.dense_rc >> 0) & 1u) ? a.rc[0][i] : a.rc[0][0]) : T(0);
+        T rc_n = has_rc ? (((a.dense_rc >> 1) & 1u) ? a.rc[1][i] : a.rc[1][0]) : T(0);
+        T day, night;
+        et_static_pixel(x, p, has_rc, rc_d, rc_n, any_gs, day, night);
+        a.out[0][i] = day;
+        a.out[1][i] = night;
+    }
+}
+
 }  // namespace mod16

@@ -292,6 +292,93 @@ __device__ __forceinline__ PixelOut<T> et_pixel_exact(const PixelIn<T>& x, const
     return o;
 }
 
+// ============================================================ static (N2)
+// MOD16._evapotranspiration, mod16/__init__.py:195-382: the vectorised
+// calibration path. A different algorithm from the instance path (W m-2, no
+// upper RH clamp, tmin_open in the G condition, no negative clamps, and a
+// whole-array branch on any(g_surf > 0)), kept in its own operation order.
+
+// day-time surface conductance before the division by r_corr, :325-327
+template <typename T>
+__device__ __forceinline__ T gsurf_static(const ClassPar<T>& p, T tmin, T vpd) {
+#pragma clang fp contract(off)
+    return p.csl * ramp_up_exact(tmin - K<T>::t0, p.tmin_close, p.tmin_open) *
+           ramp_down_exact(vpd, p.vpd_open, p.vpd_close);
+}
+
+template <typename T, bool DAY>
+__device__ __forceinline__ T period_static(const PixelIn<T>& x, const ClassPar<T>& p, T t, T vpd,
+                                           T sw, T lw, T rad_soil, bool has_rc, T rc_in,
+                                           bool any_gs) {
+#pragma clang fp contract(off)
+    const T tiny = K<T>::tiny;
+    T rad_net = sw * (T(1) - x.alb) + lw;                          // :272-274
+    T rad_c = x.fpar * rad_net;
+    T sv = svp_exact(t);
+    T rh = (sv - vpd) / sv;                                        // :280-281
+    rh = (rh < T(0)) ? T(0) : rh;
+    T fw = (rh < T(0.7)) ? T(0) : ExactMath<T>::pow(rh, T(4));
+    T d = (T(239.0) + t) - K<T>::t0;
+    T s = (T(17.38 * 239.0) * sv) / (d * d);
+    T lhv = lhv_exact(t);
+    T gamma = gamma_exact(x.pa, t);
+    T rc = has_rc ? rc_in : rcorr_exact(x.pa, t);                  // :291-294
+    T rho = rho_exact(t, x.pa, rh);
+    T r_r = rr_exact(rho, t);
+    T r_h = T(1) / (p.gl_sh * x.lai * fw);                         // :305-311
+    T r_e = T(1) / (p.gl_wv * x.lai * fw);
+    T r_a = (r_h * r_r) / (r_h + r_r);
+    T e = (fw * ((s * rad_c) + (rho * K<T>::cp * x.fpar * vpd * T(1) / r_a))) /
+          (s + ((x.pa * K<T>::cp * r_e) * T(1) / (lhv * K<T>::eps * r_a)));
+    T e_canopy = (x.lai * fw <= tiny) ? T(0) : e;                  // :320
+    T g_surf = DAY ? gsurf_static(p, x.tmin, vpd) : T(0);
+    g_surf = g_surf / rc;                                          // :328
+    T g_cut = p.g_cut / rc;
+    T gl = p.gl_sh * x.lai * (T(1) - fw);
+    T g = (gl * (g_surf + g_cut)) / (gl + g_surf + g_cut);
+    T g_can = ((x.lai > T(0)) && ((T(1) - fw) > T(0))) ? g : tiny;
+    T r_dry = (T(1) / p.gl_sh * r_r) / (T(1) / p.gl_sh + r_r);
+    T tr = T(0);                                                   // :343-348
+    if (any_gs) {
+        tr = (T(1) - fw) * ((s * rad_c) + (rho * K<T>::cp * x.fpar * (vpd / r_dry)));
+        tr = tr / (s + gamma * (T(1) + (T(1) / g_can) / r_dry));
+    }
+    T r_tot = (vpd <= p.vpd_open) ? p.rbl_min
+              : ((vpd >= p.vpd_close) ? p.rbl_max
+                 : p.rbl_max - ((p.rbl_max - p.rbl_min) * (p.vpd_close - vpd)) /
+                                   (p.vpd_close - p.vpd_open));
+    r_tot = r_tot / rc;
+    T r_as = (r_tot * r_r) / (r_tot + r_r);
+    T numer = (s * rad_soil) + (rho * K<T>::cp * (T(1) - x.fpar) * (vpd / r_as));
+    T denom = s + gamma * (r_tot / r_as);
+    T sat = (numer * fw) / denom;
+    T unsat = (numer * (T(1) - fw)) / denom;
+    T e_soil = sat + unsat * ExactMath<T>::pow(rh, vpd / p.beta);  // :376
+    return (tr + e_canopy) + e_soil;                               // :380
+}
+
+template <typename T>
+__device__ __forceinline__ void et_static_pixel(const PixelIn<T>& x, const ClassPar<T>& p,
+                                                bool has_rc, T rc_d, T rc_n, bool any_gs_day,
+                                                T& day, T& night) {
+#pragma clang fp contract(off)
+    T a_d = x.sw_d * (T(1) - x.alb) + x.lw_d;                      // :225-226
+    T a_n = x.lw_n;
+    bool cond = (x.t_ann < T(273.15 + 25.0)) && (x.t_ann > (K<T>::t0 + p.tmin_open)) &&
+                ((x.t_d - x.t_n) >= T(5));                         // :230-234 (tmin_open, strict)
+    T g_d = cond ? (T(4.73) * (x.t_d - K<T>::t0)) - T(20.87) : T(0);
+    g_d = (__builtin_fabs(g_d) > (T(0.39) * __builtin_fabs(a_d))) ? T(0.39) * a_d : g_d;
+    T g_n = cond ? (T(4.73) * (x.t_n - K<T>::t0)) - T(20.87) : T(0);
+    g_n = (__builtin_fabs(g_n) > (T(0.39) * __builtin_fabs(a_n))) ? T(0.39) * a_n : g_n;
+    g_d = ((a_d - g_d < T(0)) && (a_d > T(0))) ? a_d : g_d;
+    g_n = ((a_d > T(0)) && ((a_n - g_n) < (T(-0.5) * a_d))) ? a_n + (T(0.5) * a_d) : g_n;
+    T rs_d = (T(1) - x.fpar) * (a_d - g_d);
+    T rs_n = (T(1) - x.fpar) * (a_n - g_n);
+    day = period_static<T, true>(x, p, x.t_d, x.vpd_d, x.sw_d, x.lw_d, rs_d, has_rc, rc_d, any_gs_day);
+    // at night g_surf = 0 / r_corr, so any(g_surf > 0) is False: t = 0 (:343-348)
+    night = period_static<T, false>(x, p, x.t_n, x.vpd_n, x.sw_n, x.lw_n, rs_n, has_rc, rc_n, false);
+}
+
 // ====================================================================== fast
 // Quantities that do not depend on the period (day / night).
 template <typename T> struct PixelShared {

@@ -323,3 +323,111 @@ def bplut_table(bplut):
     PARAM_NAMES column order (the layout ``mod16_set_bplut_f64`` takes)."""
     return np.ascontiguousarray(
         np.stack([np.asarray(bplut[k], np.float64) for k in PARAM_NAMES], 1))
+
+
+# ---------------------------------------------------------------------------
+# The vectorised calibration path (SURVEY.md section 8f, row N2). It is a
+# different algorithm from the instance path above (W m-2, other clamps, a
+# whole-array branch on g_surf), restated here in its own operation order.
+
+def et_static_daynight(params, lw_net_day, lw_net_night, sw_rad_day,
+                       sw_rad_night, sw_albedo, temp_day, temp_night,
+                       temp_annual, tmin, vpd_day, vpd_night, pressure, fpar,
+                       lai, tiny=TINY, r_corr_list=None):
+    """MOD16._evapotranspiration, mod16/__init__.py:195-382: [day, night]
+    latent heat flux [W m-2]. ``params`` is the 11-vector in
+    MOD16.required_parameters order (scalars or (1 x N) arrays)."""
+    with np.errstate(all='ignore'):
+        rad_net_day = sw_rad_day * (1 - sw_albedo) + lw_net_day          # :225
+        rad_net_night = lw_net_night
+        condition = np.logical_and(                                       # :230-234
+            np.logical_and(
+                temp_annual < (273.15 + 25),
+                temp_annual > (273.15 + params[1])),
+            (temp_day - temp_night) >= 5)
+        g_soil = []
+        for rad_i, temp_i in ((rad_net_day, temp_day), (rad_net_night, temp_night)):
+            g = np.where(condition, (4.73 * (temp_i - 273.15)) - 20.87, 0)
+            g = np.where(np.abs(g) > (0.39 * np.abs(rad_i)), 0.39 * rad_i, g)
+            g_soil.append(g)
+        g_soil_day, g_soil_night = g_soil
+        g_soil_day = np.where(
+            np.logical_and(rad_net_day - g_soil_day < 0, rad_net_day > 0),
+            rad_net_day, g_soil_day)
+        g_soil_night = np.where(
+            np.logical_and(
+                rad_net_day > 0,
+                (rad_net_night - g_soil_night) < (-0.5 * rad_net_day)),
+            rad_net_night + (0.5 * rad_net_day), g_soil_night)
+        rad_soil_day = (1 - fpar) * (rad_net_day - g_soil_day)
+        rad_soil_night = (1 - fpar) * (rad_net_night - g_soil_night)
+        out = []
+        for i, (temp_k, vpd, sw_rad, lw_net, rad_soil) in enumerate((
+                (temp_day, vpd_day, sw_rad_day, lw_net_day, rad_soil_day),
+                (temp_night, vpd_night, sw_rad_night, lw_net_night, rad_soil_night))):
+            daytime = (i == 0)
+            rad_net = sw_rad * (1 - sw_albedo) + lw_net
+            rad_canopy = fpar * rad_net
+            _svp = svp(temp_k)
+            rh = (_svp - vpd) / _svp                                      # :280-281
+            rh = np.where(rh < 0, 0, rh)
+            f_wet = np.where(rh < 0.7, 0, np.power(rh, 4))
+            s = svp_slope(temp_k, _svp)
+            lhv = latent_heat_vaporization(temp_k)
+            gamma = psychrometric_constant(pressure, temp_k)
+            if r_corr_list is None:
+                r_corr = (101300 / pressure) * (temp_k / 293.15)**1.75
+            else:
+                r_corr = r_corr_list[i]
+            rho = air_density(temp_k, pressure, rh)
+            r_r = (rho * SPECIFIC_HEAT_CAPACITY_AIR) / (
+                4 * STEFAN_BOLTZMANN * temp_k**3)
+            r_h = 1 / (params[4] * lai * f_wet)                           # :305-311
+            r_e = 1 / (params[5] * lai * f_wet)
+            r_a_wet = np.divide(r_h * r_r, r_h + r_r)
+            e = np.divide(
+                f_wet * ((s * rad_canopy) + (
+                    rho * SPECIFIC_HEAT_CAPACITY_AIR * fpar * vpd * 1 / r_a_wet)),
+                s + ((pressure * SPECIFIC_HEAT_CAPACITY_AIR * r_e) *
+                     1 / (lhv * MOL_WEIGHT_WET_DRY_RATIO_AIR * r_a_wet)))
+            e_canopy = np.where(lai * f_wet <= tiny, 0, e)                # :320
+            g_surf = 0
+            if daytime:
+                m_tmin = linear_constraint(params[0], params[1])
+                m_vpd = linear_constraint(params[2], params[3], 'reversed')
+                g_surf = (params[7] * m_tmin(tmin - 273.15) * m_vpd(vpd))
+            g_surf = g_surf / r_corr                                      # :328
+            g_cuticular = params[6] / r_corr
+            gl_sh = params[4] * lai * (1 - f_wet)
+            g = ((gl_sh * (g_surf + g_cuticular)) / (
+                gl_sh + g_surf + g_cuticular))
+            g_canopy = np.where(
+                np.logical_and(lai > 0, (1 - f_wet) > 0), g, tiny)
+            r_a_dry = (1 / params[4] * r_r) / (1 / params[4] + r_r)
+            if np.any(g_surf > 0):                                        # :343-348
+                t = (1 - f_wet) * ((s * rad_canopy) + (
+                    rho * SPECIFIC_HEAT_CAPACITY_AIR * fpar * (vpd / r_a_dry)))
+                t = t / (s + gamma * (1 + (1 / g_canopy) / r_a_dry))
+            else:
+                t = 0
+            r_tot = np.where(
+                vpd <= params[2], params[8],
+                np.where(vpd >= params[3], params[9],
+                         params[9] - ((params[9] - params[8]) * (params[3] - vpd))
+                         / (params[3] - params[2])))
+            r_tot = r_tot / r_corr
+            r_as = (r_tot * r_r) / (r_tot + r_r)
+            numer = (s * rad_soil) + (
+                rho * SPECIFIC_HEAT_CAPACITY_AIR * (1 - fpar) * (vpd / r_as))
+            denom = (s + gamma * (r_tot / r_as))
+            evap_sat = (numer * f_wet) / denom
+            evap_unsat = (numer * (1 - f_wet)) / denom
+            e_soil = evap_sat + evap_unsat * rh**(vpd / params[10])       # :376
+            out.append((t + e_canopy + e_soil))                           # :380
+    return out
+
+
+def et_static(params, *drivers, r_corr_list=None):
+    """MOD16._et, mod16/__init__.py:162-193: day + night [W m-2]."""
+    day, night = et_static_daynight(params, *drivers, r_corr_list=r_corr_list)
+    return np.add(day, night)

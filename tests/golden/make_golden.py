@@ -249,6 +249,29 @@ def main():
         pa, t_n, vpd_n, lai_, fpar_, fpar_ * lw_n, tmin_, daytime=False)
     np.savez_compressed(os.path.join(HERE, 'f6_submethods.npz'), **f6)
 
+    # ---- F7: the vectorised calibration path MOD16._evapotranspiration / _et
+    #      (mod16/__init__.py:162-382): (T x N) drivers, (1 x N) parameters
+    T_, N_ = 12, 40
+    cls7, drv7 = synth.drivers((T_, N_), seed=7, special=False)
+    site_cls = cls7[0]
+    pars7 = [bplut[k][site_cls].reshape(1, N_) for k in names]
+    drv7[7] = np.broadcast_to(drv7[7][0], (T_, N_)).copy()       # temp_annual per site
+    drv7[12][3, :5] = 0.0                                        # fpar / lai specials
+    drv7[13][4, :5] = 0.0
+    day7, night7 = MOD16._evapotranspiration(pars7, *drv7)
+    et7 = MOD16._et(pars7, *drv7)
+    rcl = [np.full((T_, N_), 1.1), np.full((T_, N_), 1.05)]
+    dayr, nightr = MOD16._evapotranspiration(pars7, *drv7, r_corr_list=rcl)
+    # a case where no pixel has g_surf > 0 (tmin below tmin_close everywhere)
+    drv_cold = [d.copy() for d in drv7]
+    drv_cold[8] = np.full((T_, N_), 240.0)
+    dayc, nightc = MOD16._evapotranspiration(pars7, *drv_cold)
+    np.savez_compressed(
+        os.path.join(HERE, 'f7_static_path.npz'), params=np.concatenate(pars7, 0),
+        drivers=np.stack(drv7), day=day7, night=night7, et=et7,
+        r_corr_day=rcl[0], r_corr_night=rcl[1], day_rcorr=dayr, night_rcorr=nightr,
+        tmin_cold=drv_cold[8], day_cold=dayc, night_cold=nightc)
+
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith('.npz'):
             print('%-28s %7d bytes' % (fn, os.path.getsize(os.path.join(HERE, fn))))

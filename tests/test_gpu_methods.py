@@ -226,5 +226,38 @@ def test_unsupported_corners(m16):
     with pytest.raises(NotImplementedError):
         m.transpiration(S.pressure, S.temp_k, S.vpd, S.lai, S.fpar, S.rad_canopy, S.tmin,
                         tiny=1e-6)
-    with pytest.raises(NotImplementedError):
-        m16.MOD16._et([1] * 11, *([1.0] * 14))
+
+
+def test_et_vectorized(m16, golden):                      # tests.py:64-90, all three interfaces
+    params_vector = [S.params[p] for p in m16.MOD16.required_parameters]
+    drivers = (-50, -30, 150, 0, 0.3, 293, 290, 285, 285, 1000, 500, S.pressure, S.fpar, S.lai)
+    _et = m16.MOD16._et(params_vector, *drivers)
+    _day, _night = m16.MOD16._evapotranspiration(params_vector, *drivers)
+    assert round(float(_et), 2) == 40.94
+    assert round(float(_day + _night), 2) == 40.94
+    f = golden('f1_tests_scalars')
+    assert_parity(np.asarray(_et), f['et_static'], RTOL, '_et')
+    assert_parity(np.array([_day, _night]), f['et_static_daynight'], RTOL, '_evapotranspiration')
+
+
+def test_static_calibration_path(m16, golden):
+    """MOD16._evapotranspiration with (T x N) drivers and (1 x N) parameters
+    against the reference's own run (f7), incl. r_corr_list and the whole-array
+    any(g_surf > 0) switch."""
+    f = golden('f7_static_path')
+    params = [f['params'][k:k + 1] for k in range(11)]
+    drv = list(f['drivers'])
+    day, night = m16.MOD16._evapotranspiration(params, *drv)
+    assert day.shape == (12, 40)
+    assert_parity(day, f['day'], 1e-11, 'day')
+    assert_parity(night, f['night'], 1e-11, 'night')
+    assert_parity(m16.MOD16._et(params, *drv), f['et'], 1e-11, 'et')
+    day, night = m16.MOD16._evapotranspiration(
+        params, *drv, r_corr_list=[f['r_corr_day'], f['r_corr_night']])
+    assert_parity(day, f['day_rcorr'], 1e-11, 'day r_corr_list')
+    assert_parity(night, f['night_rcorr'], 1e-11, 'night r_corr_list')
+    cold = list(drv)
+    cold[8] = f['tmin_cold']
+    day, night = m16.MOD16._evapotranspiration(params, *cold)
+    assert_parity(day, f['day_cold'], 1e-11, 'day, no g_surf anywhere')
+    assert_parity(night, f['night_cold'], 1e-11, 'night, no g_surf anywhere')

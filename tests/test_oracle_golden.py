@@ -141,3 +141,28 @@ def test_f6_submethods(golden):
          f['transpiration_day'])
     same(oracle.transpiration(p, pa, t_n, vpd_n, lai, fpar, fpar * lw_n, tmin,
                               daytime=False), f['transpiration_night'])
+
+
+def test_f7_static_calibration_path(golden):
+    """MOD16._evapotranspiration / _et (mod16/__init__.py:162-382), row N2."""
+    f = golden('f7_static_path')
+    params = [f['params'][k:k + 1] for k in range(11)]        # (1 x N) each
+    drv = list(f['drivers'])
+    day, night = oracle.et_static_daynight(params, *drv)
+    same(day, f['day'])
+    same(night, f['night'])
+    same(oracle.et_static(params, *drv), f['et'])
+    day, night = oracle.et_static_daynight(
+        params, *drv, r_corr_list=[f['r_corr_day'], f['r_corr_night']])
+    same(day, f['day_rcorr'])
+    same(night, f['night_rcorr'])
+    cold = list(drv)
+    cold[8] = f['tmin_cold']
+    day, night = oracle.et_static_daynight(params, *cold)
+    same(day, f['day_cold'])      # no pixel with g_surf > 0: transpiration off everywhere
+    same(night, f['night_cold'])
+    assert not np.array_equal(f['day_cold'], f['day'])
+    # the reference's own assertions, tests/tests.py:85-87
+    g = golden('f1_tests_scalars')
+    et = oracle.et_static(list(g['params']), *list(g['drivers']))
+    assert round(float(et), 2) == 40.94 and float(et) == float(g['et_static'])

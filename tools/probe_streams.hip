@@ -32,6 +32,33 @@ __global__ void __launch_bounds__(256) stream_kernel(Args a) {
     }
 }
 
+template <int K, int W, int NT>
+__global__ void __launch_bounds__(256) oneshot_kernel(Args a) {
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= a.nvec) return;
+    d2 s = {0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < K; ++k) s += (NT & 1) ? __builtin_nontemporal_load(&a.in[k][v]) : a.in[k][v];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        if (NT & 2) __builtin_nontemporal_store(s + (double)w, &a.out[w][v]);
+        else a.out[w][v] = s + (double)w;
+    }
+    if (W == 0 && s[0] == 1.2345e300) a.out[0][v] = s;
+}
+template <int K, int W, int NT> void run_oneshot(Args a, const char* name) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const unsigned grid = (unsigned)((a.nvec + 255) / 256);
+    oneshot_kernel<K, W, NT><<<grid, 256>>>(a); hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        hipEventRecord(e0); oneshot_kernel<K, W, NT><<<grid, 256>>>(a); hipEventRecord(e1);
+        hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    double bytes = (double)a.nvec * 16.0 * (K + W);
+    printf("%-22s one-shot     %8.3f ms  %8.1f GB/s  (%.1f%% of 8 TB/s)\n", name, best, bytes / best / 1e6, bytes / best / 1e6 / 80.0);
+}
+
 template <int K, int W, bool CLS, int NT = 0> void run(Args a, int grid, const char* name) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     stream_kernel<K, W, CLS, NT><<<grid, 256>>>(a); hipDeviceSynchronize();
@@ -51,6 +78,13 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 4; ++k) hipMalloc((void**)&a.out[k], nvec * 16);
     hipMalloc((void**)&a.cls, nvec * 2); hipMemset((void*)a.cls, 1, nvec * 2);
     a.nvec = nvec;
+    run_oneshot<1, 1, 0>(a, "1R+1W");
+    run_oneshot<14, 0, 0>(a, "14R");
+    run_oneshot<14, 2, 0>(a, "14R+2W");
+    run_oneshot<14, 2, 3>(a, "14R+2W nt-both");
+    run_oneshot<14, 2, 2>(a, "14R+2W nt-store");
+    run_oneshot<7, 1, 0>(a, "7R+1W");
+    run_oneshot<0, 2, 0>(a, "2W");
     for (int grid : {256 * 64}) {
         run<1, 1, false>(a, grid, "1R+1W (copy)");
         run<1, 0, false>(a, grid, "1R");
