@@ -139,11 +139,19 @@ def main():
     from mod16_amd.utils import restore_bplut, bplut_table
     from mod16_amd.models import COLLECTION61_BPLUT
 
+    # rehearsal on a 1-GPU box: MOD16_BENCH_ONE_DEVICE=1 puts every rank on
+    # cuda:0 and uses gloo (RCCL refuses two ranks on one device)
+    rehearsal = os.environ.get('MOD16_BENCH_ONE_DEVICE') == '1'
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if rehearsal:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
 
     table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
     math = _lib.MATH_FAST if args.math == 'fast' else _lib.MATH_EXACT
@@ -155,8 +163,10 @@ def main():
     day, night = eng.empty(n, 2)
     diag = torch.zeros(8, dtype=torch.float64, device='cuda')
 
+    launch = eng.bind(cls, drv, day, night, diag)   # ET + diagnostics in one pass
+
     def step():
-        eng.run(cls, drv, day, night, diag=diag)   # ET + diagnostics in one pass
+        launch()
         tiles.allreduce_diag(diag)
 
     def fence():

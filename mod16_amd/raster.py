@@ -195,6 +195,29 @@ class RasterEngine(object):
         compute.wait_stream(ingest)
         return diag, day, night
 
+    def bind(self, cls, drivers, out_day, out_night, diag):
+        '''Pre-marshal one ``run(..., diag=diag)`` call and return a function
+        that enqueues it on the then-current stream with a single library call
+        (the per-step host cost of a time loop: no tensor checks, no ctypes
+        array construction). The tensors must stay alive and in place.'''
+        torch = _torch()
+        n = cls.numel()
+        cptr = self._check_tensor(cls, torch.uint8, n, 'cls')
+        keep, dptr, dstride = self._marshal_drivers(drivers, n)
+        args = (self.ctx.handle, cptr, _lib.ptr_array(dptr), _lib.i64_array(dstride), n,
+                self._check_tensor(out_day, self.dtype, n, 'out_day'),
+                self._check_tensor(out_night, self.dtype, n, 'out_night'), int(self.math),
+                self._check_tensor(diag, torch.float64, 8, 'diag'))
+        fn = self.ctx.lib.mod16_et_diag_f32 if self.np_dtype == np.float32 \
+            else self.ctx.lib.mod16_et_diag_f64
+        check, device = self.ctx.check, self.device
+        keepalive = (keep, cls, out_day, out_night, diag)
+
+        def launch():
+            check(fn(*args, torch.cuda.current_stream(device).cuda_stream))
+            return keepalive[2], keepalive[3]
+        return launch
+
     def check(self):
         '''Synchronise and raise deferred errors (IndexError for a class code
         >= 13, as the reference's numpy gather would).'''

@@ -206,3 +206,21 @@ def test_time_series_streaming_ring(env):
     assert torch.equal(acc, want_acc)
     # steps differ from one another (the generator is keyed on the step)
     assert not torch.equal(diag[0], diag[1])
+
+
+def test_bound_launch_equals_run(env):
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table)
+    n = 200000
+    cls, drv = eng.synth(n, seed=9)
+    d1 = torch.zeros(8, dtype=torch.float64, device='cuda')
+    a, b = eng.run(cls, drv, diag=d1)
+    day, night = eng.empty(n, 2)
+    d2 = torch.zeros(8, dtype=torch.float64, device='cuda')
+    launch = eng.bind(cls, drv, day, night, d2)
+    for _ in range(3):
+        launch()
+    eng.check()
+    assert torch.equal(d1, d2)
+    assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(day))
+    assert torch.equal(torch.nan_to_num(b), torch.nan_to_num(night))
