@@ -159,8 +159,8 @@ def main():
     offset, n = tiles.pixel_range(args.rows, args.cols, rank, world)
     total = args.rows * args.cols
 
-    cls, drv = eng.synth(n, seed=SEED, step=0, pixel_offset=offset)
-    day, night = eng.empty(n, 2)
+    cls, drv, day, night = eng.alloc_raster(n)      # one slab, staggered arrays
+    eng.synth(n, seed=SEED, step=0, pixel_offset=offset, out=(cls, drv))
     diag = torch.zeros(8, dtype=torch.float64, device='cuda')
 
     launch = eng.bind(cls, drv, day, night, diag)   # ET + diagnostics in one pass

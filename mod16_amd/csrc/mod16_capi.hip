@@ -22,6 +22,7 @@ namespace {
 constexpr int64_t kTilePixels = int64_t(1) << 21;   // HOST mode: pixels per staged tile
 constexpr int kDiagBlocks = 1024;
 constexpr int kSlots = 2;                           // double buffering
+constexpr size_t kStagger = 33 * 1024;              // see RasterEngine.STAGGER_BYTES
 }  // namespace
 
 struct mod16_ctx {
@@ -372,7 +373,9 @@ static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
     if (n == 0) return MOD16_OK;
     const int64_t tile = std::min<int64_t>(n, kTilePixels);
     // slab layout per slot: 14 drivers | 11 params | 8 outputs (T each) | class bytes
-    const size_t per_arr = (((size_t)tile * sizeof(T)) + 255) / 256 * 256;
+    // successive staged arrays are kStagger bytes apart on top of their size:
+    // power-of-two spacing makes the 16 concurrent streams collide in HBM
+    const size_t per_arr = (((size_t)tile * sizeof(T)) + 255) / 256 * 256 + kStagger;
     const size_t need = per_arr * (14 + 11 + 8) + (size_t)tile + 256;
     if (ctx->slab_bytes < need) {
         for (int s = 0; s < kSlots; ++s) {

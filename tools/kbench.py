@@ -25,7 +25,18 @@ def child(args):
     math = _lib.MATH_EXACT if args.math == 'exact' else _lib.MATH_FAST
     eng = RasterEngine(table, dtype=args.dtype, math=math)
     n = args.rows * 43200
-    if args.stagger:
+    if args.slab >= 0:
+        # experiment: every array carved out of ONE allocation, successive
+        # arrays offset by an extra `slab` bytes (physical placement control)
+        esz = 8 if args.dtype == 'float64' else 4
+        pad = (args.slab + 255) // 256 * 256
+        per = (n * esz + 4095) // 4096 * 4096 + pad
+        slab = torch.empty(16 * per + n + 4096, dtype=torch.uint8, device='cuda')
+        views = [slab[k * per:k * per + n * esz].view(eng.dtype) for k in range(16)]
+        drv, (day, night) = views[:14], views[14:]
+        cls = slab[16 * per:16 * per + n]
+        eng.synth(n, seed=16, out=(cls, drv))
+    elif args.stagger:
         # experiment: offset the arrays' base addresses against each other
         pad = args.stagger * 16 // 8
         bufs = [torch.empty(n + pad, dtype=eng.dtype, device='cuda') for _ in range(16)]
@@ -53,6 +64,7 @@ def main():
     ap.add_argument('--math', default='fast')
     ap.add_argument('--child', action='store_true')
     ap.add_argument('--stagger', type=int, default=0, help='bytes between successive array bases (mod allocation)')
+    ap.add_argument('--slab', type=int, default=-1, help='carve all arrays from one allocation with this extra offset (bytes)')
     ap.add_argument('libs', nargs='*')
     args = ap.parse_args()
     if args.child:
@@ -62,7 +74,7 @@ def main():
         env = dict(os.environ, MOD16_LIB=os.path.abspath(lib))
         subprocess.run([sys.executable, __file__, '--child', '--rows', str(args.rows),
                         '--launches', str(args.launches), '--rounds', str(args.rounds),
-                        '--dtype', args.dtype, '--math', args.math, '--stagger', str(args.stagger)], env=env, check=False)
+                        '--dtype', args.dtype, '--math', args.math, '--stagger', str(args.stagger), '--slab', str(args.slab)], env=env, check=False)
 
 
 if __name__ == '__main__':
