@@ -286,17 +286,23 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
     if (nbody) {
         EtArgs<T> b = a;
         b.n = nbody;
-        const int grid = grid_for(ctx, nbody / V);
-        if (dma && ddiag && nbody == a.n) {   // outputs reduced while still in registers
+        const int grid = dma ? (int)std::max<int64_t>(1, std::min<int64_t>(
+                                   (nbody / V + kDmaBlock - 1) / kDmaBlock, (int64_t)ctx->cus * ctx->grid_mult))
+                             : grid_for(ctx, nbody / V);
+        if (dma) {
+            // One production kernel: it always accumulates the per-block
+            // diagnostics partials while the outputs are in registers (~2 % of
+            // its VALU work; the variant without them compiles to 50-60 more
+            // VGPRs and runs slower); the final sum runs only when asked for.
             int rc = reserve_diag(ctx, grid);
             if (rc != MOD16_OK) return rc;
             b.diag_partial = ctx->diag_partial;
-            hipLaunchKernelGGL((et_kernel_dma<T, true, true>), dim3(grid), dim3(kBlock), 0, st, b);
-            hipLaunchKernelGGL(diag_final_fused_kernel, dim3(1), dim3(kBlock), 0, st,
-                               ctx->diag_partial, grid, a.n, ddiag);
-            fused_diag = true;
-        } else if (dma) {
-            hipLaunchKernelGGL((et_kernel_dma<T, true, false>), dim3(grid), dim3(kBlock), 0, st, b);
+            hipLaunchKernelGGL((et_kernel_dma<T, true, true>), dim3(grid), dim3(kDmaBlock), 0, st, b);
+            if (ddiag && nbody == a.n) {
+                hipLaunchKernelGGL(diag_final_fused_kernel, dim3(1), dim3(kFinalBlock), 0, st,
+                                   ctx->diag_partial, grid, a.n, ddiag);
+                fused_diag = true;
+            }
         } else {
             launch_variant<T, V>(b, lut, fast, sep, dense, grid, st);
         }

@@ -31,7 +31,7 @@ template <typename T> struct EtArgs {
     unsigned* status;
     uint32_t dense_drv;    // bit k set: driver k is a dense array, else a broadcast scalar
     uint32_t dense_par;
-    double* diag_partial;  // et_kernel_dma<.., DIAG>: [gridDim][8] per-block diagnostics
+    double* diag_partial;  // et_kernel_dma: [gridDim][8] per-block diagnostics
 };
 
 template <typename T, int V> struct Vec;
@@ -76,11 +76,8 @@ __device__ __forceinline__ void store_vec(T* __restrict__ p, int64_t i, const T 
 // parameters from the BPLUT in LDS by class code (else per-pixel / scalar
 // parameter inputs), FAST = strength-reduced arithmetic, SEP = also store the
 // six components, DENSE = every driver is a dense array (no broadcast checks).
-#ifndef MOD16_ET_WAVES
-#define MOD16_ET_WAVES 1
-#endif
 template <typename T, int V, bool LUT, bool FAST, bool SEP, bool DENSE>
-__global__ void __launch_bounds__(kBlock, MOD16_ET_WAVES) et_kernel(const EtArgs<T> a) {
+__global__ void __launch_bounds__(kBlock) et_kernel(const EtArgs<T> a) {
     // FAST always computes in float64 (float32 data are widened on load and
     // the result rounded once on store); EXACT computes in the data type, as
     // numpy does for the reference code.
@@ -174,9 +171,6 @@ __global__ void __launch_bounds__(kBlock, MOD16_ET_WAVES) et_kernel(const EtArgs
                 res[6][j] = (T)o.soil_n;
                 res[7][j] = (T)o.trans_n;
             }
-#ifdef MOD16_SCHED_BARRIER
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         }
 #pragma unroll
         for (int k = 0; k < (SEP ? 8 : 2); ++k)
@@ -197,8 +191,9 @@ __device__ __forceinline__ void diag_merge(double (&a)[kDiag], const double (&b)
     a[7] = (b[7] > a[7]) ? b[7] : a[7];
 }
 
+template <int BLOCK = kBlock>
 __device__ __forceinline__ void diag_block_reduce(double (&acc)[kDiag], double* out) {
-    __shared__ double sm[kBlock / 64][kDiag];
+    __shared__ double sm[BLOCK / 64][kDiag];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         double o[kDiag];
@@ -211,7 +206,7 @@ __device__ __forceinline__ void diag_block_reduce(double (&acc)[kDiag], double* 
         for (int k = 0; k < kDiag; ++k) sm[wave][k] = acc[k];
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kBlock / 64; ++w) {
+        for (int w = 1; w < BLOCK / 64; ++w) {
             double o[kDiag];
             for (int k = 0; k < kDiag; ++k) o[k] = sm[w][k];
             diag_merge(acc, o);
@@ -255,28 +250,32 @@ __global__ void __launch_bounds__(kBlock) diag_final_kernel(const double* partia
 // ---------------------------------------------------------------- LDS-DMA form
 // Production kernel for dense multi-class rasters (class raster + BPLUT, totals
 // only). Same arithmetic as et_kernel<.., LUT, FAST, !SEP, DENSE>; what differs
-// is how the drivers reach the registers. At ~200 VGPRs only two waves fit a
+// is how the drivers reach the registers. At ~170-200 VGPRs only two waves fit a
 // SIMD, too few to hide HBM latency behind other waves, and there is no room
-// for a second register set to prefetch into. So each wave owns a 15 KiB LDS
+// for a second register set to prefetch into. So each wave owns a 14.25 KiB LDS
 // slot and streams the NEXT iteration's 14 driver vectors (+ class bytes) into
 // it with global_load_lds (LDS-DMA, no VGPR destination) while it computes the
-// current one: issue -> compute(i) -> counted vmcnt -> ds_read_b128 -> issue ...
-// The slot is private to the wave that fills it, so no barrier is involved:
-// the wave's own counted s_waitcnt vmcnt orders its ds_reads behind its DMA.
-// Every byte is touched once, so both directions use the non-temporal policy
-// (nt): +3-4 % on the 14-read + 2-write stream mix (profiles/r01_probe_streams*).
-#ifndef MOD16_DMA_AUX
-#define MOD16_DMA_AUX 2      // cache-policy bits of the LDS-DMA loads (2 = nt)
-#endif
-#ifndef MOD16_PLAIN_STORE
-#define MOD16_NT_STORE 1
-#endif
+// current one: counted vmcnt -> ds_read_b128 x 14 -> issue next -> compute ->
+// store. The slot is private to the wave that fills it, so no barrier is
+// involved: the wave's own counted s_waitcnt vmcnt orders its ds_reads behind
+// its DMA. Addresses are SGPR chunk base + 32-bit lane offset (no per-array
+// 64-bit VALU add). Every byte is touched once, so both directions use the
+// non-temporal policy: +3-4 % on the 14-read + 2-write stream mix
+// (profiles/r01_probe_streams_hbm_roof.txt).
+//
+// The kernel also reduces its outputs into per-block diagnostics partials
+// (kDiag doubles per block, the fields of diag_partial_kernel) while they are
+// still in registers (DIAG), which saves the separate 16 B/pixel reduction
+// pass. Only DIAG = true is instantiated: without the accumulation hipcc's
+// schedule needs 50-60 more VGPRs and the kernel is slower. (Timing note:
+// identical binaries differ by ~3 % from process to process on one device,
+// bimodally -- compare variants over several processes, not one.)
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+constexpr int kDmaBlock = 256;       // threads per block (128/192/320 measured slower)
+constexpr int kDmaNt = 2;            // cache-policy bits of the LDS-DMA loads: nt
+constexpr int kChunkRun = 1;         // consecutive chunks per block before striding (4..64 measured: no gain)
 
-// DIAG: also reduce the outputs into per-block diagnostics partials (kDiag
-// doubles per block, same fields as diag_partial_kernel) while they are still in
-// registers, which saves the separate 16 B/pixel reduction pass.
 template <typename T, bool FAST, bool DIAG>
 __global__ void __launch_bounds__(kBlock) et_kernel_dma(const EtArgs<T> a) {
     constexpr int V = 16 / (int)sizeof(T);
@@ -295,35 +294,38 @@ __global__ void __launch_bounds__(kBlock) et_kernel_dma(const EtArgs<T> a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char* const ws = stage + wave * kSlot;
     const int64_t nvec = a.n / V;
-#ifndef MOD16_CHUNK_RUN
-#define MOD16_CHUNK_RUN 1    // consecutive 256-vector chunks a block takes before striding
-#endif
     // chunk c covers vectors [c * 256, (c + 1) * 256); block b takes chunks
     // (b * RUN + r) + it * gridDim * RUN, r = 0..RUN-1
     const int64_t nchunk = (nvec + kBlock - 1) / kBlock;
-    const int64_t cstride = (int64_t)gridDim.x * MOD16_CHUNK_RUN;
-    int64_t cbase = (int64_t)blockIdx.x * MOD16_CHUNK_RUN;
+    const int64_t cstride = (int64_t)gridDim.x * kChunkRun;
+    int64_t cbase = (int64_t)blockIdx.x * kChunkRun;
     int run = 0;
     auto vec_of = [&](int64_t cb, int r) { return (cb + r) * kBlock + threadIdx.x; };
+    // first element of a chunk: wave-uniform, so base + it stays in SGPRs and
+    // each access is SGPR base + 32-bit lane offset (no per-array 64-bit VALU add)
+    auto first_of = [&](int64_t cb, int r) { return (cb + r) * (int64_t)(kBlock * V); };
+    const unsigned lane_elem = threadIdx.x * (unsigned)V;
     auto advance = [&](int64_t& cb, int& r) {
-        if (++r == MOD16_CHUNK_RUN) { r = 0; cb += cstride; }
+        if (++r == kChunkRun) { r = 0; cb += cstride; }
     };
     int64_t v = vec_of(cbase, run);
-#define MOD16_VEND nvec
     double dsum_d = 0, dsum_n = 0, dmax_d = -__builtin_huge_val(), dmax_n = -__builtin_huge_val();
     unsigned nan_d = 0, nan_n = 0;   // wave-uniform NaN counts (ballot + popcount)
 
-    auto issue = [&](int64_t vv) {
+    auto issue = [&](int64_t first) {
 #pragma unroll
         for (int k = 0; k < 14; ++k)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.drv[k] + vv * V), (lptr_t)(ws + k * 1024),
-                                             16, 0, MOD16_DMA_AUX);
+            __builtin_amdgcn_global_load_lds((gptr_t)((a.drv[k] + first) + lane_elem),
+                                             (lptr_t)(ws + k * 1024), 16, 0, kDmaNt);
+        // sub-dword LDS-DMA lands one dword per lane (measured): read back at lane * 4
         if constexpr (V == 2)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.cls + vv * 2), (lptr_t)(ws + 14 * 1024), 2, 0, MOD16_DMA_AUX);
+            __builtin_amdgcn_global_load_lds((gptr_t)((a.cls + first) + lane_elem),
+                                             (lptr_t)(ws + 14 * 1024), 2, 0, kDmaNt);
         else
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.cls + vv * 4), (lptr_t)(ws + 14 * 1024), 4, 0, MOD16_DMA_AUX);
+            __builtin_amdgcn_global_load_lds((gptr_t)((a.cls + first) + lane_elem),
+                                             (lptr_t)(ws + 14 * 1024), 4, 0, kDmaNt);
     };
-    if (v < MOD16_VEND) issue(v);
+    if (v < nvec) issue(first_of(cbase, run));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first fill: nothing to overlap with
 #pragma nounroll
     for (; cbase + run < nchunk; ) {
@@ -377,7 +379,7 @@ __global__ void __launch_bounds__(kBlock) et_kernel_dma(const EtArgs<T> a) {
         int run_n = run;
         advance(cb_n, run_n);
         const int64_t vn = vec_of(cb_n, run_n);
-        if (vn < MOD16_VEND) issue(vn);
+        if (vn < nvec) issue(first_of(cb_n, run_n));
         asm volatile("" ::: "memory");
 
         if (v < nvec) {   // only the last chunk is ragged
@@ -425,13 +427,9 @@ __global__ void __launch_bounds__(kBlock) et_kernel_dma(const EtArgs<T> a) {
                     dmax_n = __builtin_fmax(dmax_n, g);
                 }
             }
-#ifdef MOD16_NT_STORE
-            __builtin_nontemporal_store(day, reinterpret_cast<VT*>(a.out[0] + v * V));
-            __builtin_nontemporal_store(night, reinterpret_cast<VT*>(a.out[1] + v * V));
-#else
-            *reinterpret_cast<VT*>(a.out[0] + v * V) = day;
-            *reinterpret_cast<VT*>(a.out[1] + v * V) = night;
-#endif
+            const int64_t first = first_of(cbase, run);
+            __builtin_nontemporal_store(day, reinterpret_cast<VT*>((a.out[0] + first) + lane_elem));
+            __builtin_nontemporal_store(night, reinterpret_cast<VT*>((a.out[1] + first) + lane_elem));
         }
         cbase = cb_n;
         run = run_n;
@@ -446,29 +444,46 @@ __global__ void __launch_bounds__(kBlock) et_kernel_dma(const EtArgs<T> a) {
     }
 }
 
-// Sum of the per-block partials of et_kernel_dma<.., DIAG> in block order;
-// n_valid = n - n_nan.
-__global__ void __launch_bounds__(kBlock) diag_final_fused_kernel(const double* partial,
-                                                                  int nblocks, int64_t n,
-                                                                  double* out) {
+// Sum of the per-block partials of et_kernel_dma, fixed order (thread
+// t adds partials t, t + 1024, ...; then a fixed wave / block tree);
+// n_valid = n - n_nan. 1024 threads keep the dependent-load chain short.
+constexpr int kFinalBlock = 1024;
+__global__ void __launch_bounds__(kFinalBlock) diag_final_fused_kernel(const double* partial,
+                                                                       int nblocks, int64_t n,
+                                                                       double* out) {
     double acc[kDiag] = {0, 0, 0, 0, 0, 0, -__builtin_huge_val(), -__builtin_huge_val()};
-    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+    for (int b = threadIdx.x; b < nblocks; b += kFinalBlock) {
         double o[kDiag];
+#pragma unroll
         for (int k = 0; k < kDiag; ++k) o[k] = partial[(int64_t)b * kDiag + k];
         diag_merge(acc, o);
     }
-    __shared__ double res[kDiag];
-    diag_block_reduce(acc, res);
+    __shared__ double sm[kFinalBlock / 64][kDiag];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double o[kDiag];
+#pragma unroll
+        for (int k = 0; k < kDiag; ++k) o[k] = __shfl_down(acc[k], off, 64);
+        diag_merge(acc, o);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0)
+        for (int k = 0; k < kDiag; ++k) sm[wave][k] = acc[k];
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[0] = res[0];
-        out[1] = res[1];
-        out[2] = (double)n - res[4];
-        out[3] = (double)n - res[5];
-        out[4] = res[4];
-        out[5] = res[5];
-        out[6] = res[6];
-        out[7] = res[7];
+        for (int w = 1; w < kFinalBlock / 64; ++w) {
+            double o[kDiag];
+            for (int k = 0; k < kDiag; ++k) o[k] = sm[w][k];
+            diag_merge(acc, o);
+        }
+        out[0] = acc[0];
+        out[1] = acc[1];
+        out[2] = (double)n - acc[4];
+        out[3] = (double)n - acc[5];
+        out[4] = acc[4];
+        out[5] = acc[5];
+        out[6] = acc[6];
+        out[7] = acc[7];
     }
 }
 

@@ -490,7 +490,7 @@ template <typename T>
 __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const ClassPar<T>& p,
                                                      const T* tb) {
     PixelOut<T> o;
-#ifdef MOD16_TRIVIAL_BODY   // experiment: memory pattern only, no arithmetic
+#ifdef MOD16_TRIVIAL_BODY   // measurement aid (-DMOD16_TRIVIAL_BODY): memory pattern only, no arithmetic
     o.canopy_d = x.lw_d + x.sw_d + x.alb + x.t_d + x.t_ann + x.vpd_d + x.pa;
     o.soil_d = p.beta; o.trans_d = x.fpar;
     o.canopy_n = x.lw_n + x.sw_n + x.t_n + x.tmin + x.vpd_n + x.lai;
