@@ -135,6 +135,28 @@ MOD16_API int mod16_et_f32(mod16_ctx* ctx, const uint8_t* cls,
                  void* stream);
 
 /*
+ * Forward run that also returns potential ET: as
+ * mod16_et_* (out_day / out_night may be NULL), plus pet_day / pet_night [n]
+ * in kg m-2 s-1 = wet-canopy evaporation + saturated-soil evaporation +
+ * unsaturated-soil evaporation without the soil-moisture constraint +
+ * Priestley-Taylor potential transpiration (reference README.md:404-424;
+ * MOD16.potential_soil_evaporation :449-544, MOD16.potential_transpiration
+ * :546-602 with alpha = 1.26, evaporation_wet_canopy :866-961).
+ */
+MOD16_API int mod16_et_pet_f64(mod16_ctx* ctx, const uint8_t* cls,
+                     const double* const* drivers, const int64_t* dstride,
+                     const double* const* params, const int64_t* pstride,
+                     int64_t n, double* out_day, double* out_night,
+                     double* pet_day, double* pet_night, unsigned flags,
+                     int where, void* stream);
+MOD16_API int mod16_et_pet_f32(mod16_ctx* ctx, const uint8_t* cls,
+                     const float* const* drivers, const int64_t* dstride,
+                     const float* const* params, const int64_t* pstride,
+                     int64_t n, float* out_day, float* out_night,
+                     float* pet_day, float* pet_night, unsigned flags,
+                     int where, void* stream);
+
+/*
  * Forward run and diagnostics in one pass, DEVICE pointers only: as
  * mod16_et_* with a class raster (BPLUT parameters) and both totals, plus the
  * diagnostics vector of mod16_reduce_diag_* written to ddiag (device, 8

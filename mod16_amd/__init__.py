@@ -83,7 +83,7 @@ def _marshal(values, shape, dtype):
     return keep, ptrs, strides
 
 
-def _forward(cls, drivers, params, separate, flags, device):
+def _forward(cls, drivers, params, separate, flags, device, pet=False):
     '''Shared host path of MOD16.evapotranspiration and
     evapotranspiration_raster: marshal numpy inputs, run mod16_et_* in HOST
     mode, shape the outputs as the reference does (mod16/__init__.py:789-793).
@@ -108,6 +108,19 @@ def _forward(cls, drivers, params, separate, flags, device):
         cptr = cls.ctypes.data
     else:
         keep_p, pptr, pstride = _marshal(params, shape, dtype)
+    if pet:
+        outs = [np.empty(shape, dtype) for _ in range(4)]
+        if n:
+            fn = ctx.lib.mod16_et_pet_f32 if dtype == np.float32 else ctx.lib.mod16_et_pet_f64
+            ctx.check(fn(
+                ctx.handle, cptr, _lib.ptr_array(dptr), _lib.i64_array(dstride),
+                _lib.ptr_array(pptr) if pptr is not None else None,
+                _lib.i64_array(pstride) if pstride is not None else None, n,
+                outs[0].ctypes.data, outs[1].ctypes.data, outs[2].ctypes.data,
+                outs[3].ctypes.data, int(flags), _lib.HOST, None))
+        if not shape:
+            outs = [o[()] for o in outs]
+        return tuple(outs)
     if separate:
         outs = [np.empty(shape, dtype) for _ in range(6)]
         day = night = None
@@ -269,6 +282,30 @@ class MOD16(object):
             None, drivers, self._param_values(), separate, self.math,
             self.device)
 
+
+    def evapotranspiration_and_pet(
+            self, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
+            sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
+            vpd_night, pressure, fpar, lai):
+        r'''
+        (Extension) ET and potential ET in one
+        pass: returns ``(day, night, pet_day, pet_night)`` [kg m-2 s-1].
+        Potential ET is the sum the reference's README defines (lines
+        404-424): wet-canopy evaporation + saturated-soil evaporation +
+        unsaturated-soil evaporation without the soil-moisture constraint +
+        ``MOD16.potential_transpiration`` (alpha = 1.26), i.e. with the
+        reference's own methods::
+
+            sat, unsat = MOD16.potential_soil_evaporation(...)
+            pet = evaporation_wet_canopy(...) + (max(sat, 0) + max(unsat, 0)) / lhv \
+                + MOD16.potential_transpiration(...) / lhv
+        '''
+        drivers = (
+            lw_net_day, lw_net_night, sw_rad_day, sw_rad_night, sw_albedo,
+            temp_day, temp_night, temp_annual, tmin, vpd_day, vpd_night,
+            pressure, fpar, lai)
+        return _forward(None, drivers, self._param_values(), False, self.math,
+                        self.device, pet=True)
 
     # ---- the rest of the reference's class surface, on the GPU as well
     #      (mod16_method_*: reference operation order, IEEE divide / pow)
@@ -465,7 +502,7 @@ def evapotranspiration_raster(
         bplut, cls, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
         sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
         vpd_night, pressure, fpar, lai, separate=False, beta=None,
-        math=_lib.MATH_FAST, device=0):
+        math=_lib.MATH_FAST, device=0, pet=False):
     r'''
     Forward run over a multi-class raster. Equivalent to the reference idiom
     (forward-run notebook, cell 32)::
@@ -489,6 +526,9 @@ def evapotranspiration_raster(
         (Optional) value for the ``beta`` column where the table has none
     separate : bool
         As in ``MOD16.evapotranspiration``
+    pet : bool
+        (Extension) True to return ``(day, night, pet_day, pet_night)``, see
+        ``MOD16.evapotranspiration_and_pet``
 
     Returns
     -------
@@ -508,4 +548,4 @@ def evapotranspiration_raster(
         lw_net_day, lw_net_night, sw_rad_day, sw_rad_night, sw_albedo,
         temp_day, temp_night, temp_annual, tmin, vpd_day, vpd_night,
         pressure, fpar, lai)
-    return _forward(cls, drivers, None, separate, math, device)
+    return _forward(cls, drivers, None, separate, math, device, pet=pet)

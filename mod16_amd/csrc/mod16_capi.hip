@@ -214,6 +214,14 @@ template <> struct VecOf<float> { static constexpr int v = 4; };
 template <typename T, int V>
 static void launch_variant(const EtArgs<T>& a, bool lut, bool fast, bool sep, bool dense,
                            int grid, hipStream_t st) {
+    if (a.out[8] || a.out[9]) {   // potential ET wanted: the generic all-outputs form
+#define MOD16_LAUNCH_PET(LUT, FAST) \
+    hipLaunchKernelGGL((et_kernel<T, V, LUT, FAST, true, false, true>), dim3(grid), dim3(kBlock), 0, st, a)
+        if (lut) { if (fast) MOD16_LAUNCH_PET(true, true); else MOD16_LAUNCH_PET(true, false); }
+        else     { if (fast) MOD16_LAUNCH_PET(false, true); else MOD16_LAUNCH_PET(false, false); }
+#undef MOD16_LAUNCH_PET
+        return;
+    }
 #define MOD16_LAUNCH(LUT, FAST, SEP, DENSE) \
     hipLaunchKernelGGL((et_kernel<T, V, LUT, FAST, SEP, DENSE>), dim3(grid), dim3(kBlock), 0, st, a)
     if (fast && V > 1) {
@@ -275,13 +283,13 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
     if (lut) chk(a.cls, V);
     else for (int k = 0; k < 11; ++k) if ((a.dense_par >> k) & 1u) chk(a.par[k], 16);
     bool sep = false;
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 10; ++k) {
         chk(a.out[k], 16);
         if (k >= 2 && a.out[k]) sep = true;
     }
     const bool dense = a.dense_drv == 0x3fffu;
     const int64_t nbody = aligned ? (a.n / V) * V : 0;
-    const bool dma = ctx->use_dma && lut && fast && !sep && dense && a.out[0] && a.out[1];
+    const bool dma = ctx->use_dma && lut && fast && !sep && dense && a.out[0] && a.out[1];   // sep covers PET too
     bool fused_diag = false;
     if (nbody) {
         EtArgs<T> b = a;
@@ -313,7 +321,7 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
         for (int k = 0; k < 14; ++k) if ((t.dense_drv >> k) & 1u) t.drv[k] += off;
         if (lut) t.cls += off;
         else for (int k = 0; k < 11; ++k) if ((t.dense_par >> k) & 1u) t.par[k] += off;
-        for (int k = 0; k < 8; ++k) if (t.out[k]) t.out[k] += off;
+        for (int k = 0; k < 10; ++k) if (t.out[k]) t.out[k] += off;
         t.n = a.n - off;
         launch_variant<T, 1>(t, lut, fast, sep, dense, grid_for(ctx, t.n), st);
     }
@@ -328,7 +336,8 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
 template <typename T>
 static int fill_args(mod16_ctx* ctx, EtArgs<T>& a, const uint8_t* cls, const T* const* drivers,
                      const int64_t* dstride, const T* const* params, const int64_t* pstride,
-                     int64_t n, T* out_day, T* out_night, T* const* out_sep) {
+                     int64_t n, T* out_day, T* out_night, T* const* out_sep,
+                     T* pet_day = nullptr, T* pet_night = nullptr) {
     if (!ctx) return MOD16_ERR_ARG;
     if (!drivers || !dstride || n < 0) return fail(ctx, MOD16_ERR_ARG, "mod16_et: NULL drivers/strides or n < 0");
     memset(&a, 0, sizeof a);
@@ -358,6 +367,9 @@ static int fill_args(mod16_ctx* ctx, EtArgs<T>& a, const uint8_t* cls, const T* 
             a.out[2 + k] = out_sep[k];
             any = any || out_sep[k];
         }
+    a.out[8] = pet_day;
+    a.out[9] = pet_night;
+    any = any || pet_day || pet_night;
     if (!any) return fail(ctx, MOD16_ERR_ARG, "mod16_et: no output array given");
     a.n = n;
     return MOD16_OK;
@@ -382,7 +394,7 @@ static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
     // successive staged arrays are kStagger bytes apart on top of their size:
     // power-of-two spacing makes the 16 concurrent streams collide in HBM
     const size_t per_arr = (((size_t)tile * sizeof(T)) + 255) / 256 * 256 + kStagger;
-    const size_t need = per_arr * (14 + 11 + 8) + (size_t)tile + 256;
+    const size_t need = per_arr * (14 + 11 + 10) + (size_t)tile + 256;
     if (ctx->slab_bytes < need) {
         for (int s = 0; s < kSlots; ++s) {
             if (ctx->slab[s]) HIPCHK(ctx, hipFree(ctx->slab[s]));
@@ -419,7 +431,7 @@ static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
             }
         }
         if (h.cls) {
-            uint8_t* dc = reinterpret_cast<uint8_t*>(base + per_arr * 33);
+            uint8_t* dc = reinterpret_cast<uint8_t*>(base + per_arr * 35);
             HIPCHK(ctx, hipMemcpyAsync(dc, h.cls + off, (size_t)m, hipMemcpyHostToDevice, st));
             d.cls = dc;
         } else {
@@ -434,10 +446,10 @@ static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
             }
         }
         auto out_at = [&](int k) { return reinterpret_cast<T*>(base + per_arr * (25 + k)); };
-        for (int k = 0; k < 8; ++k) d.out[k] = h.out[k] ? out_at(k) : nullptr;
+        for (int k = 0; k < 10; ++k) d.out[k] = h.out[k] ? out_at(k) : nullptr;
         int rc = launch_et<T>(ctx, d, flags, st);
         if (rc != MOD16_OK) return rc;
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < 10; ++k)
             if (h.out[k]) HIPCHK(ctx, hipMemcpyAsync(h.out[k] + off, d.out[k], sizeof(T) * m, hipMemcpyDeviceToHost, st));
     }
     for (int s = 0; s < kSlots; ++s) HIPCHK(ctx, hipStreamSynchronize(ctx->streams[s]));
@@ -448,9 +460,10 @@ template <typename T>
 static int et_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drivers,
                     const int64_t* dstride, const T* const* params, const int64_t* pstride,
                     int64_t n, T* out_day, T* out_night, T* const* out_sep, unsigned flags,
-                    int where, void* stream) {
+                    int where, void* stream, T* pet_day = nullptr, T* pet_night = nullptr) {
     EtArgs<T> a;
-    int rc = fill_args<T>(ctx, a, cls, drivers, dstride, params, pstride, n, out_day, out_night, out_sep);
+    int rc = fill_args<T>(ctx, a, cls, drivers, dstride, params, pstride, n, out_day, out_night,
+                          out_sep, pet_day, pet_night);
     if (rc != MOD16_OK) return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (where == MOD16_DEVICE) return launch_et<T>(ctx, a, flags, static_cast<hipStream_t>(stream));
@@ -498,6 +511,25 @@ extern "C" int mod16_et_diag_f32(mod16_ctx* ctx, const uint8_t* cls, const float
                                  const int64_t* dstride, int64_t n, float* out_day,
                                  float* out_night, unsigned flags, double* ddiag, void* stream) {
     return et_diag_entry<float>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, stream);
+}
+
+extern "C" int mod16_et_pet_f64(mod16_ctx* ctx, const uint8_t* cls, const double* const* drivers,
+                                const int64_t* dstride, const double* const* params,
+                                const int64_t* pstride, int64_t n, double* out_day,
+                                double* out_night, double* pet_day, double* pet_night,
+                                unsigned flags, int where, void* stream) {
+    if (ctx && !pet_day && !pet_night) return fail(ctx, MOD16_ERR_ARG, "mod16_et_pet: no PET output given");
+    return et_entry<double>(ctx, cls, drivers, dstride, params, pstride, n, out_day, out_night,
+                            nullptr, flags, where, stream, pet_day, pet_night);
+}
+extern "C" int mod16_et_pet_f32(mod16_ctx* ctx, const uint8_t* cls, const float* const* drivers,
+                                const int64_t* dstride, const float* const* params,
+                                const int64_t* pstride, int64_t n, float* out_day,
+                                float* out_night, float* pet_day, float* pet_night,
+                                unsigned flags, int where, void* stream) {
+    if (ctx && !pet_day && !pet_night) return fail(ctx, MOD16_ERR_ARG, "mod16_et_pet: no PET output given");
+    return et_entry<float>(ctx, cls, drivers, dstride, params, pstride, n, out_day, out_night,
+                           nullptr, flags, where, stream, pet_day, pet_night);
 }
 
 extern "C" int mod16_check_status(mod16_ctx* ctx, void* stream) {

@@ -26,7 +26,7 @@ template <typename T> struct EtArgs {
     const T* lut;          // device [MOD16_LUT_ROWS][kLutCols], EXACT arithmetic (type T)
     const double* lut64;   // the same table in float64, FAST arithmetic
     const double* tab;     // device exp/log tables, FastMath<double>::kTabDoubles values
-    T* out[8];             // day, night, then the 6 components (mod16_component)
+    T* out[10];            // day, night, the 6 components (mod16_component), PET day, night
     int64_t n;
     unsigned* status;
     uint32_t dense_drv;    // bit k set: driver k is a dense array, else a broadcast scalar
@@ -76,7 +76,7 @@ __device__ __forceinline__ void store_vec(T* __restrict__ p, int64_t i, const T 
 // parameters from the BPLUT in LDS by class code (else per-pixel / scalar
 // parameter inputs), FAST = strength-reduced arithmetic, SEP = also store the
 // six components, DENSE = every driver is a dense array (no broadcast checks).
-template <typename T, int V, bool LUT, bool FAST, bool SEP, bool DENSE>
+template <typename T, int V, bool LUT, bool FAST, bool SEP, bool DENSE, bool PET = false>
 __global__ void __launch_bounds__(kBlock) et_kernel(const EtArgs<T> a) {
     // FAST always computes in float64 (float32 data are widened on load and
     // the result rounded once on store); EXACT computes in the data type, as
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(kBlock) et_kernel(const EtArgs<T> a) {
             for (int k = 0; k < 11; ++k)
                 load_vec<T, V, false>(a.par[k], (a.dense_par >> k) & 1u, i, pin[k]);
         }
-        T res[8][V];
+        T res[10][V];
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             PixelIn<C> x = {(C)in[0][j], (C)in[1][j], (C)in[2][j], (C)in[3][j], (C)in[4][j],
@@ -158,8 +158,8 @@ __global__ void __launch_bounds__(kBlock) et_kernel(const EtArgs<T> a) {
                 if (FAST) p.derive();
             }
             PixelOut<C> o;
-            if constexpr (FAST) o = et_pixel_fast<double>(x, p, tab);
-            else o = et_pixel_exact<T>(x, p);
+            if constexpr (FAST) o = et_pixel_fast<double, PET>(x, p, tab);
+            else o = et_pixel_exact<T, PET>(x, p);
             // mod16/__init__.py:792: (canopy + soil) + transpiration
             res[0][j] = (T)((o.canopy_d + o.soil_d) + o.trans_d);
             res[1][j] = (T)((o.canopy_n + o.soil_n) + o.trans_n);
@@ -171,9 +171,13 @@ __global__ void __launch_bounds__(kBlock) et_kernel(const EtArgs<T> a) {
                 res[6][j] = (T)o.soil_n;
                 res[7][j] = (T)o.trans_n;
             }
+            if (PET) {
+                res[8][j] = (T)o.pet_d;
+                res[9][j] = (T)o.pet_n;
+            }
         }
 #pragma unroll
-        for (int k = 0; k < (SEP ? 8 : 2); ++k)
+        for (int k = 0; k < (PET ? 10 : (SEP ? 8 : 2)); ++k)
             if (a.out[k]) store_vec<T, V>(a.out[k], i, res[k]);
     }
 }

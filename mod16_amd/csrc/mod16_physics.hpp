@@ -41,7 +41,9 @@ template <typename T> struct ClassPar {
 
 template <typename T> struct PixelOut {
     T canopy_d, soil_d, trans_d, canopy_n, soil_n, trans_n;
+    T pet_d, pet_n;   // potential ET (only filled by the *_pet forms)
 };
+constexpr double kPriestleyTaylorAlpha = 1.26;   // mod16/__init__.py:550
 
 // Module constants, mod16/__init__.py:106-118, :869, :1157
 template <typename T> struct K {
@@ -259,7 +261,23 @@ __device__ __forceinline__ T transpiration_exact(const ClassPar<T>& p, T pa, T t
     return (g_canopy <= tiny) ? T(0) : tr / lhv;                  // :1258
 }
 
+// potential ET of one period from the reference's own component functions
+// (README.md:404-424): canopy + (sat + unsat, each clamped at 0 as in :858-861,
+// no moisture constraint) / lhv + potential_transpiration / lhv
 template <typename T>
+__device__ __forceinline__ T pet_exact(const ClassPar<T>& p, const PixelIn<T>& x, T t, T vpd,
+                                       T lw, T sw, T rad_soil, T canopy, T r_corr, T lhv, T rh,
+                                       T fw) {
+#pragma clang fp contract(off)
+    T sat, unsat;
+    pot_soil_exact(p, x.pa, t, vpd, x.fpar, rad_soil, r_corr, rh, fw, sat, unsat);
+    T e = (sat < T(0)) ? T(0) : sat;
+    e = e + ((unsat < T(0)) ? T(0) : unsat);
+    T ptr = pot_transpiration_exact(lw, sw, x.alb, x.pa, t, x.fpar, fw, T(kPriestleyTaylorAlpha));
+    return (canopy + e / lhv) + ptr / lhv;
+}
+
+template <typename T, bool PET = false>
 __device__ __forceinline__ PixelOut<T> et_pixel_exact(const PixelIn<T>& x, const ClassPar<T>& p) {
 #pragma clang fp contract(off)
     PixelOut<T> o;
@@ -276,6 +294,7 @@ __device__ __forceinline__ PixelOut<T> et_pixel_exact(const PixelIn<T>& x, const
         o.soil_d = soil_exact(p, x.pa, x.t_d, x.vpd_d, x.fpar, rs_d, rc, lhv, rh, fw);
         o.trans_d = transpiration_exact<T, true>(p, x.pa, x.t_d, x.vpd_d, x.lai, x.fpar, rad_c,
                                                  x.tmin, rc, lhv, rh, fw);
+        if (PET) o.pet_d = pet_exact(p, x, x.t_d, x.vpd_d, x.lw_d, x.sw_d, rs_d, o.canopy_d, rc, lhv, rh, fw);
     }
     {   // night
         T rad_net = x.sw_n * (T(1) - x.alb) + x.lw_n;
@@ -288,6 +307,7 @@ __device__ __forceinline__ PixelOut<T> et_pixel_exact(const PixelIn<T>& x, const
         o.soil_n = soil_exact(p, x.pa, x.t_n, x.vpd_n, x.fpar, rs_n, rc, lhv, rh, fw);
         o.trans_n = transpiration_exact<T, false>(p, x.pa, x.t_n, x.vpd_n, x.lai, x.fpar, rad_c,
                                                   x.tmin, rc, lhv, rh, fw);
+        if (PET) o.pet_n = pet_exact(p, x, x.t_n, x.vpd_n, x.lw_n, x.sw_n, rs_n, o.canopy_n, rc, lhv, rh, fw);
     }
     return o;
 }
@@ -394,11 +414,16 @@ template <typename T> struct PixelShared {
     bool lai_pos, lai_tiny;
 };
 
-template <typename T, bool DAY>
+// PET: also the potential ET of the period (reference README.md:404-424):
+// wet-canopy evaporation + saturated-soil evaporation + unsaturated-soil
+// evaporation without the soil-moisture constraint + Priestley-Taylor
+// potential transpiration (MOD16.potential_transpiration, :546-602), as a mass
+// flux like the other outputs.
+template <typename T, bool DAY, bool PET = false>
 __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<T>& p,
                                             const PixelShared<T>& sh, const T* tb, T t, T vpd,
                                             T rad_net, T rad_soil, T& canopy, T& soil,
-                                            T& trans) {
+                                            T& trans, T* pet = nullptr) {
     typedef FastMath<T> M;
     const T tiny = K<T>::tiny;
     const T cp = K<T>::cp;
@@ -409,7 +434,11 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     T esat = __builtin_fma(T(1e3 * 0.6108),
                            M::exp_tab((T(17.27) * tc) * M::rcp(tc + T(237.3)), tb), tc * T(0));
     T avp = esat - vpd;
-    T rh = avp * M::rcp(esat);
+    // rh drives the thresholds (rh < 0.7, 1 - fwet > 0), so this one quotient is
+    // finished like an IEEE division (residual correction): x / x = 1 exactly
+    T resat = M::rcp(esat);
+    T rh = avp * resat;
+    rh = __builtin_fma(__builtin_fma(-rh, esat, avp), resat, rh);
     rh = (avp < T(0)) ? T(0) : ((rh > T(1)) ? T(1) : rh);
     T rh2 = rh * rh;
     T fwet = (rh < T(0.7)) ? T(0) : rh2 * rh2;
@@ -459,6 +488,15 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
         // clamps of :858-861 fire exactly when q < 0 (NaN falls through)
         T e = q * __builtin_fma(omw, pw, fwet);
         soil = (q < T(0)) ? T(0) : e;
+        if (PET) {
+            // sat + unsat without the rh^(vpd/beta) factor
+            // two products as in :541-543, so that inf * 0 is NaN as it is there
+            T pot_soil = (q < T(0)) ? T(0) : __builtin_fma(q, fwet, q * omw);
+            // alpha s A_c (1 - fwet) / (s + gamma) / lhv, gamma lhv = k_p
+            T pot_tr = (T(kPriestleyTaylorAlpha) * (s * (x.fpar * rad_net)) * omw) *
+                       M::rcp(slhv + sh.k_p);
+            *pet = (canopy + pot_soil) + pot_tr;
+        }
     }
     // -- transpiration, :1152-1258, with g_canopy = P1 / S1 kept as a ratio
     {
@@ -486,7 +524,7 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     }
 }
 
-template <typename T>
+template <typename T, bool PET = false>
 __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const ClassPar<T>& p,
                                                      const T* tb) {
     PixelOut<T> o;
@@ -526,9 +564,11 @@ __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const 
     T tm = x.tmin - K<T>::t0;
     sh.m_tmin = (tm >= p.tmin_open) ? T(1)
                 : ((tm < p.tmin_close) ? T(0) : (tm - p.tmin_close) * p.inv_dtmin);
-    period_fast<T, true>(x, p, sh, tb, x.t_d, x.vpd_d, a_d, rs_d, o.canopy_d, o.soil_d, o.trans_d);
+    period_fast<T, true, PET>(x, p, sh, tb, x.t_d, x.vpd_d, a_d, rs_d, o.canopy_d, o.soil_d, o.trans_d,
+                              &o.pet_d);
     T rn_n = __builtin_fma(x.sw_n, sh.oma, x.lw_n);
-    period_fast<T, false>(x, p, sh, tb, x.t_n, x.vpd_n, rn_n, rs_n, o.canopy_n, o.soil_n, o.trans_n);
+    period_fast<T, false, PET>(x, p, sh, tb, x.t_n, x.vpd_n, rn_n, rs_n, o.canopy_n, o.soil_n, o.trans_n,
+                               &o.pet_n);
     return o;
 }
 

@@ -300,6 +300,53 @@ def evapotranspiration(p, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
     return tuple(out)
 
 
+def potential_transpiration(lw_net, sw_rad, sw_albedo, pressure, temp_k, vpd,
+                            fpar, rh=None, f_wet=None, alpha=1.26):
+    """MOD16.potential_transpiration, mod16/__init__.py:546-602 [W m-2]"""
+    if rh is None:
+        rh = rhumidity(temp_k, vpd)
+    if f_wet is None:
+        f_wet = wet_fraction(rh)
+    rad_net = sw_rad * (1 - sw_albedo) + lw_net
+    rad_canopy = fpar * rad_net
+    s = svp_slope(temp_k)
+    gamma = psychrometric_constant(pressure, temp_k)
+    return (alpha * (s * rad_canopy) * (1 - f_wet)) / (s + gamma)
+
+
+def potential_et(p, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
+                 sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
+                 vpd_night, pressure, fpar, lai):
+    """Potential ET (day, night) [kg m-2 s-1] as the reference's README defines
+    it (README.md:404-424), composed from the reference's own component
+    methods: wet-canopy evaporation (:866) + potential soil evaporation of the
+    saturated and unsaturated fractions (:449, clamped at 0 as :858-861 does,
+    no soil-moisture constraint) + potential transpiration (:546)."""
+    with np.errstate(all='ignore'):
+        rad_soil = radiation_soil(
+            p, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night, sw_albedo,
+            temp_day, temp_night, temp_annual, fpar)
+        out = []
+        for i, (temp_k, vpd, sw_rad, lw_net) in enumerate((
+                (temp_day, vpd_day, sw_rad_day, lw_net_day),
+                (temp_night, vpd_night, sw_rad_night, lw_net_night))):
+            rad_canopy = fpar * (sw_rad * (1 - sw_albedo) + lw_net)
+            rh = rhumidity(temp_k, vpd)
+            fw = wet_fraction(rh)
+            lhv = latent_heat_vaporization(temp_k)
+            r_corr = r_correction(pressure, temp_k)
+            canopy = evaporation_wet_canopy(
+                p, pressure, temp_k, vpd, lai, fpar, rad_canopy, lhv, rh, fw)
+            sat, unsat = potential_soil_evaporation(
+                p, pressure, temp_k, vpd, fpar, rad_soil[i], r_corr, lhv, rh, fw)
+            e = np.where(sat < 0, 0, sat)
+            e = e + np.where(unsat < 0, 0, unsat)
+            ptr = potential_transpiration(
+                lw_net, sw_rad, sw_albedo, pressure, temp_k, vpd, fpar, rh, fw)
+            out.append((canopy + e / lhv) + ptr / lhv)
+    return tuple(out)
+
+
 def gather_params(bplut, cls):
     """The multi-class idiom of the reference's forward-run notebook (cell 32):
     ``params_dict[key][pft_map]`` per parameter. ``bplut`` maps the 11

@@ -247,3 +247,31 @@ def test_conus_tile_1200(m16, golden, mode):
     print('\n[1200x1200 %s] max rel err: components %.2e day %.2e night %.2e'
           % (mode, max(errs), e_d, e_n))
     assert max(e_d, e_n) < 1e-5   # the north_star bar
+
+
+@pytest.mark.parametrize('mode', ['fast', 'exact'])
+def test_potential_et(m16, golden, mode):
+    """PET from the same pass. The checker composes
+    the reference's own component methods (oracle.potential_et); the reference
+    vectors of those components are pinned in f6 / test_gpu_methods."""
+    f = golden('f3_random64_f64')
+    bplut = {k: f['table'][:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    drv = list(f['drivers'])
+    day, night, pet_d, pet_n = m16.evapotranspiration_raster(
+        f['table'], f['cls'], *drv, pet=True, math=math_flag(m16, mode))
+    assert_parity(day, f['day'], RTOL[mode], 'day')
+    assert_parity(night, f['night'], RTOL[mode], 'night')
+    want = oracle.potential_et(oracle.gather_params(bplut, f['cls']), *drv)
+    assert_parity(pet_d, want[0], RTOL[mode], 'pet day')
+    assert_parity(pet_n, want[1], RTOL[mode], 'pet night')
+    # scalar parameters + edge cases through the class method
+    g = golden('f4_edge_cases')
+    p = dict(zip(oracle.PARAM_NAMES, g['params']))
+    m = m16.MOD16(p)
+    m.math = math_flag(m16, mode)
+    res = m.evapotranspiration_and_pet(*list(g['drivers']))
+    want = oracle.potential_et(p, *list(g['drivers']))
+    for i, case in enumerate(g['names']):
+        assert_parity(res[2][i:i + 1], want[0][i:i + 1], RTOL[mode], 'pet day ' + str(case))
+        assert_parity(res[3][i:i + 1], want[1][i:i + 1], RTOL[mode], 'pet night ' + str(case))
+    assert_parity(res[0], g['day'], RTOL[mode], 'day')

@@ -166,3 +166,16 @@ def test_f7_static_calibration_path(golden):
     g = golden('f1_tests_scalars')
     et = oracle.et_static(list(g['params']), *list(g['drivers']))
     assert round(float(et), 2) == 40.94 and float(et) == float(g['et_static'])
+
+
+def test_potential_transpiration_known_form(golden):
+    """oracle.potential_transpiration against the closed form of the reference
+    (mod16/__init__.py:546-602) evaluated with the reference's f6 vectors."""
+    f = golden('f6_submethods')
+    (lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_a, tmin, vpd_d, vpd_n, pa, fpar, lai) = \
+        list(f['drivers'])
+    rh = f['rhumidity']
+    fw = np.where(rh < 0.7, 0, np.power(rh, 4))
+    want = (1.26 * (f['svp_slope'] * (fpar * (sw_d * (1 - alb) + lw_d))) * (1 - fw)) / \
+        (f['svp_slope'] + f['psychrometric_constant'])
+    same(oracle.potential_transpiration(lw_d, sw_d, alb, pa, t_d, vpd_d, fpar), want)
