@@ -157,6 +157,42 @@ MOD16_API int mod16_et_pet_f32(mod16_ctx* ctx, const uint8_t* cls,
                      int where, void* stream);
 
 /*
+ * Forward run on raw drivers: the pre-processing the
+ * reference does in front of the forward run (mod16/calibration.py:380-423) is
+ * folded into the pixel kernel --
+ *   vpd_day   = MOD16.vpd(qv10m_day, ps_day, temp_day)            :604-644
+ *   vpd_night = max(MOD16.vpd(qv10m_night, ps_night, temp_night), 0)   calibration.py:398-401
+ *   pressure  = MOD16.air_pressure(elevation)                      :414-447
+ *   fpar = fpar_pct / 100, lai = lai_x10 / 10                      calibration.py:422-423
+ * with fPAR / LAI given as the MODIS uint8 encodings (codes >= 249 = fill ->
+ * NaN). `raw` holds 14 arrays in enum mod16_raw_driver order (rstride 0/1 as
+ * elsewhere); cls + BPLUT give the parameters. Outputs: out_day / out_night
+ * [kg m-2 s-1] and/or, with `day_hours` (hours of daylight per pixel, hstride
+ * 0/1), out_total8 = (day h + night (24 - h)) * 8 * 3600 [kg m-2 (8 d)-1], the
+ * MOD16A2 unit (reference tests/verification/verify2.py:113-115).
+ */
+#define MOD16_N_RAW_DRIVERS 14
+enum mod16_raw_driver {
+    MOD16_RAW_LW_NET_DAY = 0, MOD16_RAW_LW_NET_NIGHT, MOD16_RAW_SW_RAD_DAY,
+    MOD16_RAW_SW_RAD_NIGHT, MOD16_RAW_SW_ALBEDO, MOD16_RAW_TEMP_DAY,
+    MOD16_RAW_TEMP_NIGHT, MOD16_RAW_TEMP_ANNUAL, MOD16_RAW_TMIN,
+    MOD16_RAW_QV10M_DAY, MOD16_RAW_QV10M_NIGHT, MOD16_RAW_PS_DAY,
+    MOD16_RAW_PS_NIGHT, MOD16_RAW_ELEVATION
+};
+MOD16_API int mod16_et_raw_f64(mod16_ctx* ctx, const uint8_t* cls,
+                     const double* const* raw, const int64_t* rstride,
+                     const uint8_t* fpar_pct, const uint8_t* lai_x10,
+                     const double* day_hours, int64_t hstride, int64_t n,
+                     double* out_day, double* out_night, double* out_total8,
+                     unsigned flags, int where, void* stream);
+MOD16_API int mod16_et_raw_f32(mod16_ctx* ctx, const uint8_t* cls,
+                     const float* const* raw, const int64_t* rstride,
+                     const uint8_t* fpar_pct, const uint8_t* lai_x10,
+                     const float* day_hours, int64_t hstride, int64_t n,
+                     float* out_day, float* out_night, float* out_total8,
+                     unsigned flags, int where, void* stream);
+
+/*
  * Forward run and diagnostics in one pass, DEVICE pointers only: as
  * mod16_et_* with a class raster (BPLUT parameters) and both totals, plus the
  * diagnostics vector of mod16_reduce_diag_* written to ddiag (device, 8

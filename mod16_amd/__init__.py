@@ -549,3 +549,62 @@ def evapotranspiration_raster(
         temp_day, temp_night, temp_annual, tmin, vpd_day, vpd_night,
         pressure, fpar, lai)
     return _forward(cls, drivers, None, separate, math, device, pet=pet)
+
+
+def evapotranspiration_raw(
+        bplut, cls, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
+        sw_albedo, temp_day, temp_night, temp_annual, tmin, qv10m_day,
+        qv10m_night, ps_day, ps_night, elevation, fpar_pct, lai_x10,
+        day_hours=None, beta=None, math=_lib.MATH_FAST, device=0):
+    r'''
+    (Extension) Forward run on raw drivers: the
+    pre-processing the reference does in front of ``evapotranspiration()``
+    (mod16/calibration.py:380-423) is folded into the kernel --
+
+    - ``vpd_day = MOD16.vpd(qv10m_day, ps_day, temp_day)``,
+      ``vpd_night = max(MOD16.vpd(qv10m_night, ps_night, temp_night), 0)``;
+    - ``pressure = MOD16.air_pressure(elevation)``;
+    - ``fpar = fpar_pct / 100``, ``lai = lai_x10 / 10`` with ``fpar_pct`` and
+      ``lai_x10`` as uint8 rasters in the MODIS encodings (codes >= 249 are
+      fill values and give NaN).
+
+    Returns ``(day, night)`` [kg m-2 s-1] or, with ``day_hours`` (hours of
+    daylight), ``(day, night, total8)`` where ``total8 = (day h + night (24 -
+    h)) * 8 * 3600`` [kg m-2 (8 d)-1], the MOD16A2 unit
+    (tests/verification/verify2.py:113-115).
+    '''
+    from .utils import bplut_table
+    table = bplut_table(bplut, beta=beta) if isinstance(bplut, dict) else np.array(bplut, np.float64)
+    if not isinstance(bplut, dict) and beta is not None:
+        fill = np.isnan(table[:, 10]) & ~np.isnan(table[:, 0])
+        table[fill, 10] = beta
+    ctx = _lib.context(device)
+    ctx.set_bplut(table)
+    raw = [lw_net_day, lw_net_night, sw_rad_day, sw_rad_night, sw_albedo,
+           temp_day, temp_night, temp_annual, tmin, qv10m_day, qv10m_night,
+           ps_day, ps_night, elevation]
+    hours = [day_hours] if day_hours is not None else []
+    dtype = _result_dtype(raw + hours)
+    u8 = [np.asarray(v) for v in (cls, fpar_pct, lai_x10)]
+    shape = np.broadcast_shapes(*[np.shape(v) for v in raw + hours + u8])
+    n = int(np.prod(shape, dtype=np.int64))
+    keep, rptr, rstr = _marshal(raw, shape, dtype)
+    hkeep, hptr, hstr = _marshal(hours, shape, dtype) if hours else (None, [None], [0])
+    bytes_ = []
+    for a in u8:
+        if a.dtype != np.uint8:
+            if a.size and (a.min() < 0 or a.max() > 255):
+                raise IndexError('uint8 raster value outside [0, 255]')
+            a = a.astype(np.uint8)
+        bytes_.append(np.ascontiguousarray(np.broadcast_to(a, shape)))
+    outs = [np.empty(shape, dtype) for _ in range(3 if hours else 2)]
+    if n:
+        fn = ctx.lib.mod16_et_raw_f32 if dtype == np.float32 else ctx.lib.mod16_et_raw_f64
+        ctx.check(fn(
+            ctx.handle, bytes_[0].ctypes.data, _lib.ptr_array(rptr), _lib.i64_array(rstr),
+            bytes_[1].ctypes.data, bytes_[2].ctypes.data, hptr[0], int(hstr[0]), n,
+            outs[0].ctypes.data, outs[1].ctypes.data,
+            outs[2].ctypes.data if hours else None, int(math), _lib.HOST, None))
+    if not shape:
+        outs = [o[()] for o in outs]
+    return tuple(outs)

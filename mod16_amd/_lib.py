@@ -64,6 +64,14 @@ PROTOTYPES = {
     'mod16_et_pet_f32': (C.c_int, [
         C.c_void_p, C.c_void_p, _PP, _I64P, _PP, _I64P, C.c_int64, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_void_p]),
+    'mod16_et_raw_f64': (C.c_int, [
+        C.c_void_p, C.c_void_p, _PP, _I64P, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint,
+        C.c_int, C.c_void_p]),
+    'mod16_et_raw_f32': (C.c_int, [
+        C.c_void_p, C.c_void_p, _PP, _I64P, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint,
+        C.c_int, C.c_void_p]),
     'mod16_et_diag_f64': (C.c_int, [
         C.c_void_p, C.c_void_p, _PP, _I64P, C.c_int64, C.c_void_p, C.c_void_p,
         C.c_uint, C.c_void_p, C.c_void_p]),

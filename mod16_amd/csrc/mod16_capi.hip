@@ -700,6 +700,131 @@ extern "C" int mod16_method_f32(mod16_ctx* ctx, int method, const float* const* 
     return method_entry<float>(ctx, method, in, istride, params, pstride, n, out, alpha, where, stream);
 }
 
+// ----------------------------------------------------- raw drivers (N1)
+template <typename T>
+static int raw_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* raw,
+                     const int64_t* rstride, const uint8_t* fpar_pct, const uint8_t* lai_x10,
+                     const T* day_hours, int64_t hstride, int64_t n, T* out_day, T* out_night,
+                     T* out_total8, unsigned flags, int where, void* stream) {
+    if (!ctx) return MOD16_ERR_ARG;
+    if (!cls || !raw || !rstride || !fpar_pct || !lai_x10 || n < 0)
+        return fail(ctx, MOD16_ERR_ARG, "mod16_et_raw: NULL argument or n < 0");
+    if (!out_day && !out_night && !out_total8) return fail(ctx, MOD16_ERR_ARG, "mod16_et_raw: no output array given");
+    if (out_total8 && !day_hours) return fail(ctx, MOD16_ERR_ARG, "mod16_et_raw: out_total8 needs day_hours");
+    if (!ctx->have_lut) return fail(ctx, MOD16_ERR_NO_BPLUT, "mod16_et_raw: mod16_set_bplut_f64 was not called");
+    RawArgs<T> a;
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < 14; ++k) {
+        if (!raw[k]) return fail(ctx, MOD16_ERR_ARG, "mod16_et_raw: NULL driver array");
+        a.drv[k] = raw[k];
+        if (rstride[k]) a.dense_drv |= 1u << k;
+    }
+    a.fpar_pct = fpar_pct;
+    a.lai_x10 = lai_x10;
+    a.cls = cls;
+    a.day_hours = out_total8 ? day_hours : nullptr;
+    a.dense_hours = hstride ? 1u : 0u;
+    a.out[0] = out_day;
+    a.out[1] = out_night;
+    a.out[2] = out_total8;
+    a.n = n;
+    a.lut = ctx_lut<T>(ctx);
+    a.lut64 = ctx->lut64;
+    a.tab = ctx->tab64;
+    a.status = ctx->status;
+    if (n == 0) return MOD16_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const bool fast = (flags & MOD16_MATH_EXACT) == 0;
+    auto launch = [&](const RawArgs<T>& d, hipStream_t st) {
+        const int grid = grid_for(ctx, d.n);
+        if (fast) hipLaunchKernelGGL((et_raw_kernel<T, true>), dim3(grid), dim3(kBlock), 0, st, d);
+        else hipLaunchKernelGGL((et_raw_kernel<T, false>), dim3(grid), dim3(kBlock), 0, st, d);
+    };
+    if (where == MOD16_DEVICE) {
+        launch(a, static_cast<hipStream_t>(stream));
+        HIPCHK(ctx, hipGetLastError());
+        return MOD16_OK;
+    }
+    if (where != MOD16_HOST) return fail(ctx, MOD16_ERR_ARG, "mod16_et_raw: bad `where`");
+    // HOST: one slab, tile by tile
+    const int64_t tile = std::min<int64_t>(n, kTilePixels);
+    const size_t per_arr = (((size_t)tile * sizeof(T)) + 255) / 256 * 256 + kStagger;
+    const size_t need = per_arr * (14 + 1 + 3) + 3 * ((size_t)tile + 256) + 256;
+    if (ctx->slab_bytes < need) {
+        for (int s = 0; s < kSlots; ++s) {
+            if (ctx->slab[s]) HIPCHK(ctx, hipFree(ctx->slab[s]));
+            ctx->slab[s] = nullptr;
+        }
+        ctx->slab_bytes = 0;
+        for (int s = 0; s < kSlots; ++s) HIPCHK(ctx, hipMalloc(&ctx->slab[s], need));
+        ctx->slab_bytes = need;
+    }
+    if (!ctx->streams[0]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking));
+    hipStream_t st = ctx->streams[0];
+    T hs[16];
+    for (int k = 0; k < 14; ++k) hs[k] = ((a.dense_drv >> k) & 1u) ? T(0) : a.drv[k][0];
+    hs[14] = (a.day_hours && !a.dense_hours) ? a.day_hours[0] : T(0);
+    HIPCHK(ctx, hipMemcpy(ctx->scalars, hs, sizeof(T) * 15, hipMemcpyHostToDevice));
+    const T* dscal = static_cast<const T*>(ctx->scalars);
+    char* base = static_cast<char*>(ctx->slab[0]);
+    uint8_t* bytes = reinterpret_cast<uint8_t*>(base + per_arr * 18);
+    const size_t per_b = ((size_t)tile + 255) / 256 * 256;
+    for (int64_t off = 0; off < n; off += tile) {
+        const int64_t m = std::min(tile, n - off);
+        RawArgs<T> d = a;
+        d.n = m;
+        for (int k = 0; k < 14; ++k) {
+            if ((a.dense_drv >> k) & 1u) {
+                T* dp = reinterpret_cast<T*>(base + per_arr * k);
+                HIPCHK(ctx, hipMemcpyAsync(dp, a.drv[k] + off, sizeof(T) * m, hipMemcpyHostToDevice, st));
+                d.drv[k] = dp;
+            } else {
+                d.drv[k] = dscal + k;
+            }
+        }
+        if (a.day_hours) {
+            if (a.dense_hours) {
+                T* dp = reinterpret_cast<T*>(base + per_arr * 14);
+                HIPCHK(ctx, hipMemcpyAsync(dp, a.day_hours + off, sizeof(T) * m, hipMemcpyHostToDevice, st));
+                d.day_hours = dp;
+            } else {
+                d.day_hours = dscal + 14;
+            }
+        }
+        const uint8_t* hb[3] = {a.fpar_pct, a.lai_x10, a.cls};
+        const uint8_t** db[3] = {&d.fpar_pct, &d.lai_x10, &d.cls};
+        for (int k = 0; k < 3; ++k) {
+            uint8_t* dp = bytes + per_b * k;
+            HIPCHK(ctx, hipMemcpyAsync(dp, hb[k] + off, (size_t)m, hipMemcpyHostToDevice, st));
+            *db[k] = dp;
+        }
+        for (int k = 0; k < 3; ++k) d.out[k] = a.out[k] ? reinterpret_cast<T*>(base + per_arr * (15 + k)) : nullptr;
+        launch(d, st);
+        HIPCHK(ctx, hipGetLastError());
+        for (int k = 0; k < 3; ++k)
+            if (a.out[k]) HIPCHK(ctx, hipMemcpyAsync(a.out[k] + off, d.out[k], sizeof(T) * m, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+    }
+    return read_status(ctx, st);
+}
+
+extern "C" int mod16_et_raw_f64(mod16_ctx* ctx, const uint8_t* cls, const double* const* raw,
+                                const int64_t* rstride, const uint8_t* fpar_pct,
+                                const uint8_t* lai_x10, const double* day_hours, int64_t hstride,
+                                int64_t n, double* out_day, double* out_night, double* out_total8,
+                                unsigned flags, int where, void* stream) {
+    return raw_entry<double>(ctx, cls, raw, rstride, fpar_pct, lai_x10, day_hours, hstride, n,
+                             out_day, out_night, out_total8, flags, where, stream);
+}
+extern "C" int mod16_et_raw_f32(mod16_ctx* ctx, const uint8_t* cls, const float* const* raw,
+                                const int64_t* rstride, const uint8_t* fpar_pct,
+                                const uint8_t* lai_x10, const float* day_hours, int64_t hstride,
+                                int64_t n, float* out_day, float* out_night, float* out_total8,
+                                unsigned flags, int where, void* stream) {
+    return raw_entry<float>(ctx, cls, raw, rstride, fpar_pct, lai_x10, day_hours, hstride, n,
+                            out_day, out_night, out_total8, flags, where, stream);
+}
+
 // ------------------------------------------- vectorised calibration path (N2)
 template <typename T>
 static int static_entry(mod16_ctx* ctx, const T* const* drivers, const int64_t* dstride,

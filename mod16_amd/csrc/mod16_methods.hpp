@@ -190,4 +190,70 @@ __global__ void __launch_bounds__(kBlock) static_kernel(const StaticArgs<T> a) {
     }
 }
 
+// ---- forward run on raw drivers
+template <typename T> struct RawArgs {
+    const T* drv[14];         // enum mod16_raw_driver order
+    const uint8_t* fpar_pct;  // fPAR in percent
+    const uint8_t* lai_x10;   // LAI x 10
+    const uint8_t* cls;
+    const T* day_hours;       // optional: hours of daylight -> 8-day total output
+    const T* lut;
+    const double* lut64;
+    const double* tab;
+    T* out[3];                // day, night, 8-day total [kg m-2 (8 d)-1]
+    int64_t n;
+    unsigned* status;
+    uint32_t dense_drv;
+    uint32_t dense_hours;
+};
+
+template <typename T, bool FAST>
+__global__ void __launch_bounds__(kBlock) et_raw_kernel(const RawArgs<T> a) {
+    typedef typename std::conditional<FAST, double, T>::type C;
+    constexpr int kTab = FAST ? FastMath<double>::kTabDoubles : 1;
+    __shared__ C lut[MOD16_LUT_ROWS * kLutCols];
+    __shared__ __attribute__((aligned(16))) double tab[kTab];
+    for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) {
+        if constexpr (FAST) lut[i] = a.lut64[i];
+        else lut[i] = a.lut[i];
+    }
+    if (FAST)
+        for (int i = threadIdx.x; i < kTab; i += kBlock) tab[i] = a.tab[i];
+    __syncthreads();
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += step) {
+        auto d = [&](int k) { return (C)(((a.dense_drv >> k) & 1u) ? a.drv[k][i] : a.drv[k][0]); };
+        RawIn<C> r = {d(0), d(1), d(2), d(3), d(4), d(5), d(6), d(7), d(8), d(9), d(10), d(11),
+                      d(12), d(13), a.fpar_pct[i], a.lai_x10[i]};
+        unsigned c = a.cls[i];
+        if (c >= 13u) {
+            atomicOr(a.status, kStatusClassRange);
+            c = 13u;
+        }
+        const C* l = lut + c;
+        ClassPar<C> p;
+        p.tmin_close = l[0 * kLutCols]; p.tmin_open = l[1 * kLutCols];
+        p.vpd_open = l[2 * kLutCols]; p.vpd_close = l[3 * kLutCols];
+        p.gl_sh = l[4 * kLutCols]; p.gl_wv = l[5 * kLutCols];
+        p.g_cut = l[6 * kLutCols]; p.csl = l[7 * kLutCols];
+        p.rbl_min = l[8 * kLutCols]; p.rbl_max = l[9 * kLutCols];
+        p.beta = l[10 * kLutCols];
+        p.inv_dtmin = l[11 * kLutCols]; p.inv_dvpd = l[12 * kLutCols];
+        p.rbl_slope = l[13 * kLutCols]; p.inv_beta = l[14 * kLutCols];
+        PixelOut<C> o;
+        if constexpr (FAST) o = et_pixel_fast<double>(raw_to_pixel_fast(r, tab), p, tab);
+        else o = et_pixel_exact<T>(raw_to_pixel_exact<T>(r), p);
+        C day = (o.canopy_d + o.soil_d) + o.trans_d;
+        C night = (o.canopy_n + o.soil_n) + o.trans_n;
+        if (a.out[0]) a.out[0][i] = (T)day;
+        if (a.out[1]) a.out[1][i] = (T)night;
+        if (a.out[2]) {   // tests/verification/verify2.py:113-115
+#pragma clang fp contract(off)
+            C h = (C)((a.dense_hours & 1u) ? a.day_hours[i] : a.day_hours[0]);
+            a.out[2][i] = (T)((day * h * C(8) * C(60) * C(60)) +
+                              (night * (C(24) - h) * C(8) * C(60) * C(60)));
+        }
+    }
+}
+
 }  // namespace mod16

@@ -572,4 +572,58 @@ __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const 
     return o;
 }
 
+// ================================================================ raw drivers
+// the driver pre-processing the reference does in
+// front of the forward run (mod16/calibration.py:380-423) folded into the
+// pixel function: VPD from 10-m specific humidity and surface pressure
+// (MOD16.vpd :604-644; the night value clamped at 0, calibration.py:401),
+// air pressure from elevation (MOD16.air_pressure :414-447), fPAR in percent
+// and LAI x 10 as the MODIS uint8 encodings (calibration.py:422-423; codes
+// >= 249 are the MOD15 fill values -> NaN).
+template <typename T> struct RawIn {
+    T lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_ann, tmin, qv_d, qv_n, ps_d, ps_n, elev;
+    unsigned fpar_pct, lai_x10;
+};
+
+template <typename T> __device__ __forceinline__ PixelIn<T> raw_to_pixel_exact(const RawIn<T>& r) {
+#pragma clang fp contract(off)
+    PixelIn<T> x;
+    x.lw_d = r.lw_d; x.lw_n = r.lw_n; x.sw_d = r.sw_d; x.sw_n = r.sw_n; x.alb = r.alb;
+    x.t_d = r.t_d; x.t_n = r.t_n; x.t_ann = r.t_ann; x.tmin = r.tmin;
+    x.vpd_d = vpd_exact(r.qv_d, r.ps_d, r.t_d);
+    T vn = vpd_exact(r.qv_n, r.ps_n, r.t_n);
+    x.vpd_n = (vn < T(0)) ? T(0) : vn;
+    x.pa = air_pressure_exact(r.elev);
+    const T nan = __builtin_nan("");
+    x.fpar = (r.fpar_pct >= 249u) ? nan : T(r.fpar_pct) / T(100);
+    x.lai = (r.lai_x10 >= 249u) ? nan : T(r.lai_x10) / T(10);
+    return x;
+}
+
+__device__ __forceinline__ PixelIn<double> raw_to_pixel_fast(const RawIn<double>& r,
+                                                             const double* tb) {
+    typedef FastMath<double> M;
+    PixelIn<double> x;
+    x.lw_d = r.lw_d; x.lw_n = r.lw_n; x.sw_d = r.sw_d; x.sw_n = r.sw_n; x.alb = r.alb;
+    x.t_d = r.t_d; x.t_n = r.t_n; x.t_ann = r.t_ann; x.tmin = r.tmin;
+    auto vpd = [&](double qv, double ps, double t) {
+        double tc = t - 273.15;
+        double avp = (qv * ps) * M::rcp(0.622 + 0.379 * qv);
+        double sv = __builtin_fma(610.7, M::exp_tab((17.38 * tc) * M::rcp(239.0 + tc), tb), tc * 0.0);
+        return sv - avp;
+    };
+    x.vpd_d = vpd(r.qv_d, r.ps_d, r.t_d);
+    double vn = vpd(r.qv_n, r.ps_n, r.t_n);
+    x.vpd_n = (vn < 0.0) ? 0.0 : vn;
+    // 101325 (1 - 0.0065 z / 288.15)^5.2559 ; the ratio is in (0, 1.2] on Earth
+    double ratio = __builtin_fma(r.elev, -0.0065 / 288.15, 1.0);
+    x.pa = 101325.0 * M::exp_tab(
+        (9.80665 / (0.0065 * (8.3143 / 28.9644e-3))) * M::log_tab(ratio, tb), tb);
+    x.pa = (ratio == ratio) ? x.pa : ratio;      // log_tab's integer path drops a NaN
+    const double nan = __builtin_nan("");
+    x.fpar = (r.fpar_pct >= 249u) ? nan : (double)r.fpar_pct * 0.01;
+    x.lai = (r.lai_x10 >= 249u) ? nan : (double)r.lai_x10 * 0.1;
+    return x;
+}
+
 }  // namespace mod16

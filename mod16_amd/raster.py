@@ -214,6 +214,42 @@ class RasterEngine(object):
         compute.wait_stream(ingest)
         return diag, day, night
 
+    def run_raw(self, cls, raw, fpar_pct, lai_x10, day_hours=None, out_day=None,
+                out_night=None, out_total8=None):
+        '''Forward run on raw drivers held on the device (``mod16_et_raw_*``,
+        see ``mod16_amd.evapotranspiration_raw``): ``raw`` = 14 tensors in
+        ``mod16_raw_driver`` order, ``fpar_pct`` / ``lai_x10`` uint8 tensors.
+        Returns ``(day, night)`` or, with ``day_hours``, ``(day, night,
+        total8)``; outputs are allocated unless given.'''
+        torch = _torch()
+        n = cls.numel()
+        keep, rptr, rstr = self._marshal_drivers(raw, n)
+        hptr, hstr = None, 0
+        if day_hours is not None:
+            if isinstance(day_hours, torch.Tensor) and day_hours.numel() != 1:
+                hptr, hstr = self._check_tensor(day_hours, self.dtype, n, 'day_hours'), 1
+            else:
+                hkeep = torch.as_tensor(day_hours, dtype=self.dtype).reshape(1).to(self._dev())
+                keep.append(hkeep)
+                hptr = hkeep.data_ptr()
+        if out_day is None and out_night is None and out_total8 is None:
+            out_day, out_night = self.empty(n, 2)
+            if day_hours is not None:
+                out_total8 = self.empty(n, 1)[0]
+        ptr = lambda t, what: self._check_tensor(t, self.dtype, n, what) if t is not None else None
+        fn = self.ctx.lib.mod16_et_raw_f32 if self.np_dtype == np.float32 \
+            else self.ctx.lib.mod16_et_raw_f64
+        self.ctx.check(fn(
+            self.ctx.handle, self._check_tensor(cls, torch.uint8, n, 'cls'),
+            _lib.ptr_array(rptr), _lib.i64_array(rstr),
+            self._check_tensor(fpar_pct, torch.uint8, n, 'fpar_pct'),
+            self._check_tensor(lai_x10, torch.uint8, n, 'lai_x10'), hptr, hstr, n,
+            ptr(out_day, 'out_day'), ptr(out_night, 'out_night'), ptr(out_total8, 'out_total8'),
+            int(self.math), _lib.DEVICE, self._stream()))
+        if day_hours is not None:
+            return out_day, out_night, out_total8
+        return out_day, out_night
+
     def bind(self, cls, drivers, out_day, out_night, diag):
         '''Pre-marshal one ``run(..., diag=diag)`` call and return a function
         that enqueues it on the then-current stream with a single library call

@@ -347,6 +347,43 @@ def potential_et(p, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
     return tuple(out)
 
 
+def vpd_from_humidity(qv10m, pressure, tmean):
+    """MOD16.vpd, mod16/__init__.py:604-644 (its own SVP constants)"""
+    temp_c = tmean - 273.15
+    avp = (qv10m * pressure) / (0.622 + (0.379 * qv10m))
+    sv = 610.7 * np.exp((17.38 * temp_c) / (239 + temp_c))
+    return sv - avp
+
+
+def air_pressure(elevation_m):
+    """MOD16.air_pressure, mod16/__init__.py:414-447"""
+    rate = 9.80665 / (0.0065 * (8.3143 / 28.9644e-3))
+    temp_ratio = 1 - ((0.0065 * elevation_m) / 288.15)
+    return 101325.0 * np.power(temp_ratio, rate)
+
+
+def evapotranspiration_raw(bplut, cls, raw, fpar_pct, lai_x10, day_hours=None):
+    """Forward run on raw drivers: the reference's pre-processing
+    (mod16/calibration.py:380-423) followed by the instance path; with
+    ``day_hours`` also the 8-day total of tests/verification/verify2.py:113-115.
+    ``raw`` = the 14 arrays in mod16_raw_driver order."""
+    (lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_a, tmin, qv_d, qv_n, ps_d, ps_n, elev) = raw
+    with np.errstate(all='ignore'):
+        vpd_d = vpd_from_humidity(qv_d, ps_d, t_d)
+        vpd_n = vpd_from_humidity(qv_n, ps_n, t_n)
+        vpd_n = np.where(vpd_n < 0, 0, vpd_n)
+        pa = air_pressure(elev)
+        fpar = np.where(fpar_pct >= 249, np.nan, np.asarray(fpar_pct, t_d.dtype)) / 100
+        lai = np.where(lai_x10 >= 249, np.nan, np.asarray(lai_x10, t_d.dtype)) / 10
+        day, night = evapotranspiration_raster(
+            bplut, cls, lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_a, tmin, vpd_d, vpd_n, pa,
+            fpar, lai)
+        if day_hours is None:
+            return day, night
+        total = ((day * day_hours * 8 * 60 * 60) + (night * (24 - day_hours) * 8 * 60 * 60))
+    return day, night, total
+
+
 def gather_params(bplut, cls):
     """The multi-class idiom of the reference's forward-run notebook (cell 32):
     ``params_dict[key][pft_map]`` per parameter. ``bplut`` maps the 11

@@ -17,6 +17,7 @@ Usage (build container only):  python tests/golden/make_golden.py
 import os
 import sys
 import tempfile
+import warnings
 
 import numpy as np
 
@@ -271,6 +272,43 @@ def main():
         drivers=np.stack(drv7), day=day7, night=night7, et=et7,
         r_corr_day=rcl[0], r_corr_night=rcl[1], day_rcorr=dayr, night_rcorr=nightr,
         tmin_cold=drv_cold[8], day_cold=dayc, night_cold=nightc)
+
+    # ---- F8: raw drivers through the reference's own pre-processing
+    #      (mod16/calibration.py:380-423: MOD16.vpd, night VPD clamp,
+    #      MOD16.air_pressure, fPAR / 100, LAI / 10) and its forward run, plus
+    #      the 8-day product unit of tests/verification/verify2.py:113-115
+    rng = np.random.default_rng(8)
+    shp = (48, 50)
+    cls8, drv8 = synth.drivers(shp, seed=8, special=False)
+    qv_d, qv_n = rng.uniform(0.001, 0.02, shp), rng.uniform(0.001, 0.02, shp)
+    ps_d, ps_n = rng.uniform(70000, 101340, shp), rng.uniform(70000, 101340, shp)
+    elev = rng.uniform(-50, 3500, shp)
+    fpar_pct = rng.integers(0, 101, shp).astype(np.uint8)
+    lai_x10 = rng.integers(0, 71, shp).astype(np.uint8)
+    fpar_pct[0, :4] = (249, 250, 255, 0)
+    lai_x10[1, :4] = (249, 253, 255, 0)
+    hours = rng.uniform(8, 16, shp)
+    (lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_a, tmin8) = drv8[:9]
+    vpd_d = MOD16.vpd(qv_d, ps_d, t_d)
+    vpd_n = MOD16.vpd(qv_n, ps_n, t_n)
+    vpd_n = np.where(vpd_n < 0, 0, vpd_n)
+    pa8 = MOD16.air_pressure(elev)
+    fpar8 = np.where(fpar_pct >= 249, np.nan, fpar_pct.astype(np.float64))
+    lai8 = np.where(lai_x10 >= 249, np.nan, lai_x10.astype(np.float64))
+    fpar8 /= 100
+    lai8 /= 10
+    m8 = MOD16({k: bplut[k][cls8] for k in names})
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        day8, night8 = m8.evapotranspiration(
+            lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_a, tmin8, vpd_d, vpd_n, pa8, fpar8, lai8)
+    total8 = ((day8 * hours * 8 * 60 * 60) + (night8 * (24 - hours) * 8 * 60 * 60))
+    np.savez_compressed(
+        os.path.join(HERE, 'f8_raw_drivers.npz'), cls=cls8, table=table,
+        raw=np.stack([lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_a, tmin8, qv_d, qv_n, ps_d,
+                      ps_n, elev]),
+        fpar_pct=fpar_pct, lai_x10=lai_x10, day_hours=hours, vpd_day=vpd_d, vpd_night=vpd_n,
+        pressure=pa8, day=day8, night=night8, total8=total8)
 
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith('.npz'):

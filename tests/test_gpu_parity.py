@@ -275,3 +275,30 @@ def test_potential_et(m16, golden, mode):
         assert_parity(res[2][i:i + 1], want[0][i:i + 1], RTOL[mode], 'pet day ' + str(case))
         assert_parity(res[3][i:i + 1], want[1][i:i + 1], RTOL[mode], 'pet night ' + str(case))
     assert_parity(res[0], g['day'], RTOL[mode], 'day')
+
+
+@pytest.mark.parametrize('mode', ['fast', 'exact'])
+def test_raw_driver_forward_run(m16, golden, mode):
+    """raw reanalysis fields and uint8 fPAR / LAI in,
+    ET out, against the reference's own pre-processing + forward run (f8)."""
+    f = golden('f8_raw_drivers')
+    raw = list(f['raw'])
+    res = m16.evapotranspiration_raw(
+        f['table'], f['cls'], *raw, f['fpar_pct'], f['lai_x10'],
+        day_hours=f['day_hours'], math=math_flag(m16, mode))
+    assert res[0].shape == (48, 50)
+    assert_parity(res[0], f['day'], RTOL[mode], 'day')
+    assert_parity(res[1], f['night'], RTOL[mode], 'night')
+    assert_parity(res[2], f['total8'], RTOL[mode], 'total8')
+    day, night = m16.evapotranspiration_raw(
+        f['table'], f['cls'], *raw, f['fpar_pct'], f['lai_x10'], math=math_flag(m16, mode))
+    assert np.array_equal(day, res[0], equal_nan=True)
+    # scalar raw drivers broadcast like everywhere else
+    raw2 = list(raw)
+    raw2[13] = 350.0
+    d2, _ = m16.evapotranspiration_raw(
+        f['table'], f['cls'], *raw2, f['fpar_pct'], f['lai_x10'], math=math_flag(m16, mode))
+    bplut = {k: f['table'][:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    raw2[13] = np.full((48, 50), 350.0)
+    w2, _ = oracle.evapotranspiration_raw(bplut, f['cls'], raw2, f['fpar_pct'], f['lai_x10'])
+    assert_parity(d2, w2, RTOL[mode], 'scalar elevation')

@@ -179,3 +179,19 @@ def test_potential_transpiration_known_form(golden):
     want = (1.26 * (f['svp_slope'] * (fpar * (sw_d * (1 - alb) + lw_d))) * (1 - fw)) / \
         (f['svp_slope'] + f['psychrometric_constant'])
     same(oracle.potential_transpiration(lw_d, sw_d, alb, pa, t_d, vpd_d, fpar), want)
+
+
+def test_f8_raw_driver_preprocessing(golden):
+    """N1: the reference's pre-processing (MOD16.vpd, MOD16.air_pressure, fPAR /
+    100, LAI / 10) + forward run + 8-day unit, bit for bit."""
+    f = golden('f8_raw_drivers')
+    raw = list(f['raw'])
+    same(oracle.vpd_from_humidity(raw[9], raw[11], raw[5]), f['vpd_day'])
+    same(oracle.air_pressure(raw[13]), f['pressure'])
+    bplut = {k: f['table'][:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    day, night, total = oracle.evapotranspiration_raw(
+        bplut, f['cls'], raw, f['fpar_pct'], f['lai_x10'], f['day_hours'])
+    same(day, f['day'])
+    same(night, f['night'])
+    same(total, f['total8'])
+    assert np.isnan(f['day'][0, 1]) and np.isnan(f['night'][1, 1])     # fill codes
