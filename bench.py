@@ -35,7 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md)
-PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r01c_pmc_hbm_traffic.json')
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r01f_pmc_hbm_traffic.json')
 TILE = (1200, 1200)           # BASELINE.json configs[1], the CPU sample unit
 SEED = 16
 
