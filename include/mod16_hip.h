@@ -126,7 +126,9 @@ MOD16_API int mod16_et_f64(mod16_ctx* ctx, const uint8_t* cls,
                  double* const* out_sep, unsigned flags, int where,
                  void* stream);
 
-/* float32 variant: same meaning, float32 data and float32 arithmetic */
+/* float32 data: MOD16_MATH_FAST widens to float64 on load, computes in float64 and
+ * rounds once on store; MOD16_MATH_EXACT keeps float32 arithmetic in the reference's
+ * operation order (what numpy does for the reference on float32 inputs) */
 MOD16_API int mod16_et_f32(mod16_ctx* ctx, const uint8_t* cls,
                  const float* const* drivers, const int64_t* dstride,
                  const float* const* params, const int64_t* pstride,
