@@ -224,3 +224,20 @@ def test_bound_launch_equals_run(env):
     assert torch.equal(d1, d2)
     assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(day))
     assert torch.equal(torch.nan_to_num(b), torch.nan_to_num(night))
+
+
+def test_unaligned_device_pointers_take_the_scalar_path(env):
+    """Tensors that start 8 bytes into an allocation are not 16-byte aligned:
+    the library must fall back to the scalar-access kernel, same results."""
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table)
+    n = 100001
+    cls, drv = eng.synth(n + 1, seed=4)
+    want_d, want_n = eng.run(cls[1:].clone(), [d[1:].clone() for d in drv])
+    day = torch.empty(n + 1, dtype=torch.float64, device='cuda')
+    night = torch.empty(n + 1, dtype=torch.float64, device='cuda')
+    got_d, got_n = eng.run(cls[1:], [d[1:] for d in drv], day[1:], night[1:])
+    eng.check()
+    assert drv[0][1:].data_ptr() % 16 == 8
+    assert torch.equal(torch.nan_to_num(got_d), torch.nan_to_num(want_d))
+    assert torch.equal(torch.nan_to_num(got_n), torch.nan_to_num(want_n))
