@@ -15,7 +15,6 @@
 namespace mod16 {
 
 template <typename T> struct ExactMath {
-    static __device__ __forceinline__ T div(T a, T b) { return a / b; }
     static __device__ __forceinline__ T exp(T x);
     static __device__ __forceinline__ T pow(T x, T y);
 };
@@ -36,15 +35,6 @@ template <> struct FastMath<double> {
         T e = __builtin_fma(-x, r, 1.0);
         return __builtin_fma(r, e, r);
     }
-    // Newton steps make NaN out of rcp(0) = inf and rcp(inf) = 0; this form
-    // keeps the IEEE results 1/0 = inf, 1/inf = 0 where a mask depends on them.
-    static __device__ __forceinline__ T rcp_safe(T x) {
-        T r0 = __builtin_amdgcn_rcp(x);
-        T e = __builtin_fma(-x, r0, 1.0);
-        T r1 = __builtin_fma(r0, e, r0);
-        return (r1 == r1) ? r1 : r0;
-    }
-    static __device__ __forceinline__ T div(T a, T b) { return a * rcp(b); }
 
     // x^(-7/4) for the r_corr term (mod16/__init__.py:771). Seed y = x^(-1/4)
     // from v_rsq_f64 + v_sqrt_f64 (relative error <= 5.3e-8, measured seeds
