@@ -83,6 +83,13 @@ def cpu_baseline(max_workers):
                        'sample': '%d workers x %d tiles of 1200x1200' % (cores, reps),
                        'wall_s': wall}
     out['global_grid_seconds_1core'] = 43200 * 21600 / out['value']
+    try:
+        with open('/proc/cpuinfo') as f:
+            models = [l.split(':', 1)[1].strip() for l in f if l.startswith('model name')]
+        out['cpu_model'] = models[0] if models else None
+        out['host_logical_cpus'] = os.cpu_count()
+    except OSError:
+        pass
     return out
 
 
@@ -198,23 +205,30 @@ def main():
     parity = None
     if rank == 0 and not args.no_parity:
         from oracle import mod16_oracle as oracle
+        # 1200 x 1200-pixel samples of this band (start, two inside, end), inputs
+        # AND outputs copied back; the oracle runs on exactly those input bits
         m = min(n, TILE[0] * TILE[1])
-        h_cls = cls[:m].cpu().numpy()
-        h_drv = [d[:m].cpu().numpy() for d in drv]
-        # float32 data: the kernel widens, computes in float64 and rounds once,
-        # so the checker is the float64 oracle on the widened inputs
+        starts = sorted(set([0, (n // 3) // 4 * 4, (2 * n // 3) // 4 * 4, n - m]))
         bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
-        want = oracle.evapotranspiration_raster(
-            bplut, h_cls, *[d.astype(np.float64) for d in h_drv])
-        want = [w.astype(h_drv[0].dtype) for w in want]
         worst, masks = 0.0, True
-        for got, ref in ((day[:m].cpu().numpy(), want[0]), (night[:m].cpu().numpy(), want[1])):
-            masks = masks and bool(np.array_equal(np.isnan(got), np.isnan(ref))
-                                   and np.array_equal(got == 0, ref == 0))
-            ok = np.isfinite(ref) & (ref != 0)
-            worst = max(worst, float(np.max(np.abs(got[ok].astype(np.float64) - ref[ok]) / np.abs(ref[ok]))))
-        parity = {'pixels': int(m), 'max_rel_err': worst, 'masks_equal': masks,
-                  'rtol_north_star': 1e-5, 'against': 'numpy oracle on the same input bits'}
+        for s0 in starts:
+            h_cls = cls[s0:s0 + m].cpu().numpy()
+            h_drv = [d[s0:s0 + m].cpu().numpy() for d in drv]
+            # float32 data: the kernel widens, computes in float64 and rounds
+            # once, so the checker is the float64 oracle on the widened inputs
+            want = oracle.evapotranspiration_raster(
+                bplut, h_cls, *[d.astype(np.float64) for d in h_drv])
+            want = [w.astype(h_drv[0].dtype) for w in want]
+            for got, ref in ((day[s0:s0 + m].cpu().numpy(), want[0]),
+                             (night[s0:s0 + m].cpu().numpy(), want[1])):
+                masks = masks and bool(np.array_equal(np.isnan(got), np.isnan(ref))
+                                       and np.array_equal(got == 0, ref == 0))
+                ok = np.isfinite(ref) & (ref != 0)
+                worst = max(worst, float(np.max(
+                    np.abs(got[ok].astype(np.float64) - ref[ok]) / np.abs(ref[ok]))))
+        parity = {'pixels': int(m * len(starts)), 'tiles': len(starts), 'max_rel_err': worst,
+                  'masks_equal': masks, 'rtol_north_star': 1e-5,
+                  'against': 'numpy oracle on the same input bits'}
     if not args.no_parity and args.math == 'fast':
         # every pixel of the band: the production kernel against the kernel that
         # keeps the reference's operation order (IEEE divide / pow), on the device

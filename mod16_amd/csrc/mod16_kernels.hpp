@@ -278,7 +278,10 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int kDmaBlock = 256;       // threads per block (128/192/320 measured slower)
 constexpr int kDmaNt = 2;            // cache-policy bits of the LDS-DMA loads: nt
-constexpr int kChunkRun = 1;         // consecutive chunks per block before striding (4..64 measured: no gain)
+#ifndef MOD16_CHUNK_RUN
+#define MOD16_CHUNK_RUN 1
+#endif
+constexpr int kChunkRun = MOD16_CHUNK_RUN;   // consecutive chunks per block before striding
 
 template <typename T, bool FAST, bool DIAG>
 __global__ void __launch_bounds__(kBlock) et_kernel_dma(const EtArgs<T> a) {
