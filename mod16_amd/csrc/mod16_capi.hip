@@ -30,6 +30,9 @@ struct mod16_ctx {
     int cus = 256;
     int grid_mult = 64;              // blocks per CU in the grid-stride launch (measured best)
     bool use_dma = true;             // LDS-DMA prefetch form of the production kernel
+    int use_dyn = 1;                 // dynamic run claiming (MOD16_DYN=0: static grid-stride)
+    unsigned long long* dyn_counters = nullptr;   // ring of ticket counters, 128 B apart
+    int dyn_next = 0;
     bool have_lut = false;
     double* lut64 = nullptr;     // device [MOD16_LUT_ROWS][kLutCols]
     float* lut32 = nullptr;
@@ -104,6 +107,7 @@ extern "C" int mod16_destroy(mod16_ctx* ctx) {
     if (ctx->lut64) (void)hipFree(ctx->lut64);
     if (ctx->lut32) (void)hipFree(ctx->lut32);
     if (ctx->tab64) (void)hipFree(ctx->tab64);
+    if (ctx->dyn_counters) (void)hipFree(ctx->dyn_counters);
     if (ctx->status) (void)hipFree(ctx->status);
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     if (ctx->static_flag) (void)hipFree(ctx->static_flag);
@@ -134,6 +138,8 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
         ctx->cus = prop.multiProcessorCount;
         if (const char* g = getenv("MOD16_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(g));
         if (const char* g = getenv("MOD16_NO_DMA")) ctx->use_dma = atoi(g) == 0;
+        if (const char* g = getenv("MOD16_DYN")) ctx->use_dyn = atoi(g);
+        HIPCHK(ctx, hipMalloc(&ctx->dyn_counters, 64 * 128));
         const size_t nlut = MOD16_LUT_ROWS * kLutCols;
         HIPCHK(ctx, hipMalloc(&ctx->lut64, nlut * sizeof(double)));
         HIPCHK(ctx, hipMalloc(&ctx->lut32, nlut * sizeof(float)));
@@ -305,11 +311,43 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
             int rc = reserve_diag(ctx, grid);
             if (rc != MOD16_OK) return rc;
             b.diag_partial = ctx->diag_partial;
+            if (ctx->use_dyn) {
+                // persistent waves, runs handed out through a ticket counter; the
+                // diagnostics partials are per run (schedule-independent)
+                unsigned long long* ctr = ctx->dyn_counters + 16 * (ctx->dyn_next++ % 64);
+                HIPCHK(ctx, hipMemsetAsync(ctr, 0, sizeof(unsigned long long), st));
+                b.dyn_counter = ctr;
+                const int64_t npiece = (nbody / V + 63) / 64;
+                const int64_t nruns = (npiece + kDynRun - 1) / kDynRun;
+                const int dgrid = (int)std::max<int64_t>(1, std::min<int64_t>(
+                    (nruns + (kBlock / 64) - 1) / (kBlock / 64), (int64_t)ctx->cus * 2));
+                constexpr int kStage = 1024;
+                rc = reserve_diag(ctx, nruns + kStage);
+                if (rc != MOD16_OK) return rc;
+                b.diag_partial = ctx->diag_partial;
+                hipLaunchKernelGGL((et_kernel_dyn<T, true, true>), dim3(dgrid), dim3(kDmaBlock), 0, st, b);
+                if (ddiag && nbody == a.n) {
+                    const double* fin = ctx->diag_partial;
+                    int64_t count = nruns;
+                    if (count > 4 * kStage) {   // two-level: 1024 fixed slices, then one block
+                        double* stage = ctx->diag_partial + nruns * kDiag;
+                        const int64_t per = (count + kStage - 1) / kStage;
+                        hipLaunchKernelGGL(diag_stage_kernel, dim3(kStage), dim3(kBlock), 0, st,
+                                           fin, count, per, stage);
+                        fin = stage;
+                        count = (count + per - 1) / per;
+                    }
+                    hipLaunchKernelGGL(diag_final_fused_kernel, dim3(1), dim3(kFinalBlock), 0, st,
+                                       fin, (int)count, a.n, ddiag);
+                    fused_diag = true;
+                }
+            } else {
             hipLaunchKernelGGL((et_kernel_dma<T, true, true>), dim3(grid), dim3(kDmaBlock), 0, st, b);
             if (ddiag && nbody == a.n) {
                 hipLaunchKernelGGL(diag_final_fused_kernel, dim3(1), dim3(kFinalBlock), 0, st,
                                    ctx->diag_partial, grid, a.n, ddiag);
                 fused_diag = true;
+            }
             }
         } else {
             launch_variant<T, V>(b, lut, fast, sep, dense, grid, st);

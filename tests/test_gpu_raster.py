@@ -117,6 +117,30 @@ def test_diagnostics_fused_standalone_numpy(env):
         assert torch.equal(fused, again)
 
 
+def test_diagnostics_are_schedule_independent_at_size(env):
+    """The production kernel hands runs of pixels to whichever wave is ready;
+    its diagnostics are accumulated per run and summed in fixed order, so
+    repeated launches must agree bit for bit even with many more runs than
+    waves (here ~36000 runs for 2048 waves)."""
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table)
+    n = 1700 * 43200
+    cls, drv, day, night = eng.alloc_raster(n)
+    eng.synth(n, seed=11, out=(cls, drv))
+    vecs = []
+    for _ in range(4):
+        d = torch.zeros(8, dtype=torch.float64, device='cuda')
+        eng.run(cls, drv, day, night, diag=d)
+        vecs.append(d)
+    alone = eng.diagnostics(day, night)
+    eng.check()
+    for d in vecs[1:]:
+        assert torch.equal(vecs[0], d)
+    got, ref = vecs[0].cpu().numpy(), alone.cpu().numpy()
+    np.testing.assert_allclose(got[:2], ref[:2], rtol=1e-12)
+    assert np.array_equal(got[2:], ref[2:])
+
+
 def test_deferred_class_range_error(env):
     torch, RasterEngine, table = env
     eng = RasterEngine(table)
