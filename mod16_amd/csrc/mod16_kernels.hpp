@@ -494,7 +494,14 @@ __global__ void __launch_bounds__(kBlock) et_kernel_dyn(const EtArgs<T> a) {
     unsigned long long ticket = 0;
     int run = 0;
     auto vec_of = [&](int64_t cb, int r) { return (cb + r) * 64 + lane; };
-    auto first_of = [&](int64_t cb, int r) { return (cb + r) * (int64_t)(64 * V); };
+    // first element of a piece; readfirstlane pins it to SGPRs (the claimed run
+    // index arrives through a VGPR), so every access is SGPR base + lane offset
+    auto first_of = [&](int64_t cb, int r) {
+        const int64_t f = (cb + r) * (int64_t)(64 * V);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)f);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)f >> 32));
+        return (int64_t)(((unsigned long long)hi << 32) | lo);
+    };
     const unsigned lane_elem = (unsigned)lane * (unsigned)V;
     auto advance = [&](int64_t& cb, int& r) {
         if (++r == kDynRun) { r = 0; cb = next_base; }
