@@ -31,6 +31,7 @@ struct mod16_ctx {
     int grid_mult = 64;              // blocks per CU in the grid-stride launch (measured best)
     bool use_dma = true;             // LDS-DMA prefetch form of the production kernel
     int use_dyn = 1;                 // dynamic run claiming (MOD16_DYN=0: static grid-stride)
+    int use_pitch = 1;               // scalar base + pitch addressing for slab layouts (MOD16_PITCH=0: off)
     unsigned long long* dyn_counters = nullptr;   // ring of ticket counters, 128 B apart
     int dyn_next = 0;
     bool have_lut = false;
@@ -139,6 +140,7 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
         if (const char* g = getenv("MOD16_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(g));
         if (const char* g = getenv("MOD16_NO_DMA")) ctx->use_dma = atoi(g) == 0;
         if (const char* g = getenv("MOD16_DYN")) ctx->use_dyn = atoi(g);
+        if (const char* g = getenv("MOD16_PITCH")) ctx->use_pitch = atoi(g);
         HIPCHK(ctx, hipMalloc(&ctx->dyn_counters, 64 * 128));
         const size_t nlut = MOD16_LUT_ROWS * kLutCols;
         HIPCHK(ctx, hipMalloc(&ctx->lut64, nlut * sizeof(double)));
@@ -325,7 +327,18 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
                 rc = reserve_diag(ctx, nruns + kStage);
                 if (rc != MOD16_OK) return rc;
                 b.diag_partial = ctx->diag_partial;
-                hipLaunchKernelGGL((et_kernel_dyn<T, true, true>), dim3(dgrid), dim3(kDmaBlock), 0, st, b);
+                // equally spaced driver arrays (one slab): scalar base + k * pitch
+                const ptrdiff_t pitch_b = reinterpret_cast<const char*>(b.drv[1]) -
+                                          reinterpret_cast<const char*>(b.drv[0]);
+                bool pitched = ctx->use_pitch && pitch_b % (ptrdiff_t)sizeof(T) == 0;
+                for (int k = 2; k < 14 && pitched; ++k)
+                    pitched = reinterpret_cast<const char*>(b.drv[k]) -
+                              reinterpret_cast<const char*>(b.drv[0]) == k * pitch_b;
+                b.drv_pitch = pitched ? pitch_b / (ptrdiff_t)sizeof(T) : 0;
+                if (pitched)
+                    hipLaunchKernelGGL((et_kernel_dyn<T, true, true, true>), dim3(dgrid), dim3(kDmaBlock), 0, st, b);
+                else
+                    hipLaunchKernelGGL((et_kernel_dyn<T, true, true, false>), dim3(dgrid), dim3(kDmaBlock), 0, st, b);
                 if (ddiag && nbody == a.n) {
                     const double* fin = ctx->diag_partial;
                     int64_t count = nruns;

@@ -33,7 +33,11 @@ template <typename T> struct EtArgs {
     uint32_t dense_par;
     double* diag_partial;  // et_kernel_dma: [gridDim][8] per-block diagnostics
     unsigned long long* dyn_counter;   // et_kernel_dyn: run tickets, zero at launch
+    int64_t drv_pitch;     // et_kernel_dyn<.., PITCHED>: drv[k] = drv[0] + k * drv_pitch (elements)
 };
+
+static_assert(__builtin_offsetof(EtArgs<double>, drv) == 0 && __builtin_offsetof(EtArgs<float>, drv) == 0,
+              "et_kernel_dyn reads drv[] from offset 0 of the kernel-argument segment");
 
 template <typename T, int V> struct Vec;
 template <> struct Vec<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
@@ -466,7 +470,10 @@ __global__ void __launch_bounds__(kBlock) et_kernel_dma(const EtArgs<T> a) {
 #define MOD16_DYN_RUN 16
 #endif
 constexpr int kDynRun = MOD16_DYN_RUN;
-template <typename T, bool FAST, bool DIAG>
+// PITCHED: the 14 driver arrays are equally spaced (one slab, as
+// RasterEngine.alloc_raster lays them out), so array k's address is
+// drv[0] + k * pitch in scalar registers instead of 14 pointers.
+template <typename T, bool FAST, bool DIAG, bool PITCHED = false>
 __global__ void __launch_bounds__(kBlock) et_kernel_dyn(const EtArgs<T> a) {
     constexpr int V = 16 / (int)sizeof(T);
     constexpr int kSlot = 15 * 1024;   // 14 x (64 lanes x 16 B) + class bytes
@@ -510,20 +517,73 @@ __global__ void __launch_bounds__(kBlock) et_kernel_dyn(const EtArgs<T> a) {
     double dsum_d = 0, dsum_n = 0, dmax_d = -__builtin_huge_val(), dmax_n = -__builtin_huge_val();
     unsigned nan_d = 0, nan_n = 0;   // wave-uniform NaN counts (ballot + popcount)
 
-    auto issue = [&](int64_t first) {
+    // scalar loads of drv[0..13] from the kernel-argument segment (EtArgs::drv
+    // is at offset 0); called ahead of the wait for the DMA so that their
+    // latency is hidden
+    auto load_ptrs = [&](const char* (&dptr)[14]) {
+        if constexpr (!PITCHED) {
+            typedef const __attribute__((address_space(4))) char* kptr_t;
+            kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
 #pragma unroll
-        for (int k = 0; k < 14; ++k)
-            __builtin_amdgcn_global_load_lds((gptr_t)((a.drv[k] + first) + lane_elem),
-                                             (lptr_t)(ws + k * 1024), 16, 0, kDmaNt);
-        // sub-dword LDS-DMA lands one dword per lane (measured): read back at lane * 4
-        if constexpr (V == 2)
-            __builtin_amdgcn_global_load_lds((gptr_t)((a.cls + first) + lane_elem),
-                                             (lptr_t)(ws + 14 * 1024), 2, 0, kDmaNt);
-        else
-            __builtin_amdgcn_global_load_lds((gptr_t)((a.cls + first) + lane_elem),
-                                             (lptr_t)(ws + 14 * 1024), 4, 0, kDmaNt);
+            for (int k = 0; k < 14; ++k)
+                dptr[k] = *reinterpret_cast<const char* const __attribute__((address_space(4)))*>(ka + 8 * k);
+        }
     };
-    if (v < nvec) issue(first_of(cbase, run));
+    auto issue = [&](int64_t first, const char* (&dptr)[14]) {
+        if constexpr (PITCHED) {
+            // Opaque copies of the loop invariants keep hipcc from hoisting 14
+            // per-lane 64-bit addresses (28 VGPRs) and 14 LDS offsets out of the
+            // loop: each access is scalar (running array base) + 32-bit lane
+            // byte offset, M0 = slot + k KiB by one s_add.
+            unsigned lb = lane_elem * (unsigned)sizeof(T);
+            unsigned wl = (unsigned)(uintptr_t)(lptr_t)ws;
+            int64_t pitch_b = a.drv_pitch * (int64_t)sizeof(T);
+            asm volatile("" : "+v"(lb));
+            asm volatile("" : "+s"(wl));
+            asm volatile("" : "+s"(pitch_b));
+            const char* pk = reinterpret_cast<const char*>(a.drv[0] + first);
+#pragma unroll
+            for (int k = 0; k < 14; ++k) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(pk + lb), (lptr_t)(uintptr_t)(wl + k * 1024),
+                                                 16, 0, kDmaNt);
+                pk += pitch_b;
+            }
+            const char* pc = reinterpret_cast<const char*>(a.cls + first);
+            // sub-dword LDS-DMA lands one dword per lane (measured): read back at lane * 4
+            if constexpr (V == 2)
+                __builtin_amdgcn_global_load_lds((gptr_t)(pc + (lb >> 3)), (lptr_t)(uintptr_t)(wl + 14 * 1024),
+                                                 2, 0, kDmaNt);
+            else
+                __builtin_amdgcn_global_load_lds((gptr_t)(pc + (lb >> 2)), (lptr_t)(uintptr_t)(wl + 14 * 1024),
+                                                 4, 0, kDmaNt);
+        } else {
+            // 14 independent pointers, re-read from the kernel-argument segment
+            // by the caller (dptr) so that no register holds them across the
+            // arithmetic
+            unsigned lb = lane_elem * (unsigned)sizeof(T);
+            unsigned wl = (unsigned)(uintptr_t)(lptr_t)ws;
+            asm volatile("" : "+v"(lb));
+            asm volatile("" : "+s"(wl));
+            const int64_t first_b = first * (int64_t)sizeof(T);
+#pragma unroll
+            for (int k = 0; k < 14; ++k)
+                __builtin_amdgcn_global_load_lds((gptr_t)((dptr[k] + first_b) + lb),
+                                                 (lptr_t)(uintptr_t)(wl + k * 1024), 16, 0, kDmaNt);
+            const char* pc = reinterpret_cast<const char*>(a.cls + first);
+            if constexpr (V == 2)
+                __builtin_amdgcn_global_load_lds((gptr_t)(pc + (lb >> 3)), (lptr_t)(uintptr_t)(wl + 14 * 1024),
+                                                 2, 0, kDmaNt);
+            else
+                __builtin_amdgcn_global_load_lds((gptr_t)(pc + (lb >> 2)), (lptr_t)(uintptr_t)(wl + 14 * 1024),
+                                                 4, 0, kDmaNt);
+        }
+    };
+    {
+        const char* dptr[14];
+        load_ptrs(dptr);
+        if (v < nvec) issue(first_of(cbase, run), dptr);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first fill: nothing to overlap with
     bool flushed = false;
 #pragma nounroll
@@ -532,6 +592,8 @@ __global__ void __launch_bounds__(kBlock) et_kernel_dyn(const EtArgs<T> a) {
         // atomic) was issued before the previous iteration's two stores: all but
         // the two youngest vector-memory operations must be done
         // (after a diagnostics flush there is one more store behind them)
+        const char* dptr[14];
+        load_ptrs(dptr);
         if (flushed) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         if (run == 1) {   // the claim issued in the previous iteration has returned
@@ -592,7 +654,7 @@ __global__ void __launch_bounds__(kBlock) et_kernel_dyn(const EtArgs<T> a) {
         int run_n = run;
         advance(cb_n, run_n);
         const int64_t vn = vec_of(cb_n, run_n);
-        if (vn < nvec) issue(first_of(cb_n, run_n));
+        if (vn < nvec) issue(first_of(cb_n, run_n), dptr);
         asm volatile("" ::: "memory");
 
         if (v < nvec) {   // only the last chunk is ragged

@@ -265,3 +265,34 @@ def test_unaligned_device_pointers_take_the_scalar_path(env):
     assert drv[0][1:].data_ptr() % 16 == 8
     assert torch.equal(torch.nan_to_num(got_d), torch.nan_to_num(want_d))
     assert torch.equal(torch.nan_to_num(got_n), torch.nan_to_num(want_n))
+
+
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_slab_and_scattered_drivers_agree(env, dtype):
+    """Equally spaced driver arrays (one slab) take the scalar base + pitch
+    addressing of the production kernel, separately allocated ones the
+    14-pointer form: same pixels, same bits, same diagnostics."""
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table, dtype=dtype)
+    n = 300000 + 36          # ragged last piece
+    cls, drv, day1, night1 = eng.alloc_raster(n)
+    eng.synth(n, seed=21, out=(cls, drv))
+    gaps = [drv[k + 1].data_ptr() - drv[k].data_ptr() for k in range(13)]
+    assert len(set(gaps)) == 1, 'alloc_raster lays the drivers out equally spaced'
+    d1 = torch.zeros(8, dtype=torch.float64, device='cuda')
+    eng.run(cls, drv, day1, night1, diag=d1)
+    # copies whose spacing is irregular: 16-byte-aligned views at growing offsets
+    scattered = []
+    for k, d in enumerate(drv):
+        buf = torch.empty(n + 4 * (k * k + 1), dtype=d.dtype, device='cuda')
+        view = buf[4 * k * k:4 * k * k + n]
+        view.copy_(d)
+        scattered.append(view)
+    gaps = [scattered[k + 1].data_ptr() - scattered[k].data_ptr() for k in range(13)]
+    assert len(set(gaps)) > 1
+    d2 = torch.zeros(8, dtype=torch.float64, device='cuda')
+    day2, night2 = eng.run(cls, scattered, diag=d2)
+    eng.check()
+    assert torch.equal(torch.nan_to_num(day1), torch.nan_to_num(day2))
+    assert torch.equal(torch.nan_to_num(night1), torch.nan_to_num(night2))
+    assert torch.equal(d1, d2)

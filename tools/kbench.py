@@ -44,9 +44,12 @@ def child(args):
         drv, (day, night) = views[:14], views[14:]
         cls = torch.empty(n, dtype=torch.uint8, device='cuda')
         eng.synth(n, seed=16, out=(cls, drv))
-    else:
+    elif args.separate:
         cls, drv = eng.synth(n, seed=16)
         day, night = eng.empty(n, 2)
+    else:
+        cls, drv, day, night = eng.alloc_raster(n)      # what bench.py does
+        eng.synth(n, seed=16, out=(cls, drv))
     eng.time_kernel(cls, drv, day, night, launches=2)
     ms = [eng.time_kernel(cls, drv, day, night, launches=args.launches) for _ in range(args.rounds)]
     best = min(ms)
@@ -65,6 +68,7 @@ def main():
     ap.add_argument('--child', action='store_true')
     ap.add_argument('--stagger', type=int, default=0, help='bytes between successive array bases (mod allocation)')
     ap.add_argument('--slab', type=int, default=-1, help='carve all arrays from one allocation with this extra offset (bytes)')
+    ap.add_argument('--separate', action='store_true', help='one allocation per array instead of alloc_raster')
     ap.add_argument('libs', nargs='*')
     args = ap.parse_args()
     if args.child:
@@ -74,7 +78,7 @@ def main():
         env = dict(os.environ, MOD16_LIB=os.path.abspath(lib))
         subprocess.run([sys.executable, __file__, '--child', '--rows', str(args.rows),
                         '--launches', str(args.launches), '--rounds', str(args.rounds),
-                        '--dtype', args.dtype, '--math', args.math, '--stagger', str(args.stagger), '--slab', str(args.slab)], env=env, check=False)
+                        '--dtype', args.dtype, '--math', args.math, '--stagger', str(args.stagger), '--slab', str(args.slab)] + (['--separate'] if args.separate else []), env=env, check=False)
 
 
 if __name__ == '__main__':
