@@ -14,6 +14,7 @@
 
 #include "../../include/mod16_hip.h"
 #include "mod16_kernels.hpp"
+#include "mod16_stream.hpp"
 #include "mod16_methods.hpp"
 
 using namespace mod16;
@@ -270,6 +271,28 @@ template <typename T>
 static int reduce_entry(mod16_ctx* ctx, const T* day, const T* night, int64_t n, double* diag,
                         double* ddiag, void* stream);
 
+// The production pipeline for the other dense class-raster forms
+// (mod16_stream.hpp). s.n must be a multiple of the vector width.
+template <typename T, int MODE>
+static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st) {
+    constexpr int V = VecOf<T>::v;
+    s.lut64 = ctx->lut64;
+    s.tab = ctx->tab64;
+    s.status = ctx->status;
+    unsigned long long* ctr = ctx->dyn_counters + 16 * (ctx->dyn_next++ % 64);
+    HIPCHK(ctx, hipMemsetAsync(ctr, 0, sizeof(unsigned long long), st));
+    s.dyn_counter = ctr;
+    const int64_t npiece = (s.n / V + 63) / 64;
+    const int64_t nruns = (npiece + kDynRun - 1) / kDynRun;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(
+        (nruns + (kBlock / 64) - 1) / (kBlock / 64), (int64_t)ctx->cus * 2));
+    int rc = reserve_diag(ctx, nruns + 1024);
+    if (rc != MOD16_OK) return rc;
+    s.diag_partial = ctx->diag_partial;
+    hipLaunchKernelGGL((et_stream_kernel<T, MODE>), dim3(grid), dim3(kBlock), 0, st, s);
+    return MOD16_OK;
+}
+
 // ddiag != NULL: also produce the diagnostics vector (device, 8 doubles).
 template <typename T>
 static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st,
@@ -299,7 +322,36 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
     const int64_t nbody = aligned ? (a.n / V) * V : 0;
     const bool dma = ctx->use_dma && lut && fast && !sep && dense && a.out[0] && a.out[1];   // sep covers PET too
     bool fused_diag = false;
-    if (nbody) {
+    // the same pipeline for PET / separate components (mod16_stream.hpp)
+    int smode = -1;
+    if (ctx->use_dma && ctx->use_dyn && lut && fast && dense && sep && !ddiag) {
+        bool all6 = true, none6 = true;
+        for (int k = 2; k < 8; ++k) { all6 = all6 && a.out[k]; none6 = none6 && !a.out[k]; }
+        const bool tot = a.out[0] && a.out[1], notot = !a.out[0] && !a.out[1];
+        const bool pet = a.out[8] && a.out[9], nopet = !a.out[8] && !a.out[9];
+        if (tot && none6 && pet) smode = kStreamPet;
+        else if (tot && all6 && nopet) smode = kStreamSep8;
+        else if (notot && all6 && nopet) smode = kStreamSep6;
+    }
+    if (nbody && smode >= 0) {
+        StreamArgs<T> s;
+        memset(&s, 0, sizeof s);
+        for (int k = 0; k < 14; ++k) s.wide[k] = a.drv[k];
+        s.bytes[0] = a.cls;
+        s.n = nbody;
+        int rc;
+        if (smode == kStreamPet) {
+            s.out[0] = a.out[0]; s.out[1] = a.out[1]; s.out[2] = a.out[8]; s.out[3] = a.out[9];
+            rc = launch_stream<T, kStreamPet>(ctx, s, st);
+        } else if (smode == kStreamSep8) {
+            for (int k = 0; k < 8; ++k) s.out[k] = a.out[k];
+            rc = launch_stream<T, kStreamSep8>(ctx, s, st);
+        } else {
+            for (int k = 0; k < 6; ++k) s.out[k] = a.out[k + 2];
+            rc = launch_stream<T, kStreamSep6>(ctx, s, st);
+        }
+        if (rc != MOD16_OK) return rc;
+    } else if (nbody) {
         EtArgs<T> b = a;
         b.n = nbody;
         const int grid = dma ? (int)std::max<int64_t>(1, std::min<int64_t>(
@@ -786,13 +838,54 @@ static int raw_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* raw,
     if (n == 0) return MOD16_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const bool fast = (flags & MOD16_MATH_EXACT) == 0;
-    auto launch = [&](const RawArgs<T>& d, hipStream_t st) {
-        const int grid = grid_for(ctx, d.n);
-        if (fast) hipLaunchKernelGGL((et_raw_kernel<T, true>), dim3(grid), dim3(kBlock), 0, st, d);
-        else hipLaunchKernelGGL((et_raw_kernel<T, false>), dim3(grid), dim3(kBlock), 0, st, d);
+    // d holds device pointers. Dense, 16-byte-aligned rasters run their vector
+    // body on the production pipeline (et_stream_kernel); the ragged tail and
+    // every other shape run the plain kernel. host_hours: the scalar hours of
+    // daylight when it is known on the host (HOST mode).
+    auto launch = [&](const RawArgs<T>& d, hipStream_t st, const T* host_hours) -> int {
+        constexpr int V = VecOf<T>::v;
+        auto al = [](const void* p, size_t to) { return reinterpret_cast<uintptr_t>(p) % to == 0; };
+        bool ok = fast && ctx->use_dma && ctx->use_dyn && d.dense_drv == 0x3fffu && d.out[0] && d.out[1];
+        for (int k = 0; k < 14 && ok; ++k) ok = al(d.drv[k], 16);
+        ok = ok && al(d.fpar_pct, V) && al(d.lai_x10, V) && al(d.cls, V) && al(d.out[0], 16) && al(d.out[1], 16);
+        int mode = kStreamRaw;
+        if (ok && d.out[2]) {
+            ok = al(d.out[2], 16);
+            if (d.dense_hours) { mode = kStreamRawTotalHours; ok = ok && al(d.day_hours, 16); }
+            else if (host_hours) mode = kStreamRawTotal;
+            else ok = false;
+        }
+        const int64_t nbody = ok ? (d.n / V) * V : 0;
+        if (nbody) {
+            StreamArgs<T> s;
+            memset(&s, 0, sizeof s);
+            for (int k = 0; k < 14; ++k) s.wide[k] = d.drv[k];
+            s.wide[14] = d.day_hours;
+            s.bytes[0] = d.cls; s.bytes[1] = d.fpar_pct; s.bytes[2] = d.lai_x10;
+            for (int k = 0; k < 3; ++k) s.out[k] = d.out[k];
+            s.hours = host_hours ? (double)*host_hours : 0.0;
+            s.n = nbody;
+            int rc = mode == kStreamRaw ? launch_stream<T, kStreamRaw>(ctx, s, st)
+                     : mode == kStreamRawTotal ? launch_stream<T, kStreamRawTotal>(ctx, s, st)
+                                               : launch_stream<T, kStreamRawTotalHours>(ctx, s, st);
+            if (rc != MOD16_OK) return rc;
+        }
+        if (nbody < d.n) {
+            RawArgs<T> t = d;
+            for (int k = 0; k < 14; ++k) if ((t.dense_drv >> k) & 1u) t.drv[k] += nbody;
+            t.fpar_pct += nbody; t.lai_x10 += nbody; t.cls += nbody;
+            if (t.day_hours && t.dense_hours) t.day_hours += nbody;
+            for (int k = 0; k < 3; ++k) if (t.out[k]) t.out[k] += nbody;
+            t.n = d.n - nbody;
+            const int grid = grid_for(ctx, t.n);
+            if (fast) hipLaunchKernelGGL((et_raw_kernel<T, true>), dim3(grid), dim3(kBlock), 0, st, t);
+            else hipLaunchKernelGGL((et_raw_kernel<T, false>), dim3(grid), dim3(kBlock), 0, st, t);
+        }
+        return MOD16_OK;
     };
     if (where == MOD16_DEVICE) {
-        launch(a, static_cast<hipStream_t>(stream));
+        int rc = launch(a, static_cast<hipStream_t>(stream), nullptr);
+        if (rc != MOD16_OK) return rc;
         HIPCHK(ctx, hipGetLastError());
         return MOD16_OK;
     }
@@ -850,7 +943,10 @@ static int raw_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* raw,
             *db[k] = dp;
         }
         for (int k = 0; k < 3; ++k) d.out[k] = a.out[k] ? reinterpret_cast<T*>(base + per_arr * (15 + k)) : nullptr;
-        launch(d, st);
+        {
+            int rc = launch(d, st, (a.day_hours && !a.dense_hours) ? &hs[14] : nullptr);
+            if (rc != MOD16_OK) return rc;
+        }
         HIPCHK(ctx, hipGetLastError());
         for (int k = 0; k < 3; ++k)
             if (a.out[k]) HIPCHK(ctx, hipMemcpyAsync(a.out[k] + off, d.out[k], sizeof(T) * m, hipMemcpyDeviceToHost, st));

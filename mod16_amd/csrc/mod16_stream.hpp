@@ -1,0 +1,324 @@
+// The production pipeline of et_kernel_dyn (mod16_kernels.hpp) for the other
+// dense class-raster forms of the forward run: persistent waves that claim runs
+// of 64-vector pieces from a ticket counter, one LDS slot per wave filled by
+// LDS-DMA one iteration ahead, BPLUT + exp/log tables in LDS, non-temporal
+// 16-byte stores, per-run diagnostics partials. What varies is the set of
+// arrays and the pixel function:
+//
+//   kStreamPet            14 drivers + class -> day, night, PET day, PET night
+//                         (reference README.md:404-424, :546-602)
+//   kStreamSep8 / Sep6    14 drivers + class -> [day, night,] the six components
+//                         (separate=True, mod16/__init__.py:789-793)
+//   kStreamRaw*           14 raw drivers + class + uint8 fPAR/LAI [+ hours of
+//                         daylight] -> day, night [, 8-day total]
+//                         (calibration.py:380-423, verify2.py:113-115)
+//
+// Algorithmic bytes per pixel (float64): PET 145, Sep8 177, Sep6 161,
+// Raw 131, RawTotal 139, RawTotalHours 147.
+#pragma once
+#include "mod16_kernels.hpp"
+
+namespace mod16 {
+
+enum StreamMode {
+    kStreamPet = 0, kStreamSep8, kStreamSep6, kStreamRaw, kStreamRawTotal, kStreamRawTotalHours
+};
+
+// NW 16-byte-per-lane arrays, NB byte arrays (class raster first), NOUT outputs
+template <int MODE> struct StreamSpec;
+template <> struct StreamSpec<kStreamPet> { static constexpr int NW = 14, NB = 1, NOUT = 4; };
+template <> struct StreamSpec<kStreamSep8> { static constexpr int NW = 14, NB = 1, NOUT = 8; };
+template <> struct StreamSpec<kStreamSep6> { static constexpr int NW = 14, NB = 1, NOUT = 6; };
+template <> struct StreamSpec<kStreamRaw> { static constexpr int NW = 14, NB = 3, NOUT = 2; };
+template <> struct StreamSpec<kStreamRawTotal> { static constexpr int NW = 14, NB = 3, NOUT = 3; };
+template <> struct StreamSpec<kStreamRawTotalHours> { static constexpr int NW = 15, NB = 3, NOUT = 3; };
+
+template <typename T> struct StreamArgs {
+    const T* wide[16];         // offset 0 of the kernel-argument segment (re-read in the loop)
+    const uint8_t* bytes[4];   // offset 128: class raster, then fpar_pct, lai_x10
+    T* out[8];
+    const double* lut64;
+    const double* tab;
+    int64_t n;
+    unsigned* status;
+    double* diag_partial;      // [runs][8]
+    unsigned long long* dyn_counter;
+    double hours;              // kStreamRawTotal: the (scalar) hours of daylight
+};
+static_assert(__builtin_offsetof(StreamArgs<double>, wide) == 0 &&
+              __builtin_offsetof(StreamArgs<double>, bytes) == 128 &&
+              __builtin_offsetof(StreamArgs<float>, wide) == 0 &&
+              __builtin_offsetof(StreamArgs<float>, bytes) == 128,
+              "et_stream_kernel reads wide[] / bytes[] at fixed kernel-argument offsets");
+
+// One asm statement reads the whole slot and waits for it (see et_kernel_dma
+// for why these are not ordinary LDS loads). Byte arrays land one dword per
+// lane (sub-dword LDS-DMA, measured), 256 B per array behind the wide ones.
+#define MOD16_RD(i, off) "ds_read_b128 %[w" #i "], %[base] offset:" #off "\n\t"
+#define MOD16_RD14                                                                              \
+    "ds_read_b128 %[w0], %[base]\n\t" MOD16_RD(1, 1024) MOD16_RD(2, 2048) MOD16_RD(3, 3072)     \
+    MOD16_RD(4, 4096) MOD16_RD(5, 5120) MOD16_RD(6, 6144) MOD16_RD(7, 7168) MOD16_RD(8, 8192)   \
+    MOD16_RD(9, 9216) MOD16_RD(10, 10240) MOD16_RD(11, 11264) MOD16_RD(12, 12288)               \
+    MOD16_RD(13, 13312)
+#define MOD16_W14(in)                                                                           \
+    [w0] "=&v"(in[0]), [w1] "=&v"(in[1]), [w2] "=&v"(in[2]), [w3] "=&v"(in[3]),                 \
+    [w4] "=&v"(in[4]), [w5] "=&v"(in[5]), [w6] "=&v"(in[6]), [w7] "=&v"(in[7]),                 \
+    [w8] "=&v"(in[8]), [w9] "=&v"(in[9]), [w10] "=&v"(in[10]), [w11] "=&v"(in[11]),             \
+    [w12] "=&v"(in[12]), [w13] "=&v"(in[13])
+
+template <int NW, int NB> struct SlotRead;
+template <> struct SlotRead<14, 1> {
+    template <typename VT>
+    static __device__ __forceinline__ void go(VT (&in)[14], unsigned (&b)[1], unsigned base, unsigned bad) {
+        asm volatile(MOD16_RD14 "ds_read_b32 %[b0], %[bad]\n\ts_waitcnt lgkmcnt(0)"
+                     : MOD16_W14(in), [b0] "=&v"(b[0])
+                     : [base] "v"(base), [bad] "v"(bad)
+                     : "memory");
+    }
+};
+template <> struct SlotRead<14, 3> {
+    template <typename VT>
+    static __device__ __forceinline__ void go(VT (&in)[14], unsigned (&b)[3], unsigned base, unsigned bad) {
+        asm volatile(MOD16_RD14 "ds_read_b32 %[b0], %[bad]\n\tds_read_b32 %[b1], %[bad] offset:256\n\t"
+                     "ds_read_b32 %[b2], %[bad] offset:512\n\ts_waitcnt lgkmcnt(0)"
+                     : MOD16_W14(in), [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [b2] "=&v"(b[2])
+                     : [base] "v"(base), [bad] "v"(bad)
+                     : "memory");
+    }
+};
+template <> struct SlotRead<15, 3> {
+    template <typename VT>
+    static __device__ __forceinline__ void go(VT (&in)[15], unsigned (&b)[3], unsigned base, unsigned bad) {
+        asm volatile(MOD16_RD14 MOD16_RD(14, 14336)
+                     "ds_read_b32 %[b0], %[bad]\n\tds_read_b32 %[b1], %[bad] offset:256\n\t"
+                     "ds_read_b32 %[b2], %[bad] offset:512\n\ts_waitcnt lgkmcnt(0)"
+                     : MOD16_W14(in), [w14] "=&v"(in[14]), [b0] "=&v"(b[0]), [b1] "=&v"(b[1]),
+                       [b2] "=&v"(b[2])
+                     : [base] "v"(base), [bad] "v"(bad)
+                     : "memory");
+    }
+};
+#undef MOD16_RD
+#undef MOD16_RD14
+#undef MOD16_W14
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a) {
+    typedef StreamSpec<MODE> S;
+    constexpr int V = 16 / (int)sizeof(T);
+    constexpr int NW = S::NW, NB = S::NB, NOUT = S::NOUT;
+    constexpr int kSlot = NW * 1024 + NB * 256;
+    constexpr bool RAW = MODE == kStreamRaw || MODE == kStreamRawTotal || MODE == kStreamRawTotalHours;
+    constexpr int kTab = FastMath<double>::kTabDoubles;
+    __shared__ double lut[MOD16_LUT_ROWS * kLutCols];
+    __shared__ __attribute__((aligned(16))) double tab[kTab];
+    __shared__ __attribute__((aligned(16))) char stage[(kBlock / 64) * kSlot];
+    for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) lut[i] = a.lut64[i];
+    for (int i = threadIdx.x; i < kTab; i += kBlock) tab[i] = a.tab[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* const ws = stage + wave * kSlot;
+    const int64_t nvec = a.n / V;
+    const int64_t npiece = (nvec + 63) / 64;
+    const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+    int64_t cbase = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * kDynRun;
+    int64_t next_base = npiece;
+    unsigned long long ticket = 0;
+    int run = 0;
+    auto vec_of = [&](int64_t cb, int r) { return (cb + r) * 64 + lane; };
+    auto first_of = [&](int64_t cb, int r) {
+        const int64_t f = (cb + r) * (int64_t)(64 * V);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)f);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)f >> 32));
+        return (int64_t)(((unsigned long long)hi << 32) | lo);
+    };
+    const unsigned lane_elem = (unsigned)lane * (unsigned)V;
+    auto advance = [&](int64_t& cb, int& r) {
+        if (++r == kDynRun) { r = 0; cb = next_base; }
+    };
+    int64_t v = vec_of(cbase, run);
+    double dsum_d = 0, dsum_n = 0, dmax_d = -__builtin_huge_val(), dmax_n = -__builtin_huge_val();
+    unsigned nan_d = 0, nan_n = 0;
+
+    struct Ptrs { const char* w[NW]; const char* b[NB]; };
+    // scalar loads from the kernel-argument segment, ahead of the wait for the DMA
+    auto load_ptrs = [&](Ptrs& p) {
+        typedef const __attribute__((address_space(4))) char* kptr_t;
+        kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+            p.w[k] = *reinterpret_cast<const char* const __attribute__((address_space(4)))*>(ka + 8 * k);
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            p.b[k] = *reinterpret_cast<const char* const __attribute__((address_space(4)))*>(ka + 128 + 8 * k);
+    };
+    auto issue = [&](int64_t first, const Ptrs& p) {
+        unsigned lb = lane_elem * (unsigned)sizeof(T);
+        unsigned wl = (unsigned)(uintptr_t)(lptr_t)ws;
+        asm volatile("" : "+v"(lb));
+        asm volatile("" : "+s"(wl));
+        const int64_t first_b = first * (int64_t)sizeof(T);
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+            __builtin_amdgcn_global_load_lds((gptr_t)((p.w[k] + first_b) + lb),
+                                             (lptr_t)(uintptr_t)(wl + k * 1024), 16, 0, kDmaNt);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            if constexpr (V == 2)
+                __builtin_amdgcn_global_load_lds((gptr_t)((p.b[k] + first) + (lb >> 3)),
+                                                 (lptr_t)(uintptr_t)(wl + NW * 1024 + k * 256), 2, 0, kDmaNt);
+            else
+                __builtin_amdgcn_global_load_lds((gptr_t)((p.b[k] + first) + (lb >> 2)),
+                                                 (lptr_t)(uintptr_t)(wl + NW * 1024 + k * 256), 4, 0, kDmaNt);
+        }
+    };
+    {
+        Ptrs p;
+        load_ptrs(p);
+        if (v < nvec) issue(first_of(cbase, run), p);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bool flushed = false;
+#pragma nounroll
+    for (; cbase + run < npiece; ) {
+        Ptrs ptrs;
+        load_ptrs(ptrs);
+        // everything but the NOUT stores of the previous iteration (and its
+        // diagnostics flush, if any) must be complete: this iteration's DMA and,
+        // one iteration after a claim, the claim's atomic
+        if (flushed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOUT + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOUT) : "memory");
+        if (run == 1) {
+            asm volatile("" : "+v"(ticket));
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ticket);
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ticket >> 32));
+            next_base = (nwaves + (int64_t)(((unsigned long long)hi << 32) | lo)) * kDynRun;
+        }
+        typedef typename Vec<T, V>::type VT;
+        VT in[NW];
+        unsigned bits[NB];
+        SlotRead<NW, NB>::go(in, bits, (unsigned)(uintptr_t)(lptr_t)ws + lane * 16u,
+                             (unsigned)(uintptr_t)(lptr_t)ws + NW * 1024u + lane * 4u);
+        if (run == 0 && lane == 0) {
+            const unsigned long long one = 1;
+            asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0"
+                         : "=v"(ticket) : "v"(a.dyn_counter), "v"(one) : "memory");
+        }
+        int64_t cb_n = cbase;
+        int run_n = run;
+        advance(cb_n, run_n);
+        const int64_t vn = vec_of(cb_n, run_n);
+        if (vn < nvec) issue(first_of(cb_n, run_n), ptrs);
+        asm volatile("" ::: "memory");
+
+        if (v < nvec) {   // only the last piece is ragged
+            VT res[NOUT];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                PixelIn<double> x;
+                if constexpr (RAW) {
+                    RawIn<double> r = {(double)in[0][j], (double)in[1][j], (double)in[2][j],
+                                       (double)in[3][j], (double)in[4][j], (double)in[5][j],
+                                       (double)in[6][j], (double)in[7][j], (double)in[8][j],
+                                       (double)in[9][j], (double)in[10][j], (double)in[11][j],
+                                       (double)in[12][j], (double)in[13][j],
+                                       (bits[1] >> (8 * j)) & 0xffu, (bits[2] >> (8 * j)) & 0xffu};
+                    x = raw_to_pixel_fast(r, tab);
+                } else {
+                    x = PixelIn<double>{(double)in[0][j], (double)in[1][j], (double)in[2][j],
+                                        (double)in[3][j], (double)in[4][j], (double)in[5][j],
+                                        (double)in[6][j], (double)in[7][j], (double)in[8][j],
+                                        (double)in[9][j], (double)in[10][j], (double)in[11][j],
+                                        (double)in[12][j], (double)in[13][j]};
+                }
+                unsigned c = (bits[0] >> (8 * j)) & 0xffu;
+                if (c >= 13u) {
+                    atomicOr(a.status, kStatusClassRange);
+                    c = 13u;
+                }
+                const double* l = lut + c;
+                ClassPar<double> p;
+                p.tmin_close = l[0 * kLutCols];
+                p.tmin_open = l[1 * kLutCols];
+                p.vpd_open = l[2 * kLutCols];
+                p.vpd_close = l[3 * kLutCols];
+                p.gl_sh = l[4 * kLutCols];
+                p.gl_wv = l[5 * kLutCols];
+                p.g_cut = l[6 * kLutCols];
+                p.csl = l[7 * kLutCols];
+                p.rbl_min = l[8 * kLutCols];
+                p.rbl_max = l[9 * kLutCols];
+                p.beta = l[10 * kLutCols];
+                p.inv_dtmin = l[11 * kLutCols];
+                p.inv_dvpd = l[12 * kLutCols];
+                p.rbl_slope = l[13 * kLutCols];
+                p.inv_beta = l[14 * kLutCols];
+                PixelOut<double> o = et_pixel_fast<double, MODE == kStreamPet>(x, p, tab);
+                const double day = (o.canopy_d + o.soil_d) + o.trans_d;      // :792
+                const double night = (o.canopy_n + o.soil_n) + o.trans_n;
+                if constexpr (MODE == kStreamSep6) {
+                    res[0][j] = (T)o.canopy_d; res[1][j] = (T)o.soil_d; res[2][j] = (T)o.trans_d;
+                    res[3][j] = (T)o.canopy_n; res[4][j] = (T)o.soil_n; res[5][j] = (T)o.trans_n;
+                } else {
+                    res[0][j] = (T)day;
+                    res[1][j] = (T)night;
+                }
+                if constexpr (MODE == kStreamPet) {
+                    res[2][j] = (T)o.pet_d;
+                    res[3][j] = (T)o.pet_n;
+                }
+                if constexpr (MODE == kStreamSep8) {
+                    res[2][j] = (T)o.canopy_d; res[3][j] = (T)o.soil_d; res[4][j] = (T)o.trans_d;
+                    res[5][j] = (T)o.canopy_n; res[6][j] = (T)o.soil_n; res[7][j] = (T)o.trans_n;
+                }
+                if constexpr (MODE == kStreamRawTotal || MODE == kStreamRawTotalHours) {
+#pragma clang fp contract(off)
+                    // tests/verification/verify2.py:113-115
+                    double h = a.hours;
+                    if constexpr (MODE == kStreamRawTotalHours) h = (double)in[14][j];
+                    res[2][j] = (T)((day * h * 8.0 * 60.0 * 60.0) +
+                                    (night * (24.0 - h) * 8.0 * 60.0 * 60.0));
+                }
+                {
+                    const double d = (double)(T)day, g = (double)(T)night;
+                    const bool dn = d != d, gn = g != g;
+                    nan_d += (unsigned)__builtin_popcountll(__ballot(dn));
+                    nan_n += (unsigned)__builtin_popcountll(__ballot(gn));
+                    dsum_d += dn ? 0.0 : d;
+                    dsum_n += gn ? 0.0 : g;
+                    dmax_d = __builtin_fmax(dmax_d, d);
+                    dmax_n = __builtin_fmax(dmax_n, g);
+                }
+            }
+            const int64_t first = first_of(cbase, run);
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k)
+                __builtin_nontemporal_store(res[k], reinterpret_cast<VT*>((a.out[k] + first) + lane_elem));
+        }
+        flushed = (run_n == 0 || cb_n + run_n >= npiece);
+        if (flushed) {   // per-run diagnostics partial (schedule-independent, see et_kernel_dyn)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                dsum_d += __shfl_xor(dsum_d, off, 64);
+                dsum_n += __shfl_xor(dsum_n, off, 64);
+                dmax_d = __builtin_fmax(dmax_d, __shfl_xor(dmax_d, off, 64));
+                dmax_n = __builtin_fmax(dmax_n, __shfl_xor(dmax_n, off, 64));
+            }
+            const double cnt_d = (double)__builtin_amdgcn_readfirstlane(nan_d);
+            const double cnt_n = (double)__builtin_amdgcn_readfirstlane(nan_n);
+            const double f = lane == 0 ? dsum_d : lane == 1 ? dsum_n : lane == 4 ? cnt_d
+                           : lane == 5 ? cnt_n : lane == 6 ? dmax_d : lane == 7 ? dmax_n : 0.0;
+            if (lane < kDiag) a.diag_partial[(cbase / kDynRun) * kDiag + lane] = f;
+            dsum_d = dsum_n = 0.0;
+            dmax_d = dmax_n = -__builtin_huge_val();
+            nan_d = nan_n = 0;
+        }
+        cbase = cb_n;
+        run = run_n;
+        v = vn;
+    }
+}
+
+}  // namespace mod16

@@ -163,6 +163,24 @@ class RasterEngine(object):
                     flags=self.math, where=_lib.DEVICE, stream=self._stream())
         return out_day, out_night
 
+    def run_pet(self, cls, drivers, out=None):
+        '''ET and potential ET from one pass over device-resident drivers
+        (``mod16_et_pet_*``, see ``mod16_amd.evapotranspiration_raster(...,
+        pet=True)``). Returns ``(day, night, pet_day, pet_night)``; ``out`` may
+        give the four output tensors.'''
+        torch = _torch()
+        n = cls.numel()
+        cptr = self._check_tensor(cls, torch.uint8, n, 'cls')
+        keep, dptr, dstride = self._marshal_drivers(drivers, n)
+        out = tuple(out) if out is not None else tuple(self.empty(n, 4))
+        optr = [self._check_tensor(t, self.dtype, n, 'out') for t in out]
+        fn = self.ctx.lib.mod16_et_pet_f32 if self.np_dtype == np.float32 \
+            else self.ctx.lib.mod16_et_pet_f64
+        self.ctx.check(fn(
+            self.ctx.handle, cptr, _lib.ptr_array(dptr), _lib.i64_array(dstride), None, None,
+            n, optr[0], optr[1], optr[2], optr[3], int(self.math), _lib.DEVICE, self._stream()))
+        return out
+
     def alloc_series(self, n):
         '''Device buffers of ``run_series``: class raster, the two-slot driver
         ring and two output pairs.'''
