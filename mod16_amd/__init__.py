@@ -372,6 +372,64 @@ class MOD16(object):
         return np.add(day, night)
 
     @staticmethod
+    def _et_batch(params, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
+                  sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
+                  vpd_night, pressure, fpar, lai, observed=None, weights=None,
+                  separate=False):
+        '''
+        ``MOD16._et`` for many parameter vectors in one launch (extension; the
+        reference evaluates ``_et`` draw by draw from its MCMC sampler,
+        calibration.py:907, and Sobol analysis, sensitivity.py:95).
+        ``params`` is a (D x 11) array in ``MOD16.required_parameters`` order;
+        the drivers broadcast against each other as in ``_et``. Returns the
+        (D x shape) array of day + night latent heat flux [W m-2] -- row d
+        equals ``MOD16._et(params[d], *drivers)`` bit for bit -- or, with
+        ``separate=True``, ``[day, night]``. With ``observed`` (and optional
+        ``weights``, both of the drivers' shape) nothing of that size comes
+        back: the result is ``(sse, count)``, two float64 arrays (D,) with
+        ``sse[d] = sum((weights * (_et_d - observed))**2)`` over the non-NaN
+        pairs and their number, e.g. ``rmsd = np.sqrt(sse / count)``.
+        '''
+        drivers = [lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
+                   sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
+                   vpd_night, pressure, fpar, lai]
+        params = np.asarray(params)
+        if params.ndim != 2 or params.shape[1] != 11:
+            raise IndexError('params must be (D x 11), columns in '
+                             'MOD16.required_parameters order')
+        extra = [v for v in (observed, weights) if v is not None]
+        dtype = _result_dtype(drivers + [params] + extra)
+        shape = np.broadcast_shapes(*[np.shape(v) for v in drivers + extra])
+        n = int(np.prod(shape, dtype=np.int64))
+        ndraw = params.shape[0]
+        keep_d, dptr, dstr = _marshal(drivers, shape, dtype)
+        par = np.ascontiguousarray(params, dtype)
+        full = lambda v: np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype), shape))
+        obs = full(observed) if observed is not None else None
+        wts = full(weights) if weights is not None else None
+        if weights is not None and observed is None:
+            raise ValueError('weights need observed')
+        ctx = _lib.context(0)
+        fn = ctx.lib.mod16_et_static_batch_f32 if dtype == np.float32 \
+            else ctx.lib.mod16_et_static_batch_f64
+        adr = lambda a: a.ctypes.data if a is not None else None
+        if obs is not None:
+            sse, count = np.zeros(ndraw), np.zeros(ndraw)
+            if n and ndraw:
+                ctx.check(fn(ctx.handle, _lib.ptr_array(dptr), _lib.i64_array(dstr), n,
+                             adr(par), ndraw, None, None, None, adr(obs), adr(wts),
+                             adr(sse), adr(count), _lib.HOST, None))
+            return sse, count
+        outs = [np.empty((ndraw,) + shape, dtype) for _ in range(2 if separate else 1)]
+        if n and ndraw:
+            ctx.check(fn(ctx.handle, _lib.ptr_array(dptr), _lib.i64_array(dstr), n,
+                         adr(par), ndraw,
+                         adr(outs[0]) if separate else None, adr(outs[1]) if separate else None,
+                         None if separate else adr(outs[0]), None, None, None, None,
+                         _lib.HOST, None))
+        return outs if separate else outs[0]
+
+    @staticmethod
     def air_density(temp_k, pressure, rhumidity):
         'Air density [kg m-3], reference mod16/__init__.py:384-412.'
         return _call_method(_lib.M_AIR_DENSITY, [temp_k, pressure, rhumidity])

@@ -1075,6 +1075,134 @@ extern "C" int mod16_et_static_f32(mod16_ctx* ctx, const float* const* drivers,
     return static_entry<float>(ctx, drivers, dstride, params, pstride, rcorr, rstride, n, out_day, out_night, where, stream);
 }
 
+// ---------------------- calibration path batched over parameter vectors (N2)
+template <typename T>
+static int static_batch_entry(mod16_ctx* ctx, const T* const* drivers, const int64_t* dstride,
+                              int64_t n, const T* params, int64_t ndraw, T* out_day, T* out_night,
+                              T* out_total, const T* observed, const T* weights, double* sse,
+                              double* count, int where, void* stream) {
+    if (!ctx) return MOD16_ERR_ARG;
+    if (!drivers || !dstride || !params || n < 0 || ndraw < 0)
+        return fail(ctx, MOD16_ERR_ARG, "mod16_et_static_batch: bad argument");
+    if (!out_day && !out_night && !out_total && !sse)
+        return fail(ctx, MOD16_ERR_ARG, "mod16_et_static_batch: no output requested");
+    if ((sse != nullptr) != (count != nullptr) || (sse && !observed))
+        return fail(ctx, MOD16_ERR_ARG, "mod16_et_static_batch: sse needs count and observed");
+    if (where == MOD16_DEVICE && sse && !out_total)
+        return fail(ctx, MOD16_ERR_ARG, "mod16_et_static_batch: sse on device pointers needs out_total as workspace");
+    StaticBatchArgs<T> a;
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < 14; ++k) {
+        if (!drivers[k]) return fail(ctx, MOD16_ERR_ARG, "mod16_et_static_batch: NULL driver");
+        if (dstride[k] != 0 && dstride[k] != 1) return fail(ctx, MOD16_ERR_ARG, "mod16_et_static_batch: driver stride must be 0 or 1");
+        a.drv[k] = drivers[k];
+        if (dstride[k]) a.dense_drv |= 1u << k;
+    }
+    a.n = n;
+    if (n == 0 || ndraw == 0) return MOD16_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // device-side pass over device pointers
+    auto run = [&](StaticBatchArgs<T> d, const T* dobs, const T* dw, double* dsse, double* dcnt,
+                   unsigned* dflags, hipStream_t st) -> int {
+        d.flags = dflags;
+        HIPCHK(ctx, hipMemsetAsync(dflags, 0, sizeof(unsigned) * ndraw, st));
+        const int gx = (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, (int64_t)ctx->cus * 8));
+        for (int64_t d0 = 0; d0 < ndraw; d0 += 32768) {
+            const unsigned gy = (unsigned)std::min<int64_t>(32768, ndraw - d0);
+            d.draw0 = d0;
+            hipLaunchKernelGGL((static_batch_flag_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
+            hipLaunchKernelGGL((static_batch_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
+        }
+        if (dsse)
+            hipLaunchKernelGGL((static_batch_sse_kernel<T>), dim3((unsigned)ndraw), dim3(kBlock), 0, st,
+                               d.out[2], dobs, dw, n, dsse, dcnt);
+        HIPCHK(ctx, hipGetLastError());
+        return MOD16_OK;
+    };
+    if (ndraw > 0x7fffffff) return fail(ctx, MOD16_ERR_ARG, "mod16_et_static_batch: too many draws");
+    if (where == MOD16_DEVICE) {
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        unsigned* dflags = nullptr;
+        // flags: a per-call allocation freed on the stream (asynchronous)
+        HIPCHK(ctx, hipMallocAsync(reinterpret_cast<void**>(&dflags), sizeof(unsigned) * ndraw, st));
+        a.params = params;
+        a.out[0] = out_day; a.out[1] = out_night; a.out[2] = out_total;
+        int rc = run(a, observed, weights, sse, count, dflags, st);
+        (void)hipFreeAsync(dflags, st);
+        return rc;
+    }
+    if (where != MOD16_HOST) return fail(ctx, MOD16_ERR_ARG, "mod16_et_static_batch: bad `where`");
+    // HOST: drivers / parameters resident once, outputs [ndraw][n] come back
+    if (!ctx->streams[0]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking));
+    hipStream_t st = ctx->streams[0];
+    const size_t per_arr = (((size_t)n * sizeof(T)) + 255) / 256 * 256;
+    const size_t per_out = (((size_t)n * (size_t)ndraw * sizeof(T)) + 255) / 256 * 256;
+    const bool want[3] = {out_day != nullptr, out_night != nullptr, out_total != nullptr || sse != nullptr};
+    T* const host_out[3] = {out_day, out_night, out_total};
+    const size_t par_b = (((size_t)ndraw * 11 * sizeof(T)) + 255) / 256 * 256;
+    const size_t red_b = (((size_t)ndraw * sizeof(double)) + 255) / 256 * 256;
+    const size_t flag_b = (((size_t)ndraw * sizeof(unsigned)) + 255) / 256 * 256;
+    const size_t total = per_arr * 16 + par_b + 2 * red_b + flag_b +
+                         per_out * ((int)want[0] + (int)want[1] + (int)want[2]);
+    char* base = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&base), total) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, MOD16_ERR_NOMEM, "mod16_et_static_batch: device memory for the [ndraw][n] outputs");
+    }
+    int rc = MOD16_OK;
+    auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == MOD16_OK) { rc = MOD16_ERR_HIP; ctx->err = hipGetErrorString(e); } };
+    char* cur = base;
+    auto take = [&](size_t b) { char* p = cur; cur += b; return p; };
+    StaticBatchArgs<T> d = a;
+    for (int k = 0; k < 14; ++k) {
+        T* dp = reinterpret_cast<T*>(take(per_arr));
+        chk(hipMemcpyAsync(dp, a.drv[k], sizeof(T) * (((a.dense_drv >> k) & 1u) ? n : 1), hipMemcpyHostToDevice, st));
+        d.drv[k] = dp;
+    }
+    T* dobs = reinterpret_cast<T*>(take(per_arr));
+    T* dw = reinterpret_cast<T*>(take(per_arr));
+    if (sse) chk(hipMemcpyAsync(dobs, observed, sizeof(T) * n, hipMemcpyHostToDevice, st));
+    if (sse && weights) chk(hipMemcpyAsync(dw, weights, sizeof(T) * n, hipMemcpyHostToDevice, st));
+    T* dpar = reinterpret_cast<T*>(take(par_b));
+    chk(hipMemcpyAsync(dpar, params, sizeof(T) * ndraw * 11, hipMemcpyHostToDevice, st));
+    d.params = dpar;
+    double* dsse = reinterpret_cast<double*>(take(red_b));
+    double* dcnt = reinterpret_cast<double*>(take(red_b));
+    unsigned* dflags = reinterpret_cast<unsigned*>(take(flag_b));
+    for (int k = 0; k < 3; ++k) d.out[k] = want[k] ? reinterpret_cast<T*>(take(per_out)) : nullptr;
+    if (rc == MOD16_OK) rc = run(d, dobs, (sse && weights) ? dw : nullptr, sse ? dsse : nullptr, dcnt, dflags, st);
+    if (rc == MOD16_OK) {
+        for (int k = 0; k < 3; ++k)
+            if (host_out[k]) chk(hipMemcpyAsync(host_out[k], d.out[k], sizeof(T) * n * ndraw, hipMemcpyDeviceToHost, st));
+        if (sse) {
+            chk(hipMemcpyAsync(sse, dsse, sizeof(double) * ndraw, hipMemcpyDeviceToHost, st));
+            chk(hipMemcpyAsync(count, dcnt, sizeof(double) * ndraw, hipMemcpyDeviceToHost, st));
+        }
+    }
+    chk(hipStreamSynchronize(st));
+    (void)hipFree(base);
+    return rc;
+}
+
+extern "C" int mod16_et_static_batch_f64(mod16_ctx* ctx, const double* const* drivers,
+                                         const int64_t* dstride, int64_t n, const double* params,
+                                         int64_t ndraw, double* out_day, double* out_night,
+                                         double* out_total, const double* observed,
+                                         const double* weights, double* sse, double* count,
+                                         int where, void* stream) {
+    return static_batch_entry<double>(ctx, drivers, dstride, n, params, ndraw, out_day, out_night,
+                                      out_total, observed, weights, sse, count, where, stream);
+}
+extern "C" int mod16_et_static_batch_f32(mod16_ctx* ctx, const float* const* drivers,
+                                         const int64_t* dstride, int64_t n, const float* params,
+                                         int64_t ndraw, float* out_day, float* out_night,
+                                         float* out_total, const float* observed,
+                                         const float* weights, double* sse, double* count,
+                                         int where, void* stream) {
+    return static_batch_entry<float>(ctx, drivers, dstride, n, params, ndraw, out_day, out_night,
+                                     out_total, observed, weights, sse, count, where, stream);
+}
+
 // ------------------------------------------------------------- diagnostics
 template <typename T>
 static int reduce_entry(mod16_ctx* ctx, const T* day, const T* night, int64_t n, double* diag,

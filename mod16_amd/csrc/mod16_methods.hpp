@@ -190,6 +190,97 @@ __global__ void __launch_bounds__(kBlock) static_kernel(const StaticArgs<T> a) {
     }
 }
 
+// ---- the calibration path batched over parameter vectors:
+// what MCMC / Sobol sampling hammers (reference calibration.py:907,
+// sensitivity.py:95) is MOD16._et(params, *drivers) for thousands of parameter
+// draws over the same few 10^4..10^6 tower-days. One launch evaluates every
+// (draw, pixel) pair: blockIdx.y = draw (its 11 parameters are block-uniform
+// scalar loads), x = pixels. Same pixel function as static_kernel, so row d of
+// the result is bit-identical to a single-draw call with params[d].
+template <typename T> struct StaticBatchArgs {
+    const T* drv[14];
+    const T* params;         // [ndraw][11], MOD16.required_parameters order
+    T* out[3];               // day, night, day + night: [ndraw][n], any may be NULL
+    int64_t n;
+    int64_t draw0;           // first draw of this launch (gridDim.y draws per launch)
+    uint32_t dense_drv;
+    unsigned* flags;         // [ndraw] words: bit 0 = any(g_surf > 0) for that draw
+};
+
+template <typename T>
+__device__ __forceinline__ void batch_load(const StaticBatchArgs<T>& a, int64_t draw, int64_t i,
+                                           PixelIn<T>& x, ClassPar<T>& p) {
+    auto d = [&](int k) { return ((a.dense_drv >> k) & 1u) ? a.drv[k][i] : a.drv[k][0]; };
+    const T* q = a.params + draw * 11;
+    x = {d(0), d(1), d(2), d(3), d(4), d(5), d(6), d(7), d(8), d(9), d(10), d(11), d(12), d(13)};
+    p.tmin_close = q[0]; p.tmin_open = q[1]; p.vpd_open = q[2]; p.vpd_close = q[3];
+    p.gl_sh = q[4]; p.gl_wv = q[5]; p.g_cut = q[6]; p.csl = q[7];
+    p.rbl_min = q[8]; p.rbl_max = q[9]; p.beta = q[10];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) static_batch_flag_kernel(const StaticBatchArgs<T> a) {
+    const int64_t draw = a.draw0 + blockIdx.y;
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    bool any = false;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += step) {
+#pragma clang fp contract(off)
+        PixelIn<T> x;
+        ClassPar<T> p;
+        batch_load(a, draw, i, x, p);
+        any = any || ((gsurf_static(p, x.tmin, x.vpd_d) / rcorr_exact(x.pa, x.t_d)) > T(0));
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(a.flags + draw, 1u);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) static_batch_kernel(const StaticBatchArgs<T> a) {
+    const int64_t draw = a.draw0 + blockIdx.y;
+    const bool any_gs = (a.flags[draw] & 1u) != 0;
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    const int64_t row = draw * a.n;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += step) {
+        PixelIn<T> x;
+        ClassPar<T> p;
+        batch_load(a, draw, i, x, p);
+        T day, night;
+        et_static_pixel(x, p, false, T(0), T(0), any_gs, day, night);
+        if (a.out[0]) a.out[0][row + i] = day;
+        if (a.out[1]) a.out[1][row + i] = night;
+        if (a.out[2]) a.out[2][row + i] = day + night;      // MOD16._et, :193
+    }
+}
+
+// Weighted sum of squared residuals of each draw against observations, NaN
+// pairs skipped: sse[d] = sum_i (w_i (total[d][i] - obs_i))^2, cnt[d] = pairs
+// used. One block per draw, fixed order (deterministic).
+template <typename T>
+__global__ void __launch_bounds__(kBlock) static_batch_sse_kernel(const T* total, const T* obs,
+                                                                  const T* weights, int64_t n,
+                                                                  double* sse, double* cnt) {
+    const T* row = total + (int64_t)blockIdx.x * n;
+    double s = 0.0, c = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += kBlock) {
+        const double r = ((double)row[i] - (double)obs[i]) * (weights ? (double)weights[i] : 1.0);
+        const bool ok = r == r;
+        s += ok ? r * r : 0.0;
+        c += ok ? 1.0 : 0.0;
+    }
+    __shared__ double sm[2][kBlock / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        c += __shfl_down(c, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = s; sm[1][threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) { s += sm[0][w]; c += sm[1][w]; }
+        sse[blockIdx.x] = s;
+        cnt[blockIdx.x] = c;
+    }
+}
+
 // ---- forward run on raw drivers
 template <typename T> struct RawArgs {
     const T* drv[14];         // enum mod16_raw_driver order

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import mod16_oracle as oracle
+from oracle import synth
 from parity import assert_parity
 
 pytestmark = pytest.mark.gpu
@@ -261,3 +262,69 @@ def test_static_calibration_path(m16, golden):
     day, night = m16.MOD16._evapotranspiration(params, *cold)
     assert_parity(day, f['day_cold'], 1e-11, 'day, no g_surf anywhere')
     assert_parity(night, f['night_cold'], 1e-11, 'night, no g_surf anywhere')
+
+
+def _calibration_inputs(n, seed, dtype=np.float64):
+    """Tower-day-like drivers and a spread of parameter vectors around the
+    reference's Collection 6.1 values (ranges: sensitivity.py:31-46)."""
+    rng = np.random.default_rng(seed)
+    _, drv = synth.drivers((n,), seed=seed, dtype=dtype)
+    lo = np.array([-10, 5, 400, 2000, 0.01, 0.01, 1e-6, 0.001, 20, 60, 50.0])
+    hi = np.array([-6, 15, 1000, 5000, 0.12, 0.12, 1e-4, 0.01, 70, 120, 800.0])
+    return drv, lo, hi, rng
+
+
+def test_batched_calibration_path(m16):
+    """SURVEY.md 8f N2: MOD16._et for many parameter vectors in one launch;
+    row d equals the single-vector interface bit for bit and the oracle's
+    restatement of the reference (mod16/__init__.py:162-382) within 1e-11."""
+    drv, lo, hi, rng = _calibration_inputs(5000, 41)
+    params = rng.uniform(lo, hi, (37, 11))
+    params[5, 7] = 0.0            # csl = 0: g_surf = 0 everywhere -> the whole-array switch is off
+    params[6, 1] = 400.0          # tmin_open far above every tmin: ramp 0 everywhere, same switch
+    et = m16.MOD16._et_batch(params, *drv)
+    assert et.shape == (37, 5000) and et.dtype == np.float64
+    day, night = m16.MOD16._et_batch(params, *drv, separate=True)
+    for d in (0, 5, 6, 17, 36):
+        one = m16.MOD16._et(list(params[d]), *drv)
+        assert np.array_equal(et[d], one, equal_nan=True)
+        d1, n1 = m16.MOD16._evapotranspiration(list(params[d]), *drv)
+        assert np.array_equal(day[d], d1, equal_nan=True)
+        assert np.array_equal(night[d], n1, equal_nan=True)
+        assert_parity(et[d], oracle.et_static(list(params[d]), *drv), 1e-11, 'draw %d' % d)
+    assert not np.array_equal(et[5], et[0])
+
+
+def test_batched_calibration_objective(m16):
+    """The fused residual reduction: sse / count per draw against numpy."""
+    drv, lo, hi, rng = _calibration_inputs(3001, 42)
+    params = rng.uniform(lo, hi, (9, 11))
+    et = m16.MOD16._et_batch(params, *drv)
+    obs = et[3] + rng.normal(0, 5, 3001)
+    obs[::97] = np.nan                      # gaps in the tower record
+    w = rng.uniform(0.5, 2.0, 3001)
+    sse, cnt = m16.MOD16._et_batch(params, *drv, observed=obs, weights=w)
+    r = (et - obs) * w
+    ok = np.isfinite(r)
+    assert np.array_equal(cnt, ok.sum(1).astype(float))
+    np.testing.assert_allclose(sse, np.where(ok, r * r, 0).sum(1), rtol=1e-12)
+    assert np.argmin(sse / cnt) == 3
+    sse1, cnt1 = m16.MOD16._et_batch(params, *drv, observed=obs)
+    r1 = et - obs
+    np.testing.assert_allclose(sse1, np.where(np.isfinite(r1), r1 * r1, 0).sum(1), rtol=1e-12)
+    # deterministic: same bits on a second call
+    sse2, _ = m16.MOD16._et_batch(params, *drv, observed=obs, weights=w)
+    assert np.array_equal(sse, sse2)
+
+
+def test_batched_calibration_float32_and_shapes(m16):
+    drv, lo, hi, rng = _calibration_inputs(12 * 40, 43, np.float32)
+    drv = [d.reshape(12, 40) for d in drv]
+    params = rng.uniform(lo, hi, (4, 11)).astype(np.float32)
+    et = m16.MOD16._et_batch(params, *drv)
+    assert et.shape == (4, 12, 40) and et.dtype == np.float32
+    for d in range(4):
+        assert np.array_equal(et[d], m16.MOD16._et(list(params[d]), *drv), equal_nan=True)
+    with pytest.raises(IndexError):
+        m16.MOD16._et_batch(np.zeros((3, 10)), *drv)
+    assert m16.MOD16._et_batch(np.zeros((0, 11)), *drv).shape == (0, 12, 40)
