@@ -35,7 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md)
-PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r01g_pmc_hbm_traffic.json')
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r01h_pmc_hbm_traffic.json')
 TILE = (1200, 1200)           # BASELINE.json configs[1], the CPU sample unit
 SEED = 16
 
@@ -117,6 +117,8 @@ def main():
     ap.add_argument('--cols', type=int, default=43200, help='global raster columns')
     ap.add_argument('--dtype', default='float64', choices=['float64', 'float32'])
     ap.add_argument('--math', default='fast', choices=['fast', 'exact'])
+    ap.add_argument('--placements', type=int, default=2,
+                    help='physical placements of the raster slab to choose from at set-up (1 = take the first)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--cpu-workers', type=int, default=16)
@@ -166,7 +168,9 @@ def main():
     offset, n = tiles.pixel_range(args.rows, args.cols, rank, world)
     total = args.rows * args.cols
 
-    cls, drv, day, night = eng.alloc_raster(n)      # one slab, staggered arrays
+    # one slab, staggered arrays; the faster of --placements physical placements
+    # (set-up, outside the timed region; RasterEngine.alloc_raster_placed)
+    (cls, drv, day, night), placement_ms = eng.alloc_raster_placed(n, candidates=args.placements)
     eng.synth(n, seed=SEED, step=0, pixel_offset=offset, out=(cls, drv))
     diag = torch.zeros(8, dtype=torch.float64, device='cuda')
 
@@ -304,6 +308,9 @@ def main():
                 'pixels': total, 'pixels_per_gpu': n, 'parallelism': 'tile-dp%d' % world,
                 'math': args.math, 'bplut': os.path.basename(COLLECTION61_BPLUT),
                 'step': 'fused ET kernel with in-kernel diagnostics + 1-block final sum + all-reduce(8 doubles)',
+                'slab_placement': {'candidates_ms': [round(m, 3) for m in placement_ms],
+                                   'note': 'rank 0; set-up, not timed: the faster of the candidate '
+                                           'physical placements of the raster slab is kept'},
             },
             'roofline': {
                 'bound': 'hbm', 'kernel': 'et_kernel_dyn<%s> (LDS-DMA, dynamic runs, in-kernel diagnostics)' % args.dtype, 'achieved': achieved,

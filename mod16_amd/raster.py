@@ -89,6 +89,43 @@ class RasterEngine(object):
         cls = slab[16 * per:16 * per + n]
         return cls, views[:14], views[14], views[15]
 
+    def alloc_raster_placed(self, n, candidates=2, launches=3, seed=16):
+        '''``alloc_raster`` with a choice of physical placement. Where in HBM
+        the slab lands changes the kernel time by 3-7 % (same binary, same
+        layout: the DRAM-side read latency differs between placements,
+        measured with the TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ counters; TLB
+        misses and the layout inside the allocation do not -- DESIGN.md section
+        6). So for a raster that stays resident (a time series, a bound
+        launch) it pays to look at more than one placement: this allocates up
+        to ``candidates`` slabs (holding the best so far, so every candidate
+        is a different region of HBM), times the production kernel on
+        synthetic drivers in each and keeps the fastest.
+
+        Returns ``((cls, drivers, day, night), report)`` with ``report`` =
+        milliseconds per launch of every candidate tried; the arrays hold the
+        synthetic fields of ``seed`` and are meant to be overwritten.'''
+        import gc
+        torch = _torch()
+        best, best_ms, report = None, None, []
+        for _ in range(max(1, int(candidates))):
+            try:
+                cand = self.alloc_raster(n)
+            except RuntimeError:          # no room for another candidate next to the best one
+                torch.cuda.empty_cache()
+                if best is None:
+                    raise
+                break
+            self.synth(n, seed=seed, out=(cand[0], cand[1]))
+            self.time_kernel(cand[0], cand[1], cand[2], cand[3], launches=1)
+            ms = self.time_kernel(cand[0], cand[1], cand[2], cand[3], launches=launches)
+            report.append(ms)
+            if best is None or ms < best_ms:
+                best, best_ms, cand = cand, ms, best
+            del cand                      # the slower slab goes back to the driver
+            gc.collect()
+            torch.cuda.empty_cache()
+        return best, report
+
     def empty(self, n, count=1):
         torch = _torch()
         return [torch.empty(n, dtype=self.dtype, device=self._dev()) for _ in range(count)]

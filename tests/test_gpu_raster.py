@@ -296,3 +296,18 @@ def test_slab_and_scattered_drivers_agree(env, dtype):
     assert torch.equal(torch.nan_to_num(day1), torch.nan_to_num(day2))
     assert torch.equal(torch.nan_to_num(night1), torch.nan_to_num(night2))
     assert torch.equal(d1, d2)
+
+
+def test_placed_allocation_returns_a_usable_slab(env):
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table)
+    n = 400000
+    (cls, drv, day, night), report = eng.alloc_raster_placed(n, candidates=3)
+    assert len(report) == 3 and all(ms > 0 for ms in report)
+    assert cls.numel() == n and len(drv) == 14 and day.numel() == n
+    eng.synth(n, seed=2, out=(cls, drv))
+    eng.run(cls, drv, day, night)
+    want_d, want_n = eng.run(cls, [d.clone() for d in drv])
+    eng.check()
+    assert torch.equal(torch.nan_to_num(day), torch.nan_to_num(want_d))
+    assert torch.equal(torch.nan_to_num(night), torch.nan_to_num(want_n))

@@ -50,6 +50,28 @@ def child(args):
     else:
         cls, drv, day, night = eng.alloc_raster(n)      # what bench.py does
         eng.synth(n, seed=16, out=(cls, drv))
+    if args.ab:
+        # same process, same buffers: contexts created under NAME=0 and NAME=1
+        # (process-to-process timing differs by several % with the physical
+        # placement of the slab, which confounds a process-per-variant A/B)
+        import numpy as np
+        engs = {}
+        for val in ('0', '1'):
+            os.environ[args.ab] = val
+            e = RasterEngine(table, dtype=args.dtype, math=math)
+            e.ctx = _lib.Context(0)
+            e.ctx.set_bplut(np.ascontiguousarray(table, np.float64))
+            engs[val] = e
+        del os.environ[args.ab]
+        res = {'0': [], '1': []}
+        for val in ('0', '1'):
+            engs[val].time_kernel(cls, drv, day, night, launches=2)
+        for _ in range(args.rounds):
+            for val in ('0', '1'):
+                res[val].append(round(engs[val].time_kernel(cls, drv, day, night, launches=args.launches), 3))
+        print(json.dumps({'ab': args.ab, 'ms_0': res['0'], 'ms_1': res['1'],
+                          'best_0': min(res['0']), 'best_1': min(res['1'])}))
+        return
     eng.time_kernel(cls, drv, day, night, launches=2)
     ms = [eng.time_kernel(cls, drv, day, night, launches=args.launches) for _ in range(args.rounds)]
     best = min(ms)
@@ -69,6 +91,7 @@ def main():
     ap.add_argument('--stagger', type=int, default=0, help='bytes between successive array bases (mod allocation)')
     ap.add_argument('--slab', type=int, default=-1, help='carve all arrays from one allocation with this extra offset (bytes)')
     ap.add_argument('--separate', action='store_true', help='one allocation per array instead of alloc_raster')
+    ap.add_argument('--ab', default='', help='environment switch (e.g. MOD16_PITCH) to A/B inside one process')
     ap.add_argument('libs', nargs='*')
     args = ap.parse_args()
     if args.child:
@@ -78,7 +101,7 @@ def main():
         env = dict(os.environ, MOD16_LIB=os.path.abspath(lib))
         subprocess.run([sys.executable, __file__, '--child', '--rows', str(args.rows),
                         '--launches', str(args.launches), '--rounds', str(args.rounds),
-                        '--dtype', args.dtype, '--math', args.math, '--stagger', str(args.stagger), '--slab', str(args.slab)] + (['--separate'] if args.separate else []), env=env, check=False)
+                        '--dtype', args.dtype, '--math', args.math, '--stagger', str(args.stagger), '--slab', str(args.slab)] + (['--separate'] if args.separate else []) + (['--ab', args.ab] if args.ab else []), env=env, check=False)
 
 
 if __name__ == '__main__':

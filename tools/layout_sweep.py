@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Kernel time against the layout of the raster slab inside ONE allocation of
+one process: extra bytes between successive arrays (stagger) and the offset of
+the first array inside the allocation (shift). Separates what the layout can
+control from what the physical placement of the allocation decides.
+
+  python tools/layout_sweep.py [rows=21600]
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from mod16_amd.raster import RasterEngine  # noqa: E402
+from mod16_amd.utils import restore_bplut, bplut_table  # noqa: E402
+from mod16_amd.models import COLLECTION61_BPLUT  # noqa: E402
+
+
+def main():
+    rows = int(sys.argv[1]) if len(sys.argv) > 1 else 21600
+    n = rows * 43200
+    eng = RasterEngine(bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250))
+    KiB = 1024
+    staggers = [33 * KiB, 1 * KiB, 5 * KiB, 9 * KiB, 17 * KiB, 65 * KiB, 129 * KiB, 257 * KiB, 1025 * KiB, 0, 4 * KiB]
+    shifts = [0, 1 << 20, 37 << 20]
+    max_per = (n * 8 + 4095) // 4096 * 4096 + max(staggers)
+    big = torch.empty(16 * max_per + n + max(shifts) + 4096, dtype=torch.uint8, device='cuda')
+    for shift in shifts:
+        for st in staggers:
+            per = (n * 8 + 4095) // 4096 * 4096 + st
+            base = big[shift:]
+            views = [base[k * per:k * per + n * 8].view(torch.float64) for k in range(16)]
+            cls = base[16 * per:16 * per + n]
+            drv, day, night = views[:14], views[14], views[15]
+            eng.synth(n, seed=16, out=(cls, drv))
+            eng.time_kernel(cls, drv, day, night, launches=2)
+            ms = eng.time_kernel(cls, drv, day, night, launches=8)
+            print(json.dumps({'shift': shift, 'stagger': st, 'ms': round(ms, 3)}), flush=True)
+
+
+if __name__ == '__main__':
+    main()
