@@ -170,7 +170,8 @@ def main():
 
     # one slab, staggered arrays; the faster of --placements physical placements
     # (set-up, outside the timed region; RasterEngine.alloc_raster_placed)
-    (cls, drv, day, night), placement_ms = eng.alloc_raster_placed(n, candidates=args.placements)
+    (cls, drv, day, night), placement_ms = eng.alloc_raster_placed(
+        n, candidates=1 if rehearsal else args.placements)   # rehearsal ranks share one GPU's memory
     eng.synth(n, seed=SEED, step=0, pixel_offset=offset, out=(cls, drv))
     diag = torch.zeros(8, dtype=torch.float64, device='cuda')
 
@@ -269,7 +270,10 @@ def main():
         # configs[3]: drivers of step s+1 produced on a second stream into a
         # two-slot ring while the kernel works on step s (producer = the
         # on-device generator standing in for an ingest stage)
-        del cls, drv, day, night
+        # everything that still refers into the slab: the bound launch keeps its
+        # tensors alive, the parity loops leave views behind
+        got = ref = h_cls = h_drv = None
+        del cls, drv, day, night, launch, step
         torch.cuda.empty_cache()
         bufs = eng.alloc_series(n)
         eng.run_series(n, 2, seed=SEED, pixel_offset=offset, buffers=bufs)   # warm-up
