@@ -117,8 +117,8 @@ def main():
     ap.add_argument('--cols', type=int, default=43200, help='global raster columns')
     ap.add_argument('--dtype', default='float64', choices=['float64', 'float32'])
     ap.add_argument('--math', default='fast', choices=['fast', 'exact'])
-    ap.add_argument('--placements', type=int, default=2,
-                    help='physical placements of the raster slab to choose from at set-up (1 = take the first)')
+    ap.add_argument('--no-tune', action='store_true',
+                    help='arrays of the raster slab back to back instead of the measured best spacing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--cpu-workers', type=int, default=16)
@@ -168,10 +168,13 @@ def main():
     offset, n = tiles.pixel_range(args.rows, args.cols, rank, world)
     total = args.rows * args.cols
 
-    # one slab, staggered arrays; the faster of --placements physical placements
-    # (set-up, outside the timed region; RasterEngine.alloc_raster_placed)
-    (cls, drv, day, night), placement_ms = eng.alloc_raster_placed(
-        n, candidates=1 if rehearsal else args.placements)   # rehearsal ranks share one GPU's memory
+    # one slab; the spacing between its arrays is chosen by measurement at set-up
+    # (outside the timed region; RasterEngine.alloc_raster_tuned)
+    if args.no_tune:
+        cls, drv, day, night = eng.alloc_raster(n)
+        layout = {'chosen_extra_bytes': 0}
+    else:
+        (cls, drv, day, night), layout = eng.alloc_raster_tuned(n)
     eng.synth(n, seed=SEED, step=0, pixel_offset=offset, out=(cls, drv))
     diag = torch.zeros(8, dtype=torch.float64, device='cuda')
 
@@ -275,7 +278,7 @@ def main():
         got = ref = h_cls = h_drv = None
         del cls, drv, day, night, launch, step
         torch.cuda.empty_cache()
-        bufs = eng.alloc_series(n)
+        bufs = eng.alloc_series(n, layout['chosen_extra_bytes'])
         eng.run_series(n, 2, seed=SEED, pixel_offset=offset, buffers=bufs)   # warm-up
         fence()
         t0 = time.perf_counter()
@@ -312,9 +315,8 @@ def main():
                 'pixels': total, 'pixels_per_gpu': n, 'parallelism': 'tile-dp%d' % world,
                 'math': args.math, 'bplut': os.path.basename(COLLECTION61_BPLUT),
                 'step': 'fused ET kernel with in-kernel diagnostics + 1-block final sum + all-reduce(8 doubles)',
-                'slab_placement': {'candidates_ms': [round(m, 3) for m in placement_ms],
-                                   'note': 'rank 0; set-up, not timed: the faster of the candidate '
-                                           'physical placements of the raster slab is kept'},
+                'slab_layout': dict(layout, note='rank 0; set-up, not timed: spacing between the arrays '
+                                                 'of the raster slab chosen by measurement'),
             },
             'roofline': {
                 'bound': 'hbm', 'kernel': 'et_kernel_dyn<%s> (LDS-DMA, dynamic runs, in-kernel diagnostics)' % args.dtype, 'achieved': achieved,

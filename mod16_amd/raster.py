@@ -75,56 +75,63 @@ class RasterEngine(object):
     #: is fine, 33 KiB measured best
     STAGGER_BYTES = 33 * 1024
 
-    def alloc_raster(self, n):
-        '''Device arrays for one raster of n pixels in the layout the fused
-        kernel streams best: class raster, 14 drivers and the two outputs are
-        carved out of ONE allocation with ``STAGGER_BYTES`` between successive
-        arrays, so their relative placement in HBM does not depend on the
-        allocator. Returns ``(cls, drivers, day, night)``.'''
-        torch = _torch()
+    def _carve(self, slab, n, per):
         esz = self.np_dtype.itemsize
-        per = (n * esz + 4095) // 4096 * 4096 + self.STAGGER_BYTES
-        slab = torch.empty(16 * per + n + 4096, dtype=torch.uint8, device=self._dev())
         views = [slab[k * per:k * per + n * esz].view(self.dtype) for k in range(16)]
         cls = slab[16 * per:16 * per + n]
         return cls, views[:14], views[14], views[15]
 
-    def alloc_raster_placed(self, n, candidates=2, launches=3, seed=16):
-        '''``alloc_raster`` with a choice of physical placement. Where in HBM
-        the slab lands changes the kernel time by 3-7 % (same binary, same
-        layout: the DRAM-side read latency differs between placements,
-        measured with the TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ counters; TLB
-        misses and the layout inside the allocation do not -- DESIGN.md section
-        6). So for a raster that stays resident (a time series, a bound
-        launch) it pays to look at more than one placement: this allocates up
-        to ``candidates`` slabs (holding the best so far, so every candidate
-        is a different region of HBM), times the production kernel on
-        synthetic drivers in each and keeps the fastest.
+    def _pitch(self, n, extra):
+        return (n * self.np_dtype.itemsize + 4095) // 4096 * 4096 + self.STAGGER_BYTES + int(extra)
 
-        Returns ``((cls, drivers, day, night), report)`` with ``report`` =
-        milliseconds per launch of every candidate tried; the arrays hold the
-        synthetic fields of ``seed`` and are meant to be overwritten.'''
-        import gc
+    def alloc_raster(self, n, extra=0):
+        '''Device arrays for one raster of n pixels in the layout the fused
+        kernel streams best: class raster, 14 drivers and the two outputs are
+        carved out of ONE allocation, successive arrays ``STAGGER_BYTES`` +
+        ``extra`` bytes apart on top of their size (see ``alloc_raster_tuned``
+        for ``extra``), so their relative placement in HBM does not depend on
+        the allocator. Returns ``(cls, drivers, day, night)``.'''
         torch = _torch()
-        best, best_ms, report = None, None, []
-        for _ in range(max(1, int(candidates))):
-            try:
-                cand = self.alloc_raster(n)
-            except RuntimeError:          # no room for another candidate next to the best one
-                torch.cuda.empty_cache()
-                if best is None:
-                    raise
-                break
+        per = self._pitch(n, extra)
+        slab = torch.empty(16 * per + n + 4096, dtype=torch.uint8, device=self._dev())
+        return self._carve(slab, n, per)
+
+    #: candidate extra spacings between the arrays of a raster [bytes] that
+    #: ``alloc_raster_tuned`` looks at
+    TUNE_EXTRA = tuple(int(g * 2 ** 30) for g in (0, 0.125, 0.25, 0.375, 0.5, 0.625, 0.75))
+
+    def alloc_raster_tuned(self, n, extras=None, launches=3, seed=16):
+        '''``alloc_raster`` with the distance between the arrays chosen by
+        measurement. The 16 streams of the fused kernel walk their arrays in
+        lock step, and how far apart the arrays lie -- at the scale of
+        hundreds of MiB -- changes the DRAM-side read latency and with it the
+        kernel time by 5-9 % (43200 x 21600 float64: 21.9-22.5 ms with the
+        arrays back to back, 21.0-21.2 ms with 0.5 GiB between them;
+        DESIGN.md section 6, ``tools/layout_sweep.py``). Which spacing is best
+        depends on the raster size and somewhat on where the allocation
+        landed, so for a raster that stays resident this allocates one slab
+        large enough for every candidate in ``extras`` (bytes, default
+        ``TUNE_EXTRA``), times the production kernel on synthetic drivers
+        for each and keeps the fastest -- a few launches per candidate,
+        once, at set-up.
+
+        Returns ``((cls, drivers, day, night), report)``; ``report`` maps each
+        extra spacing to its milliseconds per launch and names the choice.
+        The arrays hold the synthetic fields of ``seed``, to be overwritten.'''
+        torch = _torch()
+        extras = [int(e) for e in (self.TUNE_EXTRA if extras is None else extras)]
+        per_max = self._pitch(n, max(extras))
+        slab = torch.empty(16 * per_max + n + 4096, dtype=torch.uint8, device=self._dev())
+        times = {}
+        for e in extras:
+            cand = self._carve(slab, n, self._pitch(n, e))
             self.synth(n, seed=seed, out=(cand[0], cand[1]))
             self.time_kernel(cand[0], cand[1], cand[2], cand[3], launches=1)
-            ms = self.time_kernel(cand[0], cand[1], cand[2], cand[3], launches=launches)
-            report.append(ms)
-            if best is None or ms < best_ms:
-                best, best_ms, cand = cand, ms, best
-            del cand                      # the slower slab goes back to the driver
-            gc.collect()
-            torch.cuda.empty_cache()
-        return best, report
+            times[e] = self.time_kernel(cand[0], cand[1], cand[2], cand[3], launches=launches)
+        best = min(times, key=times.get)
+        report = {'extra_bytes_ms': {str(e): round(ms, 4) for e, ms in times.items()},
+                  'chosen_extra_bytes': best}
+        return self._carve(slab, n, self._pitch(n, best)), report
 
     def empty(self, n, count=1):
         torch = _torch()
@@ -218,11 +225,11 @@ class RasterEngine(object):
             n, optr[0], optr[1], optr[2], optr[3], int(self.math), _lib.DEVICE, self._stream()))
         return out
 
-    def alloc_series(self, n):
+    def alloc_series(self, n, extra=0):
         '''Device buffers of ``run_series``: class raster, the two-slot driver
-        ring and two output pairs.'''
+        ring and two output pairs (``extra``: see ``alloc_raster``).'''
         torch = _torch()
-        a, b = self.alloc_raster(n), self.alloc_raster(n)
+        a, b = self.alloc_raster(n, extra), self.alloc_raster(n, extra)
         return {'cls': a[0], 'ring': [a[1], b[1]], 'outs': [[a[2], a[3]], [b[2], b[3]]]}
 
     def run_series(self, n, steps, seed=16, pixel_offset=0, on_step=None, buffers=None):

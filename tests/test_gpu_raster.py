@@ -298,12 +298,16 @@ def test_slab_and_scattered_drivers_agree(env, dtype):
     assert torch.equal(d1, d2)
 
 
-def test_placed_allocation_returns_a_usable_slab(env):
+def test_tuned_allocation_returns_a_usable_slab(env):
     torch, RasterEngine, table = env
     eng = RasterEngine(table)
     n = 400000
-    (cls, drv, day, night), report = eng.alloc_raster_placed(n, candidates=3)
-    assert len(report) == 3 and all(ms > 0 for ms in report)
+    extras = (0, 1 << 20, 3 << 20)
+    (cls, drv, day, night), report = eng.alloc_raster_tuned(n, extras=extras)
+    assert sorted(report['extra_bytes_ms']) == sorted(str(e) for e in extras)
+    assert report['chosen_extra_bytes'] in extras
+    gaps = {drv[k + 1].data_ptr() - drv[k].data_ptr() for k in range(13)}
+    assert gaps == {eng._pitch(n, report['chosen_extra_bytes'])}
     assert cls.numel() == n and len(drv) == 14 and day.numel() == n
     eng.synth(n, seed=2, out=(cls, drv))
     eng.run(cls, drv, day, night)

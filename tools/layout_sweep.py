@@ -23,8 +23,20 @@ def main():
     n = rows * 43200
     eng = RasterEngine(bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250))
     KiB = 1024
-    staggers = [33 * KiB, 1 * KiB, 5 * KiB, 9 * KiB, 17 * KiB, 65 * KiB, 129 * KiB, 257 * KiB, 1025 * KiB, 0, 4 * KiB]
-    shifts = [0, 1 << 20, 37 << 20]
+    MiB = 1024 * KiB
+    if len(sys.argv) > 2 and sys.argv[2] == 'coarse':
+        staggers = [33 * KiB] + [m * MiB + 33 * KiB for m in (2, 3, 5, 8, 17, 32, 97, 128, 512, 1024)] + [33 * KiB]
+        shifts = [0]
+    elif len(sys.argv) > 2 and sys.argv[2] == 'fine':
+        lo, hi, step = (int(x) for x in sys.argv[3:6])          # MiB
+        staggers = [m * MiB + 33 * KiB for m in range(lo, hi + 1, step)]
+        shifts = [0]
+    elif len(sys.argv) > 2 and sys.argv[2] == 'gib':
+        staggers = [m * 128 * MiB + 33 * KiB for m in range(0, 25)]
+        shifts = [0]
+    else:
+        staggers = [33 * KiB, 1 * KiB, 5 * KiB, 9 * KiB, 17 * KiB, 65 * KiB, 129 * KiB, 257 * KiB, 1025 * KiB, 0, 4 * KiB]
+        shifts = [0, 1 << 20, 37 << 20]
     max_per = (n * 8 + 4095) // 4096 * 4096 + max(staggers)
     big = torch.empty(16 * max_per + n + max(shifts) + 4096, dtype=torch.uint8, device='cuda')
     for shift in shifts:
@@ -37,7 +49,7 @@ def main():
             eng.synth(n, seed=16, out=(cls, drv))
             eng.time_kernel(cls, drv, day, night, launches=2)
             ms = eng.time_kernel(cls, drv, day, night, launches=8)
-            print(json.dumps({'shift': shift, 'stagger': st, 'ms': round(ms, 3)}), flush=True)
+            print(json.dumps({'shift': shift, 'stagger': st, 'pitch_GiB': round(per / 2**30, 4), 'ms': round(ms, 3)}), flush=True)
 
 
 if __name__ == '__main__':
