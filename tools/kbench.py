@@ -48,7 +48,7 @@ def child(args):
         cls, drv = eng.synth(n, seed=16)
         day, night = eng.empty(n, 2)
     else:
-        cls, drv, day, night = eng.alloc_raster(n)      # what bench.py does
+        cls, drv, day, night = eng.alloc_raster(n, args.extra_mib << 20)
         eng.synth(n, seed=16, out=(cls, drv))
     if args.ab:
         # same process, same buffers: contexts created under NAME=0 and NAME=1
@@ -56,21 +56,21 @@ def child(args):
         # placement of the slab, which confounds a process-per-variant A/B)
         import numpy as np
         engs = {}
-        for val in ('0', '1'):
+        vals = args.ab_values.split(',')
+        for val in vals:
             os.environ[args.ab] = val
             e = RasterEngine(table, dtype=args.dtype, math=math)
             e.ctx = _lib.Context(0)
             e.ctx.set_bplut(np.ascontiguousarray(table, np.float64))
             engs[val] = e
         del os.environ[args.ab]
-        res = {'0': [], '1': []}
-        for val in ('0', '1'):
+        res = {v: [] for v in vals}
+        for val in vals:
             engs[val].time_kernel(cls, drv, day, night, launches=2)
         for _ in range(args.rounds):
-            for val in ('0', '1'):
+            for val in vals:
                 res[val].append(round(engs[val].time_kernel(cls, drv, day, night, launches=args.launches), 3))
-        print(json.dumps({'ab': args.ab, 'ms_0': res['0'], 'ms_1': res['1'],
-                          'best_0': min(res['0']), 'best_1': min(res['1'])}))
+        print(json.dumps({'ab': args.ab, 'ms': res, 'best': {v: min(res[v]) for v in vals}}))
         return
     eng.time_kernel(cls, drv, day, night, launches=2)
     ms = [eng.time_kernel(cls, drv, day, night, launches=args.launches) for _ in range(args.rounds)]
@@ -92,6 +92,8 @@ def main():
     ap.add_argument('--slab', type=int, default=-1, help='carve all arrays from one allocation with this extra offset (bytes)')
     ap.add_argument('--separate', action='store_true', help='one allocation per array instead of alloc_raster')
     ap.add_argument('--ab', default='', help='environment switch (e.g. MOD16_PITCH) to A/B inside one process')
+    ap.add_argument('--ab-values', default='0,1', help='values of the --ab switch to compare')
+    ap.add_argument('--extra-mib', type=int, default=0, help='extra distance between the arrays of the slab [MiB]')
     ap.add_argument('libs', nargs='*')
     args = ap.parse_args()
     if args.child:
@@ -101,7 +103,7 @@ def main():
         env = dict(os.environ, MOD16_LIB=os.path.abspath(lib))
         subprocess.run([sys.executable, __file__, '--child', '--rows', str(args.rows),
                         '--launches', str(args.launches), '--rounds', str(args.rounds),
-                        '--dtype', args.dtype, '--math', args.math, '--stagger', str(args.stagger), '--slab', str(args.slab)] + (['--separate'] if args.separate else []) + (['--ab', args.ab] if args.ab else []), env=env, check=False)
+                        '--dtype', args.dtype, '--math', args.math, '--stagger', str(args.stagger), '--slab', str(args.slab)] + (['--separate'] if args.separate else []) + (['--ab', args.ab, '--ab-values', args.ab_values] if args.ab else []) + ['--extra-mib', str(args.extra_mib)], env=env, check=False)
 
 
 if __name__ == '__main__':
