@@ -35,7 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md)
-PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r01h_pmc_hbm_traffic.json')
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r01i_pmc_hbm_traffic.json')
 TILE = (1200, 1200)           # BASELINE.json configs[1], the CPU sample unit
 SEED = 16
 
@@ -320,7 +320,7 @@ def main():
                                                  'of the raster slab chosen by measurement'),
             },
             'roofline': {
-                'bound': 'hbm', 'kernel': 'et_kernel_dyn<%s> (LDS-DMA, dynamic runs, in-kernel diagnostics)' % args.dtype, 'achieved': achieved,
+                'bound': 'hbm', 'kernel': 'et_stream_kernel<%s, totals> (LDS-DMA, dynamic runs, in-kernel diagnostics)' % args.dtype, 'achieved': achieved,
                 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
                 'traffic': pmc_traffic(n, args.dtype) if args.math == 'fast' else None,
                 'traffic_source': os.path.relpath(PMC_TRAFFIC, ROOT), 'traffic_unit': 'bytes per launch',

@@ -29,9 +29,8 @@ constexpr size_t kStagger = 33 * 1024;              // see RasterEngine.STAGGER_
 struct mod16_ctx {
     int device = 0;
     int cus = 256;
-    int grid_mult = 64;              // blocks per CU in the grid-stride launch (measured best)
-    bool use_dma = true;             // LDS-DMA prefetch form of the production kernel
-    int use_dyn = 1;                 // dynamic run claiming (MOD16_DYN=0: static grid-stride)
+    int grid_mult = 64;              // blocks per CU in the grid-stride launches of the plain kernels
+    bool use_dma = true;             // production pipeline (mod16_stream.hpp); MOD16_NO_DMA=1: plain kernels only
     int use_pitch = 1;               // scalar base + pitch addressing for slab layouts (MOD16_PITCH=0: off)
     unsigned long long* dyn_counters = nullptr;   // ring of ticket counters, 128 B apart
     int dyn_next = 0;
@@ -140,7 +139,6 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
         ctx->cus = prop.multiProcessorCount;
         if (const char* g = getenv("MOD16_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(g));
         if (const char* g = getenv("MOD16_NO_DMA")) ctx->use_dma = atoi(g) == 0;
-        if (const char* g = getenv("MOD16_DYN")) ctx->use_dyn = atoi(g);
         if (const char* g = getenv("MOD16_PITCH")) ctx->use_pitch = atoi(g);
         HIPCHK(ctx, hipMalloc(&ctx->dyn_counters, 64 * 128));
         const size_t nlut = MOD16_LUT_ROWS * kLutCols;
@@ -271,11 +269,14 @@ template <typename T>
 static int reduce_entry(mod16_ctx* ctx, const T* day, const T* night, int64_t n, double* diag,
                         double* ddiag, void* stream);
 
-// The production pipeline for the other dense class-raster forms
-// (mod16_stream.hpp). s.n must be a multiple of the vector width.
+// The production pipeline for dense class rasters (mod16_stream.hpp). s.n must
+// be a multiple of the vector width. ddiag != NULL: also the fixed-order sum
+// of the per-run diagnostics partials -> ddiag (8 doubles on the device), over
+// n_valid_total pixels.
 template <typename T, int MODE>
-static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st) {
+static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double* ddiag = nullptr) {
     constexpr int V = VecOf<T>::v;
+    constexpr int kStage = 1024;
     s.lut64 = ctx->lut64;
     s.tab = ctx->tab64;
     s.status = ctx->status;
@@ -284,12 +285,34 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st) {
     s.dyn_counter = ctr;
     const int64_t npiece = (s.n / V + 63) / 64;
     const int64_t nruns = (npiece + kDynRun - 1) / kDynRun;
+    // persistent waves: 2 blocks per CU is what the LDS slots allow
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(
         (nruns + (kBlock / 64) - 1) / (kBlock / 64), (int64_t)ctx->cus * 2));
-    int rc = reserve_diag(ctx, nruns + 1024);
+    int rc = reserve_diag(ctx, nruns + kStage);
     if (rc != MOD16_OK) return rc;
     s.diag_partial = ctx->diag_partial;
-    hipLaunchKernelGGL((et_stream_kernel<T, MODE>), dim3(grid), dim3(kBlock), 0, st, s);
+    // equally spaced wide arrays (one slab): scalar base + k * pitch
+    constexpr int NW = StreamSpec<MODE>::NW;
+    const ptrdiff_t pitch_b = reinterpret_cast<const char*>(s.wide[1]) - reinterpret_cast<const char*>(s.wide[0]);
+    bool pitched = ctx->use_pitch && pitch_b % (ptrdiff_t)sizeof(T) == 0;
+    for (int k = 2; k < NW && pitched; ++k)
+        pitched = reinterpret_cast<const char*>(s.wide[k]) - reinterpret_cast<const char*>(s.wide[0]) == k * pitch_b;
+    s.wide_pitch = pitched ? pitch_b / (ptrdiff_t)sizeof(T) : 0;
+    if (pitched) hipLaunchKernelGGL((et_stream_kernel<T, MODE, true>), dim3(grid), dim3(kBlock), 0, st, s);
+    else hipLaunchKernelGGL((et_stream_kernel<T, MODE, false>), dim3(grid), dim3(kBlock), 0, st, s);
+    if (ddiag) {
+        const double* fin = ctx->diag_partial;
+        int64_t count = nruns;
+        if (count > 4 * kStage) {   // two-level: 1024 fixed slices, then one block
+            double* stage = ctx->diag_partial + nruns * kDiag;
+            const int64_t per = (count + kStage - 1) / kStage;
+            hipLaunchKernelGGL(diag_stage_kernel, dim3(kStage), dim3(kBlock), 0, st, fin, count, per, stage);
+            fin = stage;
+            count = (count + per - 1) / per;
+        }
+        hipLaunchKernelGGL(diag_final_fused_kernel, dim3(1), dim3(kFinalBlock), 0, st,
+                           fin, (int)count, s.n, ddiag);
+    }
     return MOD16_OK;
 }
 
@@ -320,16 +343,18 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
     }
     const bool dense = a.dense_drv == 0x3fffu;
     const int64_t nbody = aligned ? (a.n / V) * V : 0;
-    const bool dma = ctx->use_dma && lut && fast && !sep && dense && a.out[0] && a.out[1];   // sep covers PET too
     bool fused_diag = false;
-    // the same pipeline for PET / separate components (mod16_stream.hpp)
+    // dense class rasters with one of the supported output sets take the
+    // production pipeline (mod16_stream.hpp), everything else the plain kernel
     int smode = -1;
-    if (ctx->use_dma && ctx->use_dyn && lut && fast && dense && sep && !ddiag) {
+    if (ctx->use_dma && lut && fast && dense) {
         bool all6 = true, none6 = true;
         for (int k = 2; k < 8; ++k) { all6 = all6 && a.out[k]; none6 = none6 && !a.out[k]; }
         const bool tot = a.out[0] && a.out[1], notot = !a.out[0] && !a.out[1];
         const bool pet = a.out[8] && a.out[9], nopet = !a.out[8] && !a.out[9];
-        if (tot && none6 && pet) smode = kStreamPet;
+        if (tot && none6 && nopet) smode = kStreamTotals;
+        else if (ddiag) smode = -1;      // the fused diagnostics belong to the totals form
+        else if (tot && none6 && pet) smode = kStreamPet;
         else if (tot && all6 && nopet) smode = kStreamSep8;
         else if (notot && all6 && nopet) smode = kStreamSep6;
     }
@@ -340,7 +365,11 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
         s.bytes[0] = a.cls;
         s.n = nbody;
         int rc;
-        if (smode == kStreamPet) {
+        if (smode == kStreamTotals) {
+            s.out[0] = a.out[0]; s.out[1] = a.out[1];
+            fused_diag = ddiag && nbody == a.n;
+            rc = launch_stream<T, kStreamTotals>(ctx, s, st, fused_diag ? ddiag : nullptr);
+        } else if (smode == kStreamPet) {
             s.out[0] = a.out[0]; s.out[1] = a.out[1]; s.out[2] = a.out[8]; s.out[3] = a.out[9];
             rc = launch_stream<T, kStreamPet>(ctx, s, st);
         } else if (smode == kStreamSep8) {
@@ -354,69 +383,7 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
     } else if (nbody) {
         EtArgs<T> b = a;
         b.n = nbody;
-        const int grid = dma ? (int)std::max<int64_t>(1, std::min<int64_t>(
-                                   (nbody / V + kDmaBlock - 1) / kDmaBlock, (int64_t)ctx->cus * ctx->grid_mult))
-                             : grid_for(ctx, nbody / V);
-        if (dma) {
-            // One production kernel: it always accumulates the per-block
-            // diagnostics partials while the outputs are in registers (~2 % of
-            // its VALU work; the variant without them compiles to 50-60 more
-            // VGPRs and runs slower); the final sum runs only when asked for.
-            int rc = reserve_diag(ctx, grid);
-            if (rc != MOD16_OK) return rc;
-            b.diag_partial = ctx->diag_partial;
-            if (ctx->use_dyn) {
-                // persistent waves, runs handed out through a ticket counter; the
-                // diagnostics partials are per run (schedule-independent)
-                unsigned long long* ctr = ctx->dyn_counters + 16 * (ctx->dyn_next++ % 64);
-                HIPCHK(ctx, hipMemsetAsync(ctr, 0, sizeof(unsigned long long), st));
-                b.dyn_counter = ctr;
-                const int64_t npiece = (nbody / V + 63) / 64;
-                const int64_t nruns = (npiece + kDynRun - 1) / kDynRun;
-                const int dgrid = (int)std::max<int64_t>(1, std::min<int64_t>(
-                    (nruns + (kBlock / 64) - 1) / (kBlock / 64), (int64_t)ctx->cus * 2));
-                constexpr int kStage = 1024;
-                rc = reserve_diag(ctx, nruns + kStage);
-                if (rc != MOD16_OK) return rc;
-                b.diag_partial = ctx->diag_partial;
-                // equally spaced driver arrays (one slab): scalar base + k * pitch
-                const ptrdiff_t pitch_b = reinterpret_cast<const char*>(b.drv[1]) -
-                                          reinterpret_cast<const char*>(b.drv[0]);
-                bool pitched = ctx->use_pitch && pitch_b % (ptrdiff_t)sizeof(T) == 0;
-                for (int k = 2; k < 14 && pitched; ++k)
-                    pitched = reinterpret_cast<const char*>(b.drv[k]) -
-                              reinterpret_cast<const char*>(b.drv[0]) == k * pitch_b;
-                b.drv_pitch = pitched ? pitch_b / (ptrdiff_t)sizeof(T) : 0;
-                if (pitched)
-                    hipLaunchKernelGGL((et_kernel_dyn<T, true, true, true>), dim3(dgrid), dim3(kDmaBlock), 0, st, b);
-                else
-                    hipLaunchKernelGGL((et_kernel_dyn<T, true, true, false>), dim3(dgrid), dim3(kDmaBlock), 0, st, b);
-                if (ddiag && nbody == a.n) {
-                    const double* fin = ctx->diag_partial;
-                    int64_t count = nruns;
-                    if (count > 4 * kStage) {   // two-level: 1024 fixed slices, then one block
-                        double* stage = ctx->diag_partial + nruns * kDiag;
-                        const int64_t per = (count + kStage - 1) / kStage;
-                        hipLaunchKernelGGL(diag_stage_kernel, dim3(kStage), dim3(kBlock), 0, st,
-                                           fin, count, per, stage);
-                        fin = stage;
-                        count = (count + per - 1) / per;
-                    }
-                    hipLaunchKernelGGL(diag_final_fused_kernel, dim3(1), dim3(kFinalBlock), 0, st,
-                                       fin, (int)count, a.n, ddiag);
-                    fused_diag = true;
-                }
-            } else {
-            hipLaunchKernelGGL((et_kernel_dma<T, true, true>), dim3(grid), dim3(kDmaBlock), 0, st, b);
-            if (ddiag && nbody == a.n) {
-                hipLaunchKernelGGL(diag_final_fused_kernel, dim3(1), dim3(kFinalBlock), 0, st,
-                                   ctx->diag_partial, grid, a.n, ddiag);
-                fused_diag = true;
-            }
-            }
-        } else {
-            launch_variant<T, V>(b, lut, fast, sep, dense, grid, st);
-        }
+        launch_variant<T, V>(b, lut, fast, sep, dense, grid_for(ctx, nbody / V), st);
     }
     if (nbody < a.n) {   // ragged tail (or unaligned input): scalar variant
         EtArgs<T> t = a;
@@ -845,7 +812,7 @@ static int raw_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* raw,
     auto launch = [&](const RawArgs<T>& d, hipStream_t st, const T* host_hours) -> int {
         constexpr int V = VecOf<T>::v;
         auto al = [](const void* p, size_t to) { return reinterpret_cast<uintptr_t>(p) % to == 0; };
-        bool ok = fast && ctx->use_dma && ctx->use_dyn && d.dense_drv == 0x3fffu && d.out[0] && d.out[1];
+        bool ok = fast && ctx->use_dma && d.dense_drv == 0x3fffu && d.out[0] && d.out[1];
         for (int k = 0; k < 14 && ok; ++k) ok = al(d.drv[k], 16);
         ok = ok && al(d.fpar_pct, V) && al(d.lai_x10, V) && al(d.cls, V) && al(d.out[0], 16) && al(d.out[1], 16);
         int mode = kStreamRaw;

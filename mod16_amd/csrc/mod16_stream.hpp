@@ -1,31 +1,67 @@
-// The production pipeline of et_kernel_dyn (mod16_kernels.hpp) for the other
-// dense class-raster forms of the forward run: persistent waves that claim runs
-// of 64-vector pieces from a ticket counter, one LDS slot per wave filled by
-// LDS-DMA one iteration ahead, BPLUT + exp/log tables in LDS, non-temporal
-// 16-byte stores, per-run diagnostics partials. What varies is the set of
-// arrays and the pixel function:
+// The production pipeline of the forward run for dense class rasters
+// (16-byte-aligned arrays, BPLUT parameters, FAST arithmetic): one kernel
+// template over the set of arrays and the pixel function.
 //
-//   kStreamPet            14 drivers + class -> day, night, PET day, PET night
+//   kStreamTotals         14 drivers + class -> day, night          (129 B/pixel in float64)
+//                         MOD16.evapotranspiration(), mod16/__init__.py:675-793
+//   kStreamPet            ... -> day, night, PET day, PET night      (145)
 //                         (reference README.md:404-424, :546-602)
-//   kStreamSep8 / Sep6    14 drivers + class -> [day, night,] the six components
+//   kStreamSep8 / Sep6    ... -> [day, night,] the six components    (177 / 161)
 //                         (separate=True, mod16/__init__.py:789-793)
 //   kStreamRaw*           14 raw drivers + class + uint8 fPAR/LAI [+ hours of
-//                         daylight] -> day, night [, 8-day total]
+//                         daylight] -> day, night [, 8-day total]    (131 / 139 / 147)
 //                         (calibration.py:380-423, verify2.py:113-115)
 //
-// Algorithmic bytes per pixel (float64): PET 145, Sep8 177, Sep6 161,
-// Raw 131, RawTotal 139, RawTotalHours 147.
+// How the bytes move. At ~175-200 VGPRs only two waves fit a SIMD, too few to
+// hide HBM latency behind other waves, and there is no room for a second
+// register set to prefetch into. So each wave owns one LDS slot (NW KiB + NB x
+// 256 B) and streams the NEXT iteration's NW driver vectors and NB byte
+// vectors into it with global_load_lds (LDS-DMA, no VGPR destination) while it
+// computes the current one:
+//     counted s_waitcnt vmcnt(NOUT) -> ds_read_b128 x NW -> issue next DMA ->
+//     compute -> NOUT non-temporal 16-byte stores.
+// The slot is private to the wave that fills it, so no barrier is involved: the
+// wave's own counted vmcnt orders its ds_reads behind its DMA. Every byte is
+// touched once, so both directions use the non-temporal policy (+3-4 % on this
+// read/write mix, profiles/r01_probe_streams_hbm_roof.txt).
+//
+// Who takes which pixels. Waves are persistent (the grid is what fits the
+// chip: 2 blocks per CU) and every WAVE claims runs of kDynRun consecutive
+// 64-vector pieces (kDynRun KiB per array) from a global ticket counter, one
+// run ahead, so pieces are handed out in address order to whichever wave is
+// ready -- the order a one-shot launch gives (4-5 % faster than a static
+// grid-stride for a 14-read + 2-write mix) without giving up the LDS-DMA
+// pipeline. The claim is an asm atomic issued by lane 0 in the first
+// iteration of a run, in front of that iteration's DMA; the loop's counted
+// vmcnt of the next iteration retires it, no extra wait exists.
+//
+// Diagnostics (sums, NaN counts, maxima of day / night) are accumulated while
+// the outputs are in registers and flushed per RUN: a run is always the same
+// pixels in the same order whichever wave claimed it, so the partials -- and
+// the fixed-order sums over them -- do not depend on the dynamic schedule.
+// (The variant without the accumulation compiles to 50-60 more VGPRs and runs
+// slower, so there is only this one.)
 #pragma once
 #include "mod16_kernels.hpp"
 
 namespace mod16 {
 
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+constexpr int kDmaNt = 2;            // cache-policy bits of the LDS-DMA loads: nt
+#ifndef MOD16_DYN_RUN
+#define MOD16_DYN_RUN 16             // runs of 2-4 pieces saturate the ticket counter (88 atomics/us)
+#endif
+constexpr int kDynRun = MOD16_DYN_RUN;
+
 enum StreamMode {
-    kStreamPet = 0, kStreamSep8, kStreamSep6, kStreamRaw, kStreamRawTotal, kStreamRawTotalHours
+    kStreamPet = 0, kStreamSep8, kStreamSep6, kStreamRaw, kStreamRawTotal, kStreamRawTotalHours,
+    kStreamTotals
 };
 
 // NW 16-byte-per-lane arrays, NB byte arrays (class raster first), NOUT outputs
 template <int MODE> struct StreamSpec;
+template <> struct StreamSpec<kStreamTotals> { static constexpr int NW = 14, NB = 1, NOUT = 2; };
 template <> struct StreamSpec<kStreamPet> { static constexpr int NW = 14, NB = 1, NOUT = 4; };
 template <> struct StreamSpec<kStreamSep8> { static constexpr int NW = 14, NB = 1, NOUT = 8; };
 template <> struct StreamSpec<kStreamSep6> { static constexpr int NW = 14, NB = 1, NOUT = 6; };
@@ -44,6 +80,7 @@ template <typename T> struct StreamArgs {
     double* diag_partial;      // [runs][8]
     unsigned long long* dyn_counter;
     double hours;              // kStreamRawTotal: the (scalar) hours of daylight
+    int64_t wide_pitch;        // PITCHED: wide[k] = wide[0] + k * wide_pitch (elements)
 };
 static_assert(__builtin_offsetof(StreamArgs<double>, wide) == 0 &&
               __builtin_offsetof(StreamArgs<double>, bytes) == 128 &&
@@ -51,9 +88,12 @@ static_assert(__builtin_offsetof(StreamArgs<double>, wide) == 0 &&
               __builtin_offsetof(StreamArgs<float>, bytes) == 128,
               "et_stream_kernel reads wide[] / bytes[] at fixed kernel-argument offsets");
 
-// One asm statement reads the whole slot and waits for it (see et_kernel_dma
-// for why these are not ordinary LDS loads). Byte arrays land one dword per
-// lane (sub-dword LDS-DMA, measured), 256 B per array behind the wide ones.
+// One asm statement reads the whole slot and waits for it (lgkmcnt(0)): as
+// ordinary LDS loads hipcc would put a full s_waitcnt vmcnt(0) in front of them
+// (it pairs them with the LDS-DMA), which would also wait for the stores just
+// issued. The returned reads are what allows the refill of the slot (WAR).
+// Byte arrays land one dword per lane (sub-dword LDS-DMA, measured), 256 B per
+// array behind the wide ones.
 #define MOD16_RD(i, off) "ds_read_b128 %[w" #i "], %[base] offset:" #off "\n\t"
 #define MOD16_RD14                                                                              \
     "ds_read_b128 %[w0], %[base]\n\t" MOD16_RD(1, 1024) MOD16_RD(2, 2048) MOD16_RD(3, 3072)     \
@@ -102,7 +142,10 @@ template <> struct SlotRead<15, 3> {
 #undef MOD16_RD14
 #undef MOD16_W14
 
-template <typename T, int MODE>
+// PITCHED: the wide arrays are equally spaced (one slab, as
+// RasterEngine.alloc_raster lays them out): array k's address is wide[0] +
+// k * pitch by two scalar adds instead of a pointer load.
+template <typename T, int MODE, bool PITCHED = false>
 __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a) {
     typedef StreamSpec<MODE> S;
     constexpr int V = 16 / (int)sizeof(T);
@@ -147,9 +190,11 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
         typedef const __attribute__((address_space(4))) char* kptr_t;
         kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ka));
+        if constexpr (!PITCHED) {
 #pragma unroll
-        for (int k = 0; k < NW; ++k)
-            p.w[k] = *reinterpret_cast<const char* const __attribute__((address_space(4)))*>(ka + 8 * k);
+            for (int k = 0; k < NW; ++k)
+                p.w[k] = *reinterpret_cast<const char* const __attribute__((address_space(4)))*>(ka + 8 * k);
+        }
 #pragma unroll
         for (int k = 0; k < NB; ++k)
             p.b[k] = *reinterpret_cast<const char* const __attribute__((address_space(4)))*>(ka + 128 + 8 * k);
@@ -160,10 +205,22 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
         asm volatile("" : "+v"(lb));
         asm volatile("" : "+s"(wl));
         const int64_t first_b = first * (int64_t)sizeof(T);
+        if constexpr (PITCHED) {
+            int64_t pitch_b = a.wide_pitch * (int64_t)sizeof(T);
+            asm volatile("" : "+s"(pitch_b));     // opaque: keeps 14 addresses from being hoisted
+            const char* pk = reinterpret_cast<const char*>(a.wide[0]) + first_b;
 #pragma unroll
-        for (int k = 0; k < NW; ++k)
-            __builtin_amdgcn_global_load_lds((gptr_t)((p.w[k] + first_b) + lb),
-                                             (lptr_t)(uintptr_t)(wl + k * 1024), 16, 0, kDmaNt);
+            for (int k = 0; k < NW; ++k) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(pk + lb), (lptr_t)(uintptr_t)(wl + k * 1024),
+                                                 16, 0, kDmaNt);
+                pk += pitch_b;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NW; ++k)
+                __builtin_amdgcn_global_load_lds((gptr_t)((p.w[k] + first_b) + lb),
+                                                 (lptr_t)(uintptr_t)(wl + k * 1024), 16, 0, kDmaNt);
+        }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             if constexpr (V == 2)
@@ -298,7 +355,7 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
                 __builtin_nontemporal_store(res[k], reinterpret_cast<VT*>((a.out[k] + first) + lane_elem));
         }
         flushed = (run_n == 0 || cb_n + run_n >= npiece);
-        if (flushed) {   // per-run diagnostics partial (schedule-independent, see et_kernel_dyn)
+        if (flushed) {   // per-run diagnostics partial: butterfly, then lanes 0..7 store the 8 fields
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 dsum_d += __shfl_xor(dsum_d, off, 64);

@@ -23,7 +23,7 @@ group, out = -1, collections.defaultdict(list)
 for d in sorted(names):
     if 'synth_kernel' in names[d]:
         group += 1
-    elif 'et_kernel_dyn' in names[d]:
+    elif 'et_stream_kernel' in names[d]:
         out[group].append((dur.get(d), by[d]))
 for g in sorted(out):
     v = out[g]

@@ -2,7 +2,7 @@
 # kernel stats and the two PMC passes (results under gpurun_out/).
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r01h
+O=gpurun_out/r01i
 rm -rf $O && mkdir -p $O
 timeout -k 10 600 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1 || { tail -30 $O/pytest_gpu.log; exit 1; }
 tail -2 $O/pytest_gpu.log
@@ -14,14 +14,14 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 python - <<'PY'
 import csv, glob, json, os
-O = 'gpurun_out/r01h'
+O = 'gpurun_out/r01i'
 res = {}
 for name in ('FETCH_SIZE', 'WRITE_SIZE'):
     d = os.path.join(O, 'pmc_fetch' if name == 'FETCH_SIZE' else 'pmc_write')
     vals = []
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            if 'et_kernel_dyn' in r['Kernel_Name'] and r['Counter_Name'] == name:
+            if 'et_stream_kernel' in r['Kernel_Name'] and r['Counter_Name'] == name:
                 vals.append(float(r['Counter_Value']))
     res[name] = (sum(vals) / len(vals) if vals else None, len(vals))
 print(json.dumps(res))
