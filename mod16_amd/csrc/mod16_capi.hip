@@ -284,7 +284,14 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     HIPCHK(ctx, hipMemsetAsync(ctr, 0, sizeof(unsigned long long), st));
     s.dyn_counter = ctr;
     const int64_t npiece = (s.n / V + 63) / 64;
-    const int64_t nruns = (npiece + kDynRun - 1) / kDynRun;
+    // run length: kDynRun pieces, halved for small rasters until every wave the
+    // chip holds (2 blocks of 4 per CU) gets at least one run
+    const int64_t chip_waves = (int64_t)ctx->cus * 2 * (kBlock / 64);
+    int run_shift = 0;
+    while ((1 << run_shift) < kDynRun) ++run_shift;
+    while (run_shift > 1 && (npiece >> run_shift) < chip_waves) --run_shift;   // >= 2 pieces: the claim of a run is consumed in its second iteration
+    s.run_shift = run_shift;
+    const int64_t nruns = (npiece + (int64_t(1) << run_shift) - 1) >> run_shift;
     // persistent waves: 2 blocks per CU is what the LDS slots allow
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(
         (nruns + (kBlock / 64) - 1) / (kBlock / 64), (int64_t)ctx->cus * 2));

@@ -81,6 +81,8 @@ template <typename T> struct StreamArgs {
     unsigned long long* dyn_counter;
     double hours;              // kStreamRawTotal: the (scalar) hours of daylight
     int64_t wide_pitch;        // PITCHED: wide[k] = wide[0] + k * wide_pitch (elements)
+    int run_shift;             // a run is 2^run_shift pieces (kDynRun for large rasters, less for
+                               // small ones so that every wave of the chip gets work)
 };
 static_assert(__builtin_offsetof(StreamArgs<double>, wide) == 0 &&
               __builtin_offsetof(StreamArgs<double>, bytes) == 128 &&
@@ -165,7 +167,8 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
     const int64_t nvec = a.n / V;
     const int64_t npiece = (nvec + 63) / 64;
     const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
-    int64_t cbase = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * kDynRun;
+    const int rs = a.run_shift, rl = 1 << rs;
+    int64_t cbase = ((int64_t)blockIdx.x * (kBlock / 64) + wave) << rs;
     int64_t next_base = npiece;
     unsigned long long ticket = 0;
     int run = 0;
@@ -178,7 +181,7 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
     };
     const unsigned lane_elem = (unsigned)lane * (unsigned)V;
     auto advance = [&](int64_t& cb, int& r) {
-        if (++r == kDynRun) { r = 0; cb = next_base; }
+        if (++r == rl) { r = 0; cb = next_base; }
     };
     int64_t v = vec_of(cbase, run);
     double dsum_d = 0, dsum_n = 0, dmax_d = -__builtin_huge_val(), dmax_n = -__builtin_huge_val();
@@ -251,7 +254,7 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
             asm volatile("" : "+v"(ticket));
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ticket);
             const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ticket >> 32));
-            next_base = (nwaves + (int64_t)(((unsigned long long)hi << 32) | lo)) * kDynRun;
+            next_base = (nwaves + (int64_t)(((unsigned long long)hi << 32) | lo)) << rs;
         }
         typedef typename Vec<T, V>::type VT;
         VT in[NW];
@@ -367,7 +370,7 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
             const double cnt_n = (double)__builtin_amdgcn_readfirstlane(nan_n);
             const double f = lane == 0 ? dsum_d : lane == 1 ? dsum_n : lane == 4 ? cnt_d
                            : lane == 5 ? cnt_n : lane == 6 ? dmax_d : lane == 7 ? dmax_n : 0.0;
-            if (lane < kDiag) a.diag_partial[(cbase / kDynRun) * kDiag + lane] = f;
+            if (lane < kDiag) a.diag_partial[(cbase >> rs) * kDiag + lane] = f;
             dsum_d = dsum_n = 0.0;
             dmax_d = dmax_n = -__builtin_huge_val();
             nan_d = nan_n = 0;
