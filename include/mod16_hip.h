@@ -79,6 +79,9 @@ enum mod16_where { MOD16_HOST = 0, MOD16_DEVICE = 1 };
 /* flags of mod16_et_* */
 #define MOD16_MATH_FAST   0u  /* strength-reduced arithmetic (default)          */
 #define MOD16_MATH_EXACT  1u  /* reference operation order, IEEE divide/pow     */
+#define MOD16_MATH_MIXED  2u  /* float32 rasters: float64 where it decides a mask or
+                                 feeds the humidity terms, packed float32 elsewhere
+                                 (dense class-raster totals; other forms run FAST)  */
 
 typedef struct mod16_ctx mod16_ctx;
 

@@ -14,7 +14,7 @@ N_PARAMS = 11
 N_CLASSES = 13
 N_COMPONENTS = 6
 HOST, DEVICE = 0, 1
-MATH_FAST, MATH_EXACT = 0, 1
+MATH_FAST, MATH_EXACT, MATH_MIXED = 0, 1, 2
 
 METHOD_MAX_IN = 13
 (M_SVP, M_SVP_SLOPE, M_LHV, M_PSYCHROMETRIC, M_RADIATION_NET, M_AIR_DENSITY,

@@ -8,8 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 SRC = os.path.join(HERE, 'mod16_capi.hip')
-DEPS = [SRC] + [os.path.join(HERE, f) for f in (
-    'mod16_kernels.hpp', 'mod16_physics.hpp', 'mod16_math.hpp', 'mod16_methods.hpp', 'mod16_stream.hpp')] + [
+DEPS = [SRC] + sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.hpp')) + [
     os.path.join(os.path.dirname(PKG), 'include', 'mod16_hip.h')]
 OUT = os.path.join(PKG, 'libmod16hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')

@@ -375,7 +375,14 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
         if (smode == kStreamTotals) {
             s.out[0] = a.out[0]; s.out[1] = a.out[1];
             fused_diag = ddiag && nbody == a.n;
-            rc = launch_stream<T, kStreamTotals>(ctx, s, st, fused_diag ? ddiag : nullptr);
+            if constexpr (std::is_same<T, float>::value) {
+                if (flags & MOD16_MATH_MIXED)
+                    rc = launch_stream<T, kStreamTotalsMixed>(ctx, s, st, fused_diag ? ddiag : nullptr);
+                else
+                    rc = launch_stream<T, kStreamTotals>(ctx, s, st, fused_diag ? ddiag : nullptr);
+            } else {
+                rc = launch_stream<T, kStreamTotals>(ctx, s, st, fused_diag ? ddiag : nullptr);
+            }
         } else if (smode == kStreamPet) {
             s.out[0] = a.out[0]; s.out[1] = a.out[1]; s.out[2] = a.out[8]; s.out[3] = a.out[9];
             rc = launch_stream<T, kStreamPet>(ctx, s, st);

@@ -1,0 +1,220 @@
+// Mixed-precision pixel function for float32 rasters (MOD16_MATH_MIXED,
+// BASELINE.json configs[4]).
+//
+// The FAST form computes everything in float64 whatever the storage type; on
+// float32 data that makes the kernel VALU-bound at 45 % of the HBM rate. gfx950
+// issues a wave64 float32 instruction at the float64 rate unless it is PACKED
+// (v_pk_fma_f32 & co: two values per lane per instruction), so this form works
+// on PAIRS of pixels (float2) and keeps float64 only where it decides something
+// or where a difference of nearly equal numbers feeds a quotient:
+//
+//   float64  the radiation balance with its discontinuous soil-heat-flux clamps
+//            (mod16/__init__.py:1033-1052, :1103-1112), the Tmin ramp (:1148), and per
+//            period esat -> avp = esat - vpd -> rh, the rh < 0.7 and 1 - fwet > 0
+//            decisions (:646-673, :763-764, :1245). Every NaN / exact-zero mask that is
+//            decided here is decided exactly as in the FAST form.
+//   float32  everything downstream (slope, densities, conductances, the three
+//            Penman-Monteith quotients), packed; reciprocals, 2^x and log2 x are
+//            the hardware ones (v_rcp_f32, v_exp_f32, v_log_f32, 1 ulp).
+//
+// Accuracy against the float64 result on the same float32 inputs (numpy model
+// of this arithmetic on 4 M synthetic pixels, and tests/test_gpu_mixed.py on
+// the device): NaN and zero masks identical, median 1e-7, 99 % of the pixels
+// within 1e-6, absolute error below 1e-6 of the largest value; the tail is the
+// cancellation s*A + rho*Cp*vpd/r_a with A < 0, which float32 factors cannot
+// resolve better than 1e-7 * |s*A| (pixels whose value is orders of magnitude
+// below the typical one).
+#pragma once
+#include "mod16_physics.hpp"
+
+namespace mod16 {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
+// 1/x: v_rcp_f32 + one Newton step. The step is there for the degenerate
+// inputs, not the last bit: like FastMath<double>::rcp it turns 1/0 and 1/inf
+// into NaN (0 * inf), which is what the reference's 0/0 and inf/inf give at
+// pressure = 0 and the like.
+__device__ __forceinline__ f2 rcp2(f2 x) {
+    f2 r = f2{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
+    f2 e = __builtin_elementwise_fma(-x, r, f2{1.f, 1.f});
+    return __builtin_elementwise_fma(r, e, r);
+}
+__device__ __forceinline__ f2 exp2_2(f2 x) { return f2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
+__device__ __forceinline__ f2 log2_2(f2 x) { return f2{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)}; }
+__device__ __forceinline__ i2 mask2(bool a, bool b) { return i2{a ? -1 : 0, b ? -1 : 0}; }
+
+// class parameters of the two pixels, float32 (the LDS table is float64:
+// rounded on the way in, 15 conversions per pixel)
+struct ClassPar2 {
+    f2 vpd_open, vpd_close, gl_sh, gl_wv, g_cut, csl, rbl_min, rbl_max, inv_dvpd, rbl_slope, inv_beta;
+};
+
+struct Shared2 {
+    f2 fpar, omf, p_rel, k_p, p_mbar_k, glsh_l, glwv_l, glsh_lai, m_tmin;
+    i2 lai_pos, lai_tiny;
+};
+
+// what the float64 section hands to one period
+struct Humid2 {
+    f2 esat, rh, fwet, omw;
+    i2 dry;       // rh < 0.7  (fwet = 0)
+    i2 open_w;    // 1 - fwet > 0
+};
+
+// esat, rh, fwet, 1 - fwet of one pixel and period in float64, as in period_fast
+__device__ __forceinline__ void humid64(double t, double vpd, const double* tb, float& esat_f,
+                                        float& rh_f, float& fwet_f, float& omw_f, bool& dry,
+                                        bool& open_w) {
+    typedef FastMath<double> M;
+    double tc = t - K<double>::t0;
+    double esat = __builtin_fma(1e3 * 0.6108, M::exp_tab((17.27 * tc) * M::rcp(tc + 237.3), tb), tc * 0.0);
+    double avp = esat - vpd;
+    double resat = M::rcp(esat);
+    double rh = avp * resat;
+    rh = __builtin_fma(__builtin_fma(-rh, esat, avp), resat, rh);
+    rh = (avp < 0.0) ? 0.0 : ((rh > 1.0) ? 1.0 : rh);
+    dry = rh < 0.7;
+    double rh2 = rh * rh;
+    double fwet = dry ? 0.0 : rh2 * rh2;
+    double omw = 1.0 - fwet;
+    open_w = omw > 0.0;
+    esat_f = (float)esat; rh_f = (float)rh; fwet_f = (float)fwet; omw_f = (float)omw;
+}
+
+template <bool DAY>
+__device__ __forceinline__ f2 period_mixed(const ClassPar2& p, const Shared2& sh, const Humid2& h,
+                                           f2 t, f2 vpd, f2 rad_net, f2 rad_soil) {
+    const f2 zero = splat(0.f), one = splat(1.f), tiny = splat(1e-7f);
+    f2 tc = t - splat(273.15f);
+    f2 ta = (splat(239.0f) + t) - splat(273.15f);
+    f2 rta = rcp2(ta);
+    f2 s = (splat((float)(17.38 * 239.0)) * h.esat) * (rta * rta);          // :1395-1397
+    f2 lhv = (splat(2.501f) - splat(0.002361f) * tc) * splat(1e6f);          // :121
+    f2 slhv = s * lhv;
+    // 1 / r_corr = (P / 101300) (T / 293.15)^-1.75, :771
+    f2 inv_rcorr = sh.p_rel * exp2_2(splat(-1.75f) * log2_2(t * splat((float)(1.0 / 293.15))));
+    // rho Cp and 4 sigma T^3 / (rho Cp) from one reciprocal, :408-412, :947
+    f2 nn = sh.p_mbar_k - (h.rh * splat(100.f)) * (splat(0.00252f) * tc - splat(0.020582f));
+    f2 u = rcp2(nn * t);
+    f2 rho_cp = splat(1013.0f) * ((nn * nn) * u);
+    f2 t2 = t * t;
+    f2 g_rr = splat((float)(4.0 * 5.67e-8 / 1013.0)) * ((t2 * t2) * t) * u;
+    f2 rcfv = rho_cp * vpd;
+    f2 radc_raw = sh.fpar * rad_net;
+
+    // wet canopy, :866-961
+    f2 fw = h.dry ? tiny : h.fwet;                                           // :934 (fwet == 0 <=> dry)
+    f2 g_h = sh.glsh_l * fw, g_e = sh.glwv_l * fw, g_a = g_h + g_rr;
+    f2 numer = fw * ((rcfv * sh.fpar) * g_a + s * radc_raw);
+    f2 den = slhv * g_e + sh.k_p * g_a;
+    f2 evap = (numer * g_e) * rcp2(den);
+    evap = (numer < zero) ? zero : evap;                                     // :959
+    f2 canopy = (h.dry | sh.lai_tiny) ? zero : evap;                         // :961 (fw <= tiny <=> dry)
+
+    // bare soil, :449-544, :795-864
+    f2 r0 = (vpd <= p.vpd_open) ? p.rbl_min
+            : ((vpd >= p.vpd_close) ? p.rbl_max : p.rbl_max - (p.vpd_close - vpd) * p.rbl_slope);
+    f2 r_tot = r0 * inv_rcorr;
+    f2 w = r_tot * g_rr + one;
+    f2 num = (s * rad_soil) * r_tot + (rcfv * sh.omf) * w;
+    f2 dens = r_tot * (sh.k_p * w + slhv);
+    f2 q = num * rcp2(dens);
+    f2 pw = exp2_2((vpd * p.inv_beta) * log2_2(h.rh));                      // rh ** (vpd / beta), :861
+    f2 e = q * (h.omw * pw + h.fwet);
+    f2 soil = (q < zero) ? zero : e;
+
+    // transpiration, :1152-1258
+    f2 g_s = zero;
+    if (DAY) {
+        f2 m_vpd = (vpd >= p.vpd_close) ? zero
+                   : ((vpd < p.vpd_open) ? one : one - (vpd - p.vpd_open) * p.inv_dvpd);
+        g_s = ((p.csl * sh.m_tmin) * m_vpd) * inv_rcorr;
+    }
+    f2 gsc = g_s + p.g_cut * inv_rcorr;
+    f2 g_bl = sh.glsh_lai * h.omw;
+    f2 p1 = g_bl * gsc, s1 = g_bl + gsc;
+    i2 open = sh.lai_pos & h.open_w;                                         // :1245
+    i2 shut = ~open | (p1 <= tiny * s1);                                     // :1258
+    f2 g_d = p.gl_sh + g_rr;
+    f2 rad_c = (radc_raw < zero) ? zero : radc_raw;                          // :1251
+    f2 numt = (h.omw * ((rcfv * sh.fpar) * g_d + s * rad_c)) * p1;
+    f2 dent = slhv * p1 + sh.k_p * (g_d * s1 + p1);
+    f2 tr = numt * rcp2(dent);
+    f2 trans = shut ? zero : tr;
+    return (canopy + soil) + trans;                                          // :792
+}
+
+// Two pixels. in[k][j]: driver k of pixel j; l0 / l1: the pixels' columns of
+// the float64 BPLUT table in LDS ([row][kLutCols] layout, row stride `ls`).
+__device__ __forceinline__ void et_pair_mixed(const float (&in)[14][2], const double* l0,
+                                              const double* l1, int ls, const double* tb,
+                                              f2& day, f2& night) {
+    const double* l[2] = {l0, l1};
+    float a_d[2], rs_d[2], rs_n[2], rn_n[2], m_tmin[2];
+    Humid2 hd, hn;
+    bool dry_d[2], dry_n[2], open_d[2], open_n[2];
+    float esat_d[2], rh_d[2], fwet_d[2], omw_d[2], esat_n[2], rh_n[2], fwet_n[2], omw_n[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        // ---- float64: radiation received by the soil, :963-1119 (predicates verbatim)
+        const double lw_d = in[0][j], lw_n = in[1][j], sw_d = in[2][j], sw_n = in[3][j], alb = in[4][j];
+        const double t_d = in[5][j], t_n = in[6][j], t_ann = in[7][j], tmin = in[8][j];
+        const double fpar = in[12][j];
+        const double tmin_close = l[j][0 * ls], tmin_open = l[j][1 * ls], inv_dtmin = l[j][11 * ls];
+        const double oma = 1.0 - alb, omf = 1.0 - fpar;
+        const double ad = __builtin_fma(sw_d, oma, lw_d);
+        const double an = lw_n;
+        const bool cond = (t_ann < 273.15 + 25.0) && (t_ann >= (273.15 + tmin_close)) && ((t_d - t_n) >= 5.0);
+        double g_d = cond ? (4.73 * (t_d - 273.15)) - 20.87 : 0.0;
+        g_d = (__builtin_fabs(g_d) > (0.39 * __builtin_fabs(ad))) ? 0.39 * ad : g_d;
+        double g_n = cond ? (4.73 * (t_n - 273.15)) - 20.87 : 0.0;
+        g_n = (__builtin_fabs(g_n) > (0.39 * __builtin_fabs(an))) ? 0.39 * an : g_n;
+        g_d = ((ad - g_d < 0.0) && (ad > 0.0)) ? ad : g_d;
+        g_n = ((ad > 0.0) && ((an - g_n) < (-0.5 * ad))) ? an + (0.5 * ad) : g_n;
+        a_d[j] = (float)ad;
+        rs_d[j] = (float)(omf * (ad - g_d));
+        rs_n[j] = (float)(omf * (an - g_n));
+        rn_n[j] = (float)__builtin_fma(sw_n, oma, lw_n);
+        const double tm = tmin - 273.15;
+        m_tmin[j] = (float)((tm >= tmin_open) ? 1.0 : ((tm < tmin_close) ? 0.0 : (tm - tmin_close) * inv_dtmin));
+        // ---- float64: humidity of both periods
+        humid64(t_d, (double)in[9][j], tb, esat_d[j], rh_d[j], fwet_d[j], omw_d[j], dry_d[j], open_d[j]);
+        humid64(t_n, (double)in[10][j], tb, esat_n[j], rh_n[j], fwet_n[j], omw_n[j], dry_n[j], open_n[j]);
+    }
+    hd.esat = f2{esat_d[0], esat_d[1]}; hd.rh = f2{rh_d[0], rh_d[1]};
+    hd.fwet = f2{fwet_d[0], fwet_d[1]}; hd.omw = f2{omw_d[0], omw_d[1]};
+    hd.dry = mask2(dry_d[0], dry_d[1]); hd.open_w = mask2(open_d[0], open_d[1]);
+    hn.esat = f2{esat_n[0], esat_n[1]}; hn.rh = f2{rh_n[0], rh_n[1]};
+    hn.fwet = f2{fwet_n[0], fwet_n[1]}; hn.omw = f2{omw_n[0], omw_n[1]};
+    hn.dry = mask2(dry_n[0], dry_n[1]); hn.open_w = mask2(open_n[0], open_n[1]);
+
+    // ---- float32, packed
+    auto par = [&](int row) { return f2{(float)l0[row * ls], (float)l1[row * ls]}; };
+    ClassPar2 p;
+    p.vpd_open = par(2); p.vpd_close = par(3); p.gl_sh = par(4); p.gl_wv = par(5);
+    p.g_cut = par(6); p.csl = par(7); p.rbl_min = par(8); p.rbl_max = par(9);
+    p.inv_dvpd = par(12); p.rbl_slope = par(13); p.inv_beta = par(14);
+    const f2 pa = f2{in[11][0], in[11][1]}, lai = f2{in[13][0], in[13][1]};
+    Shared2 sh;
+    sh.fpar = f2{in[12][0], in[12][1]};
+    sh.omf = splat(1.f) - sh.fpar;
+    sh.p_rel = pa * splat((float)(1.0 / 101300.0));
+    sh.k_p = pa * splat((float)(1013.0 / 0.622));
+    sh.p_mbar_k = pa * splat((float)(0.348444 / 100.0));
+    const f2 l_wet = (lai == splat(0.f)) ? splat(1e-7f) : lai;               // :935
+    sh.lai_tiny = l_wet <= splat(1e-7f);
+    sh.lai_pos = lai > splat(0.f);
+    sh.glsh_l = p.gl_sh * l_wet;
+    sh.glwv_l = p.gl_wv * l_wet;
+    sh.glsh_lai = p.gl_sh * lai;
+    sh.m_tmin = f2{m_tmin[0], m_tmin[1]};
+    day = period_mixed<true>(p, sh, hd, f2{in[5][0], in[5][1]}, f2{in[9][0], in[9][1]},
+                             f2{a_d[0], a_d[1]}, f2{rs_d[0], rs_d[1]});
+    night = period_mixed<false>(p, sh, hn, f2{in[6][0], in[6][1]}, f2{in[10][0], in[10][1]},
+                                f2{rn_n[0], rn_n[1]}, f2{rs_n[0], rs_n[1]});
+}
+
+}  // namespace mod16

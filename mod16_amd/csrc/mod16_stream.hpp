@@ -43,6 +43,7 @@
 // slower, so there is only this one.)
 #pragma once
 #include "mod16_kernels.hpp"
+#include "mod16_mixed.hpp"
 
 namespace mod16 {
 
@@ -56,12 +57,14 @@ constexpr int kDynRun = MOD16_DYN_RUN;
 
 enum StreamMode {
     kStreamPet = 0, kStreamSep8, kStreamSep6, kStreamRaw, kStreamRawTotal, kStreamRawTotalHours,
-    kStreamTotals
+    kStreamTotals,
+    kStreamTotalsMixed      // float32 rasters only: mixed-precision pixel function (mod16_mixed.hpp)
 };
 
 // NW 16-byte-per-lane arrays, NB byte arrays (class raster first), NOUT outputs
 template <int MODE> struct StreamSpec;
 template <> struct StreamSpec<kStreamTotals> { static constexpr int NW = 14, NB = 1, NOUT = 2; };
+template <> struct StreamSpec<kStreamTotalsMixed> { static constexpr int NW = 14, NB = 1, NOUT = 2; };
 template <> struct StreamSpec<kStreamPet> { static constexpr int NW = 14, NB = 1, NOUT = 4; };
 template <> struct StreamSpec<kStreamSep8> { static constexpr int NW = 14, NB = 1, NOUT = 8; };
 template <> struct StreamSpec<kStreamSep6> { static constexpr int NW = 14, NB = 1, NOUT = 6; };
@@ -275,6 +278,36 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
 
         if (v < nvec) {   // only the last piece is ragged
             VT res[NOUT];
+            if constexpr (MODE == kStreamTotalsMixed) {
+                static_assert(V == 4 || MODE != kStreamTotalsMixed, "the mixed form is for float32 rasters");
+#pragma unroll
+                for (int jj = 0; jj < V; jj += 2) {   // pairs of pixels: packed float32 arithmetic
+                    float pin[14][2];
+#pragma unroll
+                    for (int k = 0; k < 14; ++k) { pin[k][0] = in[k][jj]; pin[k][1] = in[k][jj + 1]; }
+                    unsigned c0 = (bits[0] >> (8 * jj)) & 0xffu, c1 = (bits[0] >> (8 * jj + 8)) & 0xffu;
+                    if (c0 >= 13u || c1 >= 13u) {
+                        atomicOr(a.status, kStatusClassRange);
+                        c0 = c0 >= 13u ? 13u : c0;
+                        c1 = c1 >= 13u ? 13u : c1;
+                    }
+                    f2 day2, night2;
+                    et_pair_mixed(pin, lut + c0, lut + c1, kLutCols, tab, day2, night2);
+                    res[0][jj] = day2.x; res[0][jj + 1] = day2.y;
+                    res[1][jj] = night2.x; res[1][jj + 1] = night2.y;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const double d = (double)res[0][jj + e], g = (double)res[1][jj + e];
+                        const bool dn = d != d, gn = g != g;
+                        nan_d += (unsigned)__builtin_popcountll(__ballot(dn));
+                        nan_n += (unsigned)__builtin_popcountll(__ballot(gn));
+                        dsum_d += dn ? 0.0 : d;
+                        dsum_n += gn ? 0.0 : g;
+                        dmax_d = __builtin_fmax(dmax_d, d);
+                        dmax_n = __builtin_fmax(dmax_n, g);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 PixelIn<double> x;
@@ -351,6 +384,7 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
                     dmax_d = __builtin_fmax(dmax_d, d);
                     dmax_n = __builtin_fmax(dmax_n, g);
                 }
+            }
             }
             const int64_t first = first_of(cbase, run);
 #pragma unroll

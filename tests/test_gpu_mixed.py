@@ -1,0 +1,129 @@
+"""GPU tests of the mixed-precision form for float32 rasters (MOD16_MATH_MIXED,
+mod16_amd/csrc/mod16_mixed.hpp; BASELINE.json configs[4]): float64 where a
+mask is decided and for the humidity terms, packed float32 elsewhere.
+
+Checked against the float64 arithmetic on the same float32 inputs (the FAST
+kernel, which is itself within 1e-8 of the oracle): identical NaN masks,
+identical exact-zero masks on these rasters, median relative error < 2e-7,
+99 % of the pixels < 3e-6, absolute error < 2e-6 of the largest value. The
+relative error of the remaining pixels is not bounded by 1e-5: where
+s*A + rho*Cp*vpd/r_a cancels (A < 0) float32 factors resolve the sum to
+1e-7 * |s*A| only; those values are orders of magnitude below the typical one."""
+import numpy as np
+import pytest
+
+from oracle import mod16_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    from mod16_amd import _lib
+    from mod16_amd.raster import RasterEngine
+    from mod16_amd.utils import restore_bplut, bplut_table
+    from mod16_amd.models import COLLECTION61_BPLUT
+    table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
+    return torch, _lib, RasterEngine, table
+
+
+def stats(got, want):
+    got = got.astype(np.float64)
+    want = want.astype(np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), 'NaN masks differ'
+    zero_mismatch = int(((got == 0) != (want.astype(np.float32) == 0)).sum())
+    m = np.isfinite(want) & (want != 0)
+    rel = np.abs(got[m] - want[m]) / np.abs(want[m])
+    scale = np.nanmax(np.abs(want))
+    return {'zero_mismatch': zero_mismatch, 'median': float(np.median(rel)),
+            'p99': float(np.percentile(rel, 99)), 'max': float(rel.max()),
+            'abs_over_scale': float(np.nanmax(np.abs(got - want)) / scale)}
+
+
+def test_mixed_against_float64_arithmetic(env):
+    torch, _lib, RasterEngine, table = env
+    n = 1200 * 1200 + 8
+    mixed = RasterEngine(table, dtype='float32', math=_lib.MATH_MIXED)
+    fast64 = RasterEngine(table, dtype='float64')
+    cls, drv32 = mixed.synth(n, seed=51)
+    d_m, n_m = mixed.run(cls, drv32)
+    d_f, n_f = fast64.run(cls, [d.double() for d in drv32])
+    mixed.check()
+    fast64.check()
+    for got, want, what in ((d_m, d_f, 'day'), (n_m, n_f, 'night')):
+        s = stats(got.cpu().numpy(), want.cpu().numpy())
+        assert s['zero_mismatch'] == 0, (what, s)
+        assert s['median'] < 2e-7 and s['p99'] < 3e-6 and s['abs_over_scale'] < 2e-6, (what, s)
+    # and against the oracle on a tile of it
+    m = 300000
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    h_drv = [d[:m].cpu().numpy().astype(np.float64) for d in drv32]
+    wd, wn = oracle.evapotranspiration_raster(bplut, cls[:m].cpu().numpy(), *h_drv)
+    for got, want in ((d_m[:m], wd), (n_m[:m], wn)):
+        s = stats(got.cpu().numpy(), want)
+        assert s['zero_mismatch'] == 0 and s['median'] < 2e-7 and s['abs_over_scale'] < 2e-6, s
+
+
+def test_mixed_edge_cases_keep_their_masks(env):
+    """The reference's edge cases (F4: zero / NaN / saturated drivers, fpar 0 and
+    1, lai 0, vpd <= 0 and beyond saturation, pressure 0 ...) as a class raster:
+    every NaN and every exact zero of the reference is one here."""
+    torch, _lib, RasterEngine, table = env
+    import mod16_amd
+    import os
+    from conftest import GOLDEN
+    f = np.load(os.path.join(GOLDEN, 'f4_edge_cases.npz'))
+    reps = 64                                   # whole pieces: the raster takes the pipeline
+    drv = [np.tile(d.astype(np.float32), reps) for d in f['drivers']]
+    t = np.full((13, 11), np.nan)
+    t[7] = f['params']
+    cls = np.full(drv[0].shape, 7, np.uint8)
+    day, night = mod16_amd.evapotranspiration_raster(t, cls, *drv, math=_lib.MATH_MIXED)
+    d64, n64 = mod16_amd.evapotranspiration_raster(t, cls, *[d.astype(np.float64) for d in drv])
+    assert day.dtype == np.float32
+    for got, want in ((day, d64), (night, n64)):
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert np.array_equal(got == 0, want.astype(np.float32) == 0)
+        ok = np.isfinite(want) & (want != 0)
+        rel = np.abs(got[ok] - want[ok]) / np.abs(want[ok])
+        assert rel.max() < 5e-6, rel.max()
+
+
+def test_mixed_falls_back_to_fast_elsewhere(env):
+    """float64 rasters and the forms the mixed pixel function does not cover run FAST."""
+    torch, _lib, RasterEngine, table = env
+    n = 100000
+    e_m = RasterEngine(table, dtype='float64', math=_lib.MATH_MIXED)
+    e_f = RasterEngine(table, dtype='float64')
+    cls, drv = e_f.synth(n, seed=52)
+    a, b = e_m.run(cls, drv)
+    c, d = e_f.run(cls, drv)
+    assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(c))
+    assert torch.equal(torch.nan_to_num(b), torch.nan_to_num(d))
+    e32m = RasterEngine(table, dtype='float32', math=_lib.MATH_MIXED)
+    e32f = RasterEngine(table, dtype='float32')
+    drv32 = [x.float() for x in drv]
+    sep_m, sep_f = e32m.empty(n, 6), e32f.empty(n, 6)
+    e32m.run(cls, drv32, out_sep=sep_m)
+    e32f.run(cls, drv32, out_sep=sep_f)
+    for x, y in zip(sep_m, sep_f):
+        assert torch.equal(torch.nan_to_num(x), torch.nan_to_num(y))
+
+
+def test_mixed_diagnostics_and_class_range(env):
+    torch, _lib, RasterEngine, table = env
+    eng = RasterEngine(table, dtype='float32', math=_lib.MATH_MIXED)
+    n = 500000
+    cls, drv = eng.synth(n, seed=53)
+    diag = torch.zeros(8, dtype=torch.float64, device='cuda')
+    day, night = eng.run(cls, drv, diag=diag)
+    want = eng.diagnostics(day, night)
+    eng.check()
+    d, w = diag.cpu().numpy(), want.cpu().numpy()
+    assert np.array_equal(d[2:], w[2:])                       # counts and maxima exactly
+    np.testing.assert_allclose(d[:2], w[:2], rtol=1e-12)      # sums: another (fixed) order
+    cls[777] = 99
+    eng.run(cls, drv)
+    with pytest.raises(IndexError):
+        eng.check()

@@ -22,7 +22,7 @@ def child(args):
     from mod16_amd.utils import restore_bplut, bplut_table
     from mod16_amd.models import COLLECTION61_BPLUT
     table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
-    math = _lib.MATH_EXACT if args.math == 'exact' else _lib.MATH_FAST
+    math = {'exact': _lib.MATH_EXACT, 'mixed': _lib.MATH_MIXED}.get(args.math, _lib.MATH_FAST)
     eng = RasterEngine(table, dtype=args.dtype, math=math)
     n = args.rows * 43200
     if args.slab >= 0:
