@@ -116,7 +116,8 @@ def main():
     ap.add_argument('--rows', type=int, default=21600, help='global raster rows')
     ap.add_argument('--cols', type=int, default=43200, help='global raster columns')
     ap.add_argument('--dtype', default='float64', choices=['float64', 'float32'])
-    ap.add_argument('--math', default='fast', choices=['fast', 'exact'])
+    ap.add_argument('--math', default='fast', choices=['fast', 'exact', 'mixed'],
+                    help="'mixed': the mixed-precision form for --dtype float32 (configs[4])")
     ap.add_argument('--no-tune', action='store_true',
                     help='arrays of the raster slab back to back instead of the measured best spacing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -163,7 +164,7 @@ def main():
                                     device_id=torch.device('cuda', local_rank))
 
     table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
-    math = _lib.MATH_FAST if args.math == 'fast' else _lib.MATH_EXACT
+    math = {'fast': _lib.MATH_FAST, 'exact': _lib.MATH_EXACT, 'mixed': _lib.MATH_MIXED}[args.math]
     eng = RasterEngine(table, device=local_rank, dtype=args.dtype, math=math)
     offset, n = tiles.pixel_range(args.rows, args.cols, rank, world)
     total = args.rows * args.cols
@@ -257,6 +258,31 @@ def main():
         parity = {'pixels': int(m * len(starts)), 'tiles': len(starts), 'max_rel_err': worst,
                   'masks_equal': masks, 'rtol_north_star': 1e-5,
                   'against': 'numpy oracle on the same input bits'}
+    if not args.no_parity and args.math == 'mixed':
+        # configs[4], every pixel of the band: the mixed-precision form against the
+        # float64 arithmetic on the same float32 rasters (FAST: float64 result
+        # rounded once), on the device
+        ref_eng = RasterEngine(table, device=local_rank, dtype=args.dtype, math=_lib.MATH_FAST)
+        rday, rnight = ref_eng.run(cls, drv)
+        ref_eng.check()
+        full = {'pixels': int(n), 'nan_masks_equal': True, 'zero_mask_mismatches': 0, 'max_rel_err': 0.0,
+                'max_abs_err_over_max_value': 0.0, 'n_rel_err_gt_1e-6': 0, 'n_rel_err_gt_1e-5': 0,
+                'n_rel_err_gt_1e-4': 0, 'n_rel_err_gt_1e-3': 0}
+        for got, ref in ((day, rday), (night, rnight)):
+            full['nan_masks_equal'] &= bool(torch.equal(torch.isnan(got), torch.isnan(ref)))
+            full['zero_mask_mismatches'] += int(((got == 0) != (ref == 0)).sum())
+            scale = float(torch.nan_to_num(ref).abs().max())
+            err = (got.double() - ref.double()).abs_()
+            full['max_abs_err_over_max_value'] = max(full['max_abs_err_over_max_value'],
+                                                     float(torch.nan_to_num(err).max()) / scale)
+            err = torch.nan_to_num_(err.div_(ref.double().abs_()), nan=0.0, posinf=0.0)
+            full['max_rel_err'] = max(full['max_rel_err'], float(err.max()))
+            for thr in ('1e-6', '1e-5', '1e-4', '1e-3'):
+                full['n_rel_err_gt_' + thr] += int((err > float(thr)).sum())
+            del err
+        del rday, rnight
+        if parity is not None:
+            parity['full_grid_mixed_vs_float64_arithmetic'] = full
     if not args.no_parity and args.math == 'fast':
         # every pixel of the band: the production kernel against the kernel that
         # keeps the reference's operation order (IEEE divide / pow), on the device
@@ -340,7 +366,8 @@ def main():
                                                  'of the raster slab chosen by measurement'),
             },
             'roofline': {
-                'bound': 'hbm', 'kernel': 'et_stream_kernel<%s, totals> (LDS-DMA, dynamic runs, in-kernel diagnostics)' % args.dtype, 'achieved': achieved,
+                'bound': 'hbm', 'kernel': 'et_stream_kernel<%s, %s> (LDS-DMA, dynamic runs, in-kernel diagnostics)'
+                                          % (args.dtype, 'totals, mixed precision' if args.math == 'mixed' else 'totals'), 'achieved': achieved,
                 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
                 'traffic': pmc_traffic(n, args.dtype) if args.math == 'fast' else None,
                 'traffic_source': os.path.relpath(PMC_TRAFFIC, ROOT), 'traffic_unit': 'bytes per launch',

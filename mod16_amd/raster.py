@@ -36,7 +36,8 @@ class RasterEngine(object):
     dtype : str
         'float64' (default) or 'float32'
     math : int
-        ``_lib.MATH_FAST`` (default) or ``_lib.MATH_EXACT``
+        ``_lib.MATH_FAST`` (default), ``_lib.MATH_EXACT`` or, for float32
+        rasters, ``_lib.MATH_MIXED`` (see ``include/mod16_hip.h``)
     '''
 
     def __init__(self, table, device=None, dtype='float64', math=_lib.MATH_FAST):
