@@ -31,6 +31,7 @@ struct mod16_ctx {
     int cus = 256;
     int grid_mult = 64;              // blocks per CU in the grid-stride launches of the plain kernels
     bool use_dma = true;             // production pipeline (mod16_stream.hpp); MOD16_NO_DMA=1: plain kernels only
+    int run_shift = -1;              // MOD16_RUN_SHIFT: force 2^k pieces per run (experiments)
     int use_pitch = 1;               // scalar base + pitch addressing for slab layouts (MOD16_PITCH=0: off)
     unsigned long long* dyn_counters = nullptr;   // ring of ticket counters, 128 B apart
     int dyn_next = 0;
@@ -140,6 +141,7 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
         if (const char* g = getenv("MOD16_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(g));
         if (const char* g = getenv("MOD16_NO_DMA")) ctx->use_dma = atoi(g) == 0;
         if (const char* g = getenv("MOD16_PITCH")) ctx->use_pitch = atoi(g);
+        if (const char* g = getenv("MOD16_RUN_SHIFT")) ctx->run_shift = std::max(1, std::min(4, atoi(g)));
         HIPCHK(ctx, hipMalloc(&ctx->dyn_counters, 64 * 128));
         const size_t nlut = MOD16_LUT_ROWS * kLutCols;
         HIPCHK(ctx, hipMalloc(&ctx->lut64, nlut * sizeof(double)));
@@ -290,6 +292,7 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     int run_shift = 0;
     while ((1 << run_shift) < kDynRun) ++run_shift;
     while (run_shift > 1 && (npiece >> run_shift) < chip_waves) --run_shift;   // >= 2 pieces: the claim of a run is consumed in its second iteration
+    if (ctx->run_shift > 0) run_shift = ctx->run_shift;
     s.run_shift = run_shift;
     const int64_t nruns = (npiece + (int64_t(1) << run_shift) - 1) >> run_shift;
     // persistent waves: 2 blocks per CU is what the LDS slots allow
