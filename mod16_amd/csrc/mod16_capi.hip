@@ -9,8 +9,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/mod16_hip.h"
 #include "mod16_kernels.hpp"
@@ -22,7 +25,7 @@ using namespace mod16;
 namespace {
 constexpr int64_t kTilePixels = int64_t(1) << 21;   // HOST mode: pixels per staged tile
 constexpr int kDiagBlocks = 1024;
-constexpr int kSlots = 2;                           // double buffering
+constexpr int kSlots = 4;                           // staging slots = host threads of the HOST mode
 constexpr size_t kStagger = 33 * 1024;              // see RasterEngine.STAGGER_BYTES
 }  // namespace
 
@@ -31,6 +34,7 @@ struct mod16_ctx {
     int cus = 256;
     int grid_mult = 64;              // blocks per CU in the grid-stride launches of the plain kernels
     bool use_dma = true;             // production pipeline (mod16_stream.hpp); MOD16_NO_DMA=1: plain kernels only
+    int host_threads = kSlots;       // MOD16_HOST_THREADS: staging threads of the HOST mode (1..kSlots)
     int run_shift = -1;              // MOD16_RUN_SHIFT: force 2^k pieces per run (experiments)
     int use_pitch = 1;               // scalar base + pitch addressing for slab layouts (MOD16_PITCH=0: off)
     unsigned long long* dyn_counters = nullptr;   // ring of ticket counters, 128 B apart
@@ -47,9 +51,10 @@ struct mod16_ctx {
     double* diag_dev = nullptr;      // device [kDiag]
     double* diag_host = nullptr;     // pinned [kDiag]
     // HOST-mode staging: per slot one device slab + one stream
-    void* slab[kSlots] = {nullptr, nullptr};
+    void* slab[kSlots] = {};
     size_t slab_bytes = 0;
-    hipStream_t streams[kSlots] = {nullptr, nullptr};
+    hipStream_t streams[kSlots] = {};
+    std::mutex launch_mu;            // HOST mode: kernel launches of the staging threads
     void* scalars = nullptr;         // device copies of broadcast scalars
     std::string err;
 };
@@ -141,6 +146,7 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
         if (const char* g = getenv("MOD16_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(g));
         if (const char* g = getenv("MOD16_NO_DMA")) ctx->use_dma = atoi(g) == 0;
         if (const char* g = getenv("MOD16_PITCH")) ctx->use_pitch = atoi(g);
+        if (const char* g = getenv("MOD16_HOST_THREADS")) ctx->host_threads = std::max(1, std::min(kSlots, atoi(g)));
         if (const char* g = getenv("MOD16_RUN_SHIFT")) ctx->run_shift = std::max(1, std::min(4, atoi(g)));
         HIPCHK(ctx, hipMalloc(&ctx->dyn_counters, 64 * 128));
         const size_t nlut = MOD16_LUT_ROWS * kLutCols;
@@ -471,15 +477,64 @@ static int read_status(mod16_ctx* ctx, hipStream_t st) {
     return MOD16_OK;
 }
 
-// HOST mode: stage tiles of kTilePixels through two device slabs / streams.
+// HOST mode: tiles of kTilePixels staged through kSlots device slabs, one host
+// thread and one stream per slot. The copies from and to pageable numpy memory
+// are what bounds this mode (the HIP runtime stages them through its own pinned
+// buffers on the calling thread), so the slots run them concurrently; kernel
+// launches are serialised (they share the context's workspace).
+template <typename T>
+static int stage_tile(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags, const T* dscal,
+                      size_t per_arr, int slot, int64_t off, int64_t m) {
+    hipStream_t st = ctx->streams[slot];
+    char* base = static_cast<char*>(ctx->slab[slot]);
+    EtArgs<T> d = h;
+    d.n = m;
+    for (int k = 0; k < 14; ++k) {
+        if ((h.dense_drv >> k) & 1u) {
+            T* dp = reinterpret_cast<T*>(base + per_arr * k);
+            HIPCHK(ctx, hipMemcpyAsync(dp, h.drv[k] + off, sizeof(T) * m, hipMemcpyHostToDevice, st));
+            d.drv[k] = dp;
+        } else {
+            d.drv[k] = dscal + k;
+        }
+    }
+    if (h.cls) {
+        uint8_t* dc = reinterpret_cast<uint8_t*>(base + per_arr * 35);
+        HIPCHK(ctx, hipMemcpyAsync(dc, h.cls + off, (size_t)m, hipMemcpyHostToDevice, st));
+        d.cls = dc;
+    } else {
+        for (int k = 0; k < 11; ++k) {
+            if ((h.dense_par >> k) & 1u) {
+                T* dp = reinterpret_cast<T*>(base + per_arr * (14 + k));
+                HIPCHK(ctx, hipMemcpyAsync(dp, h.par[k] + off, sizeof(T) * m, hipMemcpyHostToDevice, st));
+                d.par[k] = dp;
+            } else {
+                d.par[k] = dscal + 14 + k;
+            }
+        }
+    }
+    for (int k = 0; k < 10; ++k)
+        d.out[k] = h.out[k] ? reinterpret_cast<T*>(base + per_arr * (25 + k)) : nullptr;
+    {
+        std::lock_guard<std::mutex> lock(ctx->launch_mu);
+        int rc = launch_et<T>(ctx, d, flags, st);
+        if (rc != MOD16_OK) return rc;
+    }
+    for (int k = 0; k < 10; ++k)
+        if (h.out[k]) HIPCHK(ctx, hipMemcpyAsync(h.out[k] + off, d.out[k], sizeof(T) * m, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));      // the slab of this slot is free again
+    return MOD16_OK;
+}
+
 template <typename T>
 static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
     const int64_t n = h.n;
     if (n == 0) return MOD16_OK;
     const int64_t tile = std::min<int64_t>(n, kTilePixels);
-    // slab layout per slot: 14 drivers | 11 params | 8 outputs (T each) | class bytes
-    // successive staged arrays are kStagger bytes apart on top of their size:
-    // power-of-two spacing makes the 16 concurrent streams collide in HBM
+    const int64_t ntiles = (n + tile - 1) / tile;
+    const int nslots = (int)std::min<int64_t>(ntiles, ctx->host_threads);
+    // slab layout per slot: 14 drivers | 11 params | 10 outputs (T each) | class bytes
+    // successive staged arrays are kStagger bytes apart on top of their size
     const size_t per_arr = (((size_t)tile * sizeof(T)) + 255) / 256 * 256 + kStagger;
     const size_t need = per_arr * (14 + 11 + 10) + (size_t)tile + 256;
     if (ctx->slab_bytes < need) {
@@ -487,59 +542,43 @@ static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
             if (ctx->slab[s]) HIPCHK(ctx, hipFree(ctx->slab[s]));
             ctx->slab[s] = nullptr;
         }
-        ctx->slab_bytes = 0;
-        for (int s = 0; s < kSlots; ++s) HIPCHK(ctx, hipMalloc(&ctx->slab[s], need));
         ctx->slab_bytes = need;
     }
-    for (int s = 0; s < kSlots; ++s)
+    for (int s = 0; s < nslots; ++s) {
+        if (!ctx->slab[s]) HIPCHK(ctx, hipMalloc(&ctx->slab[s], ctx->slab_bytes));
         if (!ctx->streams[s]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->streams[s], hipStreamNonBlocking));
+    }
     // broadcast scalars live in one small device array
     T hs[32];
     for (int k = 0; k < 14; ++k) hs[k] = ((h.dense_drv >> k) & 1u) ? T(0) : h.drv[k][0];
     for (int k = 0; k < 11; ++k) hs[14 + k] = (!h.cls && !((h.dense_par >> k) & 1u)) ? h.par[k][0] : T(0);
     HIPCHK(ctx, hipMemcpy(ctx->scalars, hs, sizeof(T) * 25, hipMemcpyHostToDevice));
     const T* dscal = static_cast<const T*>(ctx->scalars);
-
-    int slot = 0;
-    for (int64_t off = 0; off < n; off += tile, slot ^= 1) {
-        const int64_t m = std::min(tile, n - off);
-        hipStream_t st = ctx->streams[slot];
-        HIPCHK(ctx, hipStreamSynchronize(st));   // slab of this slot is free again
-        char* base = static_cast<char*>(ctx->slab[slot]);
-        EtArgs<T> d = h;
-        d.n = m;
-        for (int k = 0; k < 14; ++k) {
-            if ((h.dense_drv >> k) & 1u) {
-                T* dp = reinterpret_cast<T*>(base + per_arr * k);
-                HIPCHK(ctx, hipMemcpyAsync(dp, h.drv[k] + off, sizeof(T) * m, hipMemcpyHostToDevice, st));
-                d.drv[k] = dp;
-            } else {
-                d.drv[k] = dscal + k;
-            }
-        }
-        if (h.cls) {
-            uint8_t* dc = reinterpret_cast<uint8_t*>(base + per_arr * 35);
-            HIPCHK(ctx, hipMemcpyAsync(dc, h.cls + off, (size_t)m, hipMemcpyHostToDevice, st));
-            d.cls = dc;
-        } else {
-            for (int k = 0; k < 11; ++k) {
-                if ((h.dense_par >> k) & 1u) {
-                    T* dp = reinterpret_cast<T*>(base + per_arr * (14 + k));
-                    HIPCHK(ctx, hipMemcpyAsync(dp, h.par[k] + off, sizeof(T) * m, hipMemcpyHostToDevice, st));
-                    d.par[k] = dp;
-                } else {
-                    d.par[k] = dscal + 14 + k;
-                }
-            }
-        }
-        auto out_at = [&](int k) { return reinterpret_cast<T*>(base + per_arr * (25 + k)); };
-        for (int k = 0; k < 10; ++k) d.out[k] = h.out[k] ? out_at(k) : nullptr;
-        int rc = launch_et<T>(ctx, d, flags, st);
+    // the kernels' shared workspace at its final size before any thread launches
+    {
+        const int64_t npiece = (tile / VecOf<T>::v + 63) / 64;
+        int rc = reserve_diag(ctx, npiece / 2 + 2048);
         if (rc != MOD16_OK) return rc;
-        for (int k = 0; k < 10; ++k)
-            if (h.out[k]) HIPCHK(ctx, hipMemcpyAsync(h.out[k] + off, d.out[k], sizeof(T) * m, hipMemcpyDeviceToHost, st));
     }
-    for (int s = 0; s < kSlots; ++s) HIPCHK(ctx, hipStreamSynchronize(ctx->streams[s]));
+    if (nslots == 1) {
+        for (int64_t off = 0; off < n; off += tile) {
+            int rc = stage_tile<T>(ctx, h, flags, dscal, per_arr, 0, off, std::min(tile, n - off));
+            if (rc != MOD16_OK) return rc;
+        }
+    } else {
+        int rcs[kSlots] = {};
+        std::vector<std::thread> workers;
+        for (int s = 0; s < nslots; ++s)
+            workers.emplace_back([&, s]() {
+                if (hipSetDevice(ctx->device) != hipSuccess) { rcs[s] = MOD16_ERR_HIP; return; }
+                for (int64_t t = s; t < ntiles && rcs[s] == MOD16_OK; t += nslots)
+                    rcs[s] = stage_tile<T>(ctx, h, flags, dscal, per_arr, s, t * tile, std::min(tile, n - t * tile));
+            });
+        for (auto& w : workers) w.join();
+        for (int s = 0; s < nslots; ++s)
+            if (rcs[s] != MOD16_OK) return rcs[s];
+    }
+    for (int s = 0; s < nslots; ++s) HIPCHK(ctx, hipStreamSynchronize(ctx->streams[s]));
     return read_status(ctx, ctx->streams[0]);
 }
 
