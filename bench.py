@@ -35,7 +35,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md)
-PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r01i_pmc_hbm_traffic.json')
+PMC_TRAFFIC = [os.path.join(ROOT, 'profiles', f) for f in
+               ('r01i_pmc_hbm_traffic.json', 'r01i_pmc_hbm_traffic_float32.json')]
 TILE = (1200, 1200)           # BASELINE.json configs[1], the CPU sample unit
 SEED = 16
 
@@ -94,18 +95,20 @@ def cpu_baseline(max_workers):
 
 
 def pmc_traffic(pixels_per_launch, dtype):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
-    PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected separately, see the file);
-    counters cannot be read from inside this process, so the figure applies
-    only when this run launches the same kernel on the same pixel count."""
-    try:
-        with open(PMC_TRAFFIC) as f:
-            rec = json.load(f)
-    except (OSError, ValueError):
-        return None
-    if rec.get('pixels_per_launch') == pixels_per_launch and rec.get('dtype') == dtype:
-        return rec['traffic_bytes_per_launch']
-    return None
+    """(HBM bytes per launch, source file) of the dominant kernel from the committed
+    rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected separately, see the
+    files); counters cannot be read from inside this process, so a figure applies
+    only when this run launches the same kernel on the same pixel count. The float32
+    record was taken with the mixed-precision form; the FAST form moves the same bytes."""
+    for path in PMC_TRAFFIC:
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if rec.get('pixels_per_launch') == pixels_per_launch and rec.get('dtype') == dtype:
+            return rec['traffic_bytes_per_launch'], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def main():
@@ -347,6 +350,7 @@ def main():
                   'sum_day_first_last': [float(sdiag[0, 0]), float(sdiag[-1, 0])]}
 
     if rank == 0:
+        traffic, traffic_source = pmc_traffic(n, args.dtype) if args.math != 'exact' else (None, None)
         value = total * args.steps / elapsed
         line = {
             'metric': 'pixels/sec, fused Penman-Monteith ET forward run (day+night), 43200x21600 global grid',
@@ -369,8 +373,7 @@ def main():
                 'bound': 'hbm', 'kernel': 'et_stream_kernel<%s, %s> (LDS-DMA, dynamic runs, in-kernel diagnostics)'
                                           % (args.dtype, 'totals, mixed precision' if args.math == 'mixed' else 'totals'), 'achieved': achieved,
                 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
-                'traffic': pmc_traffic(n, args.dtype) if args.math == 'fast' else None,
-                'traffic_source': os.path.relpath(PMC_TRAFFIC, ROOT), 'traffic_unit': 'bytes per launch',
+                'traffic': traffic, 'traffic_source': traffic_source, 'traffic_unit': 'bytes per launch',
                 'bytes_per_pixel': bpp, 'pixels_per_launch': n,
                 'kernel_ms': kernel_ms, 'kernel_pixels_per_s': n / (kernel_ms * 1e-3),
             },

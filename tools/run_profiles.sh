@@ -1,20 +1,26 @@
-# Round-end validation on the MI355X box: GPU tests, bench line, rocprofv3
-# kernel stats and the two PMC passes (results under gpurun_out/).
+# Validation on the MI355X box: GPU tests, bench line, rocprofv3 kernel stats and
+# the two PMC passes; results under gpurun_out/TAG.
+#   bash tools/run_profiles.sh TAG [bench.py arguments, e.g. --dtype float32 --math mixed]
+# SKIP_TESTS=1 leaves the test suite out.
 set -e
+TAG=${1:-r01}
+shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r01i
+O=gpurun_out/$TAG
 rm -rf $O && mkdir -p $O
-timeout -k 10 600 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1 || { tail -30 $O/pytest_gpu.log; exit 1; }
-tail -2 $O/pytest_gpu.log
-timeout -k 10 500 python bench.py > $O/bench_line.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
+if [ -z "$SKIP_TESTS" ]; then
+  timeout -k 10 600 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1 || { tail -30 $O/pytest_gpu.log; exit 1; }
+  tail -2 $O/pytest_gpu.log
+fi
+timeout -k 10 500 python bench.py "$@" > $O/bench_line.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
 cat $O/bench_line.json
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu-baseline --steps 10 > $O/bench_line_under_rocprof.json 2> $O/rocprof_stats.err
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --no-cpu-baseline --no-parity --steps 3 --warmup 1 > $O/pmc_fetch.out 2> $O/pmc_fetch.err
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --no-cpu-baseline --no-parity --steps 3 --warmup 1 > $O/pmc_write.out 2> $O/pmc_write.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py "$@" --no-cpu-baseline --steps 10 > $O/bench_line_under_rocprof.json 2> $O/rocprof_stats.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py "$@" --no-cpu-baseline --no-parity --steps 3 --warmup 1 > $O/pmc_fetch.out 2> $O/pmc_fetch.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py "$@" --no-cpu-baseline --no-parity --steps 3 --warmup 1 > $O/pmc_write.out 2> $O/pmc_write.err
 find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
-python - <<'PY'
+O=$O python - <<'PY'
 import csv, glob, json, os
-O = 'gpurun_out/r01i'
+O = os.environ['O']
 res = {}
 for name in ('FETCH_SIZE', 'WRITE_SIZE'):
     d = os.path.join(O, 'pmc_fetch' if name == 'FETCH_SIZE' else 'pmc_write')
