@@ -37,8 +37,26 @@ def main():
     else:
         staggers = [33 * KiB, 1 * KiB, 5 * KiB, 9 * KiB, 17 * KiB, 65 * KiB, 129 * KiB, 257 * KiB, 1025 * KiB, 0, 4 * KiB]
         shifts = [0, 1 << 20, 37 << 20]
-    max_per = (n * 8 + 4095) // 4096 * 4096 + max(staggers)
-    big = torch.empty(16 * max_per + n + max(shifts) + 4096, dtype=torch.uint8, device='cuda')
+    if not (len(sys.argv) > 2 and sys.argv[2] == 'outputs'):
+        max_per = (n * 8 + 4095) // 4096 * 4096 + max(staggers)
+        big = torch.empty(16 * max_per + n + max(shifts) + 4096, dtype=torch.uint8, device='cuda')
+    if len(sys.argv) > 2 and sys.argv[2] == 'outputs':
+        # drivers at a fixed spacing, the two output arrays moved as a block
+        extra = int(sys.argv[3]) * MiB if len(sys.argv) > 3 else 512 * MiB
+        per = (n * 8 + 4095) // 4096 * 4096 + 33 * KiB + extra
+        big2 = torch.empty(18 * per + n + 4096 + 2048 * MiB, dtype=torch.uint8, device='cuda')
+        views = [big2[k * per:k * per + n * 8].view(torch.float64) for k in range(14)]
+        cls = big2[14 * per:14 * per + n]
+        eng.synth(n, seed=16, out=(cls, views))
+        base_out = 14 * per + (n + 4095) // 4096 * 4096 + 33 * KiB
+        for m in range(0, 2049, 128):
+            o0 = base_out + m * MiB
+            day = big2[o0:o0 + n * 8].view(torch.float64)
+            night = big2[o0 + per:o0 + per + n * 8].view(torch.float64)
+            eng.time_kernel(cls, views, day, night, launches=2)
+            ms = eng.time_kernel(cls, views, day, night, launches=8)
+            print(json.dumps({'outputs_moved_MiB': m, 'drivers_extra_MiB': extra // MiB, 'ms': round(ms, 3)}), flush=True)
+        return
     for shift in shifts:
         for st in staggers:
             per = (n * 8 + 4095) // 4096 * 4096 + st
