@@ -77,10 +77,12 @@ def test_no_device_fails_loudly(lib):
 
 
 def test_product_never_imports_the_oracle():
-    """oracle/ is test infrastructure: nothing under mod16_amd/ may import it."""
-    pkg = os.path.join(ROOT, 'mod16_amd')
-    for dirpath, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith(('.py', '.hip', '.hpp', '.h')):
-                text = open(os.path.join(dirpath, f)).read()
-                assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f
+    """oracle/ is test infrastructure: nothing under mod16_amd/ (the product) or
+    tools/ (timing and profiling scripts) may import it; its only users are
+    tests/, __graft_entry__.smoke() and bench.py's cpu_baseline / parity legs."""
+    for sub in ('mod16_amd', 'tools'):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith(('.py', '.hip', '.hpp', '.h')):
+                    text = open(os.path.join(dirpath, f)).read()
+                    assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f

@@ -14,13 +14,13 @@ sys.path.insert(0, ROOT)
 import mod16_amd  # noqa: E402
 from mod16_amd.models import COLLECTION61_BPLUT  # noqa: E402
 from mod16_amd.utils import bplut_table, restore_bplut  # noqa: E402
-from oracle import synth  # noqa: E402
+from _drivers import drivers as synth_drivers  # noqa: E402
 
 
 def main():
     table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
     for shape in ((1200, 1200), (4800, 4800), (9600, 9600)):
-        cls, drv = synth.drivers(shape, seed=16)
+        cls, drv = synth_drivers(shape, seed=16)
         mod16_amd.evapotranspiration_raster(table, cls, *drv)      # warm-up (allocations)
         ts = []
         for _ in range(3):
