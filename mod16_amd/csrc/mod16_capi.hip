@@ -1130,8 +1130,9 @@ static int static_batch_entry(mod16_ctx* ctx, const T* const* drivers, const int
         d.flags = dflags;
         HIPCHK(ctx, hipMemsetAsync(dflags, 0, sizeof(unsigned) * ndraw, st));
         const int gx = (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, (int64_t)ctx->cus * 8));
-        for (int64_t d0 = 0; d0 < ndraw; d0 += 32768) {
-            const unsigned gy = (unsigned)std::min<int64_t>(32768, ndraw - d0);
+        d.ndraw = ndraw;
+        for (int64_t d0 = 0; d0 < ndraw; d0 += 32768 * (int64_t)kBatchDraws) {
+            const unsigned gy = (unsigned)((std::min<int64_t>(32768 * (int64_t)kBatchDraws, ndraw - d0) + kBatchDraws - 1) / kBatchDraws);
             d.draw0 = d0;
             hipLaunchKernelGGL((static_batch_flag_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
             hipLaunchKernelGGL((static_batch_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);

@@ -191,18 +191,24 @@ __global__ void __launch_bounds__(kBlock) static_kernel(const StaticArgs<T> a) {
 }
 
 // ---- the calibration path batched over parameter vectors:
-// what MCMC / Sobol sampling hammers (reference calibration.py:907,
+// the reference's MCMC / Sobol sampling hammer (reference calibration.py:907,
 // sensitivity.py:95) is MOD16._et(params, *drivers) for thousands of parameter
 // draws over the same few 10^4..10^6 tower-days. One launch evaluates every
-// (draw, pixel) pair: blockIdx.y = draw (its 11 parameters are block-uniform
-// scalar loads), x = pixels. Same pixel function as static_kernel, so row d of
+// (draw, pixel) pair: a thread owns one pixel and walks kBatchDraws
+// consecutive draws (blockIdx.y = chunk of draws; the 11 parameters of a draw
+// are block-uniform scalar loads), so everything that does not depend on the
+// parameters -- svp, its slope, rh, fwet, air density, r_corr with its pow() --
+// is loop-invariant and computed once per chunk. Same pixel function as
+// static_kernel in the same operation order (fp contraction off), so row d of
 // the result is bit-identical to a single-draw call with params[d].
+constexpr int kBatchDraws = 32;
 template <typename T> struct StaticBatchArgs {
     const T* drv[14];
     const T* params;         // [ndraw][11], MOD16.required_parameters order
     T* out[3];               // day, night, day + night: [ndraw][n], any may be NULL
     int64_t n;
-    int64_t draw0;           // first draw of this launch (gridDim.y draws per launch)
+    int64_t draw0;           // first draw of this launch (gridDim.y chunks of kBatchDraws per launch)
+    int64_t ndraw;
     uint32_t dense_drv;
     unsigned* flags;         // [ndraw] words: bit 0 = any(g_surf > 0) for that draw
 };
@@ -220,34 +226,39 @@ __device__ __forceinline__ void batch_load(const StaticBatchArgs<T>& a, int64_t 
 
 template <typename T>
 __global__ void __launch_bounds__(kBlock) static_batch_flag_kernel(const StaticBatchArgs<T> a) {
-    const int64_t draw = a.draw0 + blockIdx.y;
+    const int64_t d0 = a.draw0 + (int64_t)blockIdx.y * kBatchDraws;
+    const int64_t d1 = (d0 + kBatchDraws < a.ndraw) ? d0 + kBatchDraws : a.ndraw;
     const int64_t step = (int64_t)gridDim.x * kBlock;
-    bool any = false;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += step) {
+        for (int64_t draw = d0; draw < d1; ++draw) {
 #pragma clang fp contract(off)
-        PixelIn<T> x;
-        ClassPar<T> p;
-        batch_load(a, draw, i, x, p);
-        any = any || ((gsurf_static(p, x.tmin, x.vpd_d) / rcorr_exact(x.pa, x.t_d)) > T(0));
+            PixelIn<T> x;
+            ClassPar<T> p;
+            batch_load(a, draw, i, x, p);
+            const bool any = (gsurf_static(p, x.tmin, x.vpd_d) / rcorr_exact(x.pa, x.t_d)) > T(0);
+            if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(a.flags + draw, 1u);
+        }
     }
-    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(a.flags + draw, 1u);
 }
 
 template <typename T>
 __global__ void __launch_bounds__(kBlock) static_batch_kernel(const StaticBatchArgs<T> a) {
-    const int64_t draw = a.draw0 + blockIdx.y;
-    const bool any_gs = (a.flags[draw] & 1u) != 0;
+    const int64_t d0 = a.draw0 + (int64_t)blockIdx.y * kBatchDraws;
+    const int64_t d1 = (d0 + kBatchDraws < a.ndraw) ? d0 + kBatchDraws : a.ndraw;
     const int64_t step = (int64_t)gridDim.x * kBlock;
-    const int64_t row = draw * a.n;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += step) {
-        PixelIn<T> x;
-        ClassPar<T> p;
-        batch_load(a, draw, i, x, p);
-        T day, night;
-        et_static_pixel(x, p, false, T(0), T(0), any_gs, day, night);
-        if (a.out[0]) a.out[0][row + i] = day;
-        if (a.out[1]) a.out[1][row + i] = night;
-        if (a.out[2]) a.out[2][row + i] = day + night;      // MOD16._et, :193
+        for (int64_t draw = d0; draw < d1; ++draw) {
+            const bool any_gs = (a.flags[draw] & 1u) != 0;
+            PixelIn<T> x;
+            ClassPar<T> p;
+            batch_load(a, draw, i, x, p);
+            T day, night;
+            et_static_pixel(x, p, false, T(0), T(0), any_gs, day, night);
+            const int64_t row = draw * a.n;
+            if (a.out[0]) a.out[0][row + i] = day;
+            if (a.out[1]) a.out[1][row + i] = night;
+            if (a.out[2]) a.out[2][row + i] = day + night;      // MOD16._et, :193
+        }
     }
 }
 
