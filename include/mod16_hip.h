@@ -295,9 +295,11 @@ MOD16_API int mod16_et_static_f32(mod16_ctx* ctx, const float* const* drivers,
  * reference's MCMC sampler (calibration.py:907) and Sobol analysis
  * (sensitivity.py:95) evaluate draw by draw. `params` is [ndraw][11] row-major
  * in mod16_param order; outputs are [ndraw][n] row-major, each may be NULL:
- * out_day / out_night [W m-2] and out_total = day + night (MOD16._et). Row d
- * is bit-identical to mod16_et_static_* called with the scalars params[d]
- * (r_corr computed, `rcorr` = NULL). With `observed` [n] (and optional
+ * out_day / out_night [W m-2] and out_total = day + night (MOD16._et). With
+ * flags = MOD16_MATH_EXACT row d is bit-identical to mod16_et_static_* called
+ * with the scalars params[d] (r_corr computed, `rcorr` = NULL); MOD16_MATH_FAST
+ * uses the strength-reduced arithmetic of the forward run (float64 throughout,
+ * within 1e-9 of EXACT, same NaN and zero masks, several times faster). With `observed` [n] (and optional
  * `weights` [n]) the call also reduces each draw to
  *     sse[d]   = sum_i (weights[i] * (out_total[d][i] - observed[i]))^2
  *     count[d] = number of pairs used (NaN pairs are skipped),
@@ -310,13 +312,13 @@ MOD16_API int mod16_et_static_batch_f64(mod16_ctx* ctx, const double* const* dri
                         int64_t ndraw, double* out_day, double* out_night,
                         double* out_total, const double* observed,
                         const double* weights, double* sse, double* count,
-                        int where, void* stream);
+                        unsigned flags, int where, void* stream);
 MOD16_API int mod16_et_static_batch_f32(mod16_ctx* ctx, const float* const* drivers,
                         const int64_t* dstride, int64_t n, const float* params,
                         int64_t ndraw, float* out_day, float* out_night,
                         float* out_total, const float* observed,
                         const float* weights, double* sse, double* count,
-                        int where, void* stream);
+                        unsigned flags, int where, void* stream);
 
 /*
  * Waits for the ctx's outstanding work on `stream` and reports deferred

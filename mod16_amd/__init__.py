@@ -375,7 +375,7 @@ class MOD16(object):
     def _et_batch(params, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
                   sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
                   vpd_night, pressure, fpar, lai, observed=None, weights=None,
-                  separate=False):
+                  separate=False, math=_lib.MATH_EXACT):
         '''
         ``MOD16._et`` for many parameter vectors in one launch (extension; the
         reference evaluates ``_et`` draw by draw from its MCMC sampler,
@@ -384,7 +384,9 @@ class MOD16(object):
         the drivers broadcast against each other as in ``_et``. Returns the
         (D x shape) array of day + night latent heat flux [W m-2] -- row d
         equals ``MOD16._et(params[d], *drivers)`` bit for bit -- or, with
-        ``separate=True``, ``[day, night]``. With ``observed`` (and optional
+        ``separate=True``, ``[day, night]``. ``math=_lib.MATH_FAST`` trades the
+        bit-identity for speed: the strength-reduced float64 arithmetic of the
+        forward run, within 1e-9 of the default with the same NaN / zero masks. With ``observed`` (and optional
         ``weights``, both of the drivers' shape) nothing of that size comes
         back: the result is ``(sse, count)``, two float64 arrays (D,) with
         ``sse[d] = sum((weights * (_et_d - observed))**2)`` over the non-NaN
@@ -418,7 +420,7 @@ class MOD16(object):
             if n and ndraw:
                 ctx.check(fn(ctx.handle, _lib.ptr_array(dptr), _lib.i64_array(dstr), n,
                              adr(par), ndraw, None, None, None, adr(obs), adr(wts),
-                             adr(sse), adr(count), _lib.HOST, None))
+                             adr(sse), adr(count), int(math), _lib.HOST, None))
             return sse, count
         outs = [np.empty((ndraw,) + shape, dtype) for _ in range(2 if separate else 1)]
         if n and ndraw:
@@ -426,7 +428,7 @@ class MOD16(object):
                          adr(par), ndraw,
                          adr(outs[0]) if separate else None, adr(outs[1]) if separate else None,
                          None if separate else adr(outs[0]), None, None, None, None,
-                         _lib.HOST, None))
+                         int(math), _lib.HOST, None))
         return outs if separate else outs[0]
 
     @staticmethod

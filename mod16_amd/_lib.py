@@ -93,11 +93,11 @@ PROTOTYPES = {
     'mod16_et_static_batch_f64': (C.c_int, [
         C.c_void_p, _PP, _I64P, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-        C.c_int, C.c_void_p]),
+        C.c_uint, C.c_int, C.c_void_p]),
     'mod16_et_static_batch_f32': (C.c_int, [
         C.c_void_p, _PP, _I64P, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-        C.c_int, C.c_void_p]),
+        C.c_uint, C.c_int, C.c_void_p]),
     'mod16_check_status': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mod16_reduce_diag_f64': (C.c_int, [
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,

@@ -1103,7 +1103,7 @@ template <typename T>
 static int static_batch_entry(mod16_ctx* ctx, const T* const* drivers, const int64_t* dstride,
                               int64_t n, const T* params, int64_t ndraw, T* out_day, T* out_night,
                               T* out_total, const T* observed, const T* weights, double* sse,
-                              double* count, int where, void* stream) {
+                              double* count, unsigned flags, int where, void* stream) {
     if (!ctx) return MOD16_ERR_ARG;
     if (!drivers || !dstride || !params || n < 0 || ndraw < 0)
         return fail(ctx, MOD16_ERR_ARG, "mod16_et_static_batch: bad argument");
@@ -1128,14 +1128,21 @@ static int static_batch_entry(mod16_ctx* ctx, const T* const* drivers, const int
     auto run = [&](StaticBatchArgs<T> d, const T* dobs, const T* dw, double* dsse, double* dcnt,
                    unsigned* dflags, hipStream_t st) -> int {
         d.flags = dflags;
+        d.tab = ctx->tab64;
+        const bool fast = (flags & MOD16_MATH_EXACT) == 0;
         HIPCHK(ctx, hipMemsetAsync(dflags, 0, sizeof(unsigned) * ndraw, st));
         const int gx = (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, (int64_t)ctx->cus * 8));
         d.ndraw = ndraw;
         for (int64_t d0 = 0; d0 < ndraw; d0 += 32768 * (int64_t)kBatchDraws) {
             const unsigned gy = (unsigned)((std::min<int64_t>(32768 * (int64_t)kBatchDraws, ndraw - d0) + kBatchDraws - 1) / kBatchDraws);
             d.draw0 = d0;
-            hipLaunchKernelGGL((static_batch_flag_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
-            hipLaunchKernelGGL((static_batch_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
+            if (fast) {
+                hipLaunchKernelGGL((static_batch_flag_fast_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
+                hipLaunchKernelGGL((static_batch_fast_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
+            } else {
+                hipLaunchKernelGGL((static_batch_flag_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
+                hipLaunchKernelGGL((static_batch_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
+            }
         }
         if (dsse)
             hipLaunchKernelGGL((static_batch_sse_kernel<T>), dim3((unsigned)ndraw), dim3(kBlock), 0, st,
@@ -1213,18 +1220,18 @@ extern "C" int mod16_et_static_batch_f64(mod16_ctx* ctx, const double* const* dr
                                          int64_t ndraw, double* out_day, double* out_night,
                                          double* out_total, const double* observed,
                                          const double* weights, double* sse, double* count,
-                                         int where, void* stream) {
+                                         unsigned flags, int where, void* stream) {
     return static_batch_entry<double>(ctx, drivers, dstride, n, params, ndraw, out_day, out_night,
-                                      out_total, observed, weights, sse, count, where, stream);
+                                      out_total, observed, weights, sse, count, flags, where, stream);
 }
 extern "C" int mod16_et_static_batch_f32(mod16_ctx* ctx, const float* const* drivers,
                                          const int64_t* dstride, int64_t n, const float* params,
                                          int64_t ndraw, float* out_day, float* out_night,
                                          float* out_total, const float* observed,
                                          const float* weights, double* sse, double* count,
-                                         int where, void* stream) {
+                                         unsigned flags, int where, void* stream) {
     return static_batch_entry<float>(ctx, drivers, dstride, n, params, ndraw, out_day, out_night,
-                                     out_total, observed, weights, sse, count, where, stream);
+                                     out_total, observed, weights, sse, count, flags, where, stream);
 }
 
 // ------------------------------------------------------------- diagnostics

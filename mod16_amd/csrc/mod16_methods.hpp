@@ -209,6 +209,7 @@ template <typename T> struct StaticBatchArgs {
     int64_t n;
     int64_t draw0;           // first draw of this launch (gridDim.y chunks of kBatchDraws per launch)
     int64_t ndraw;
+    const double* tab;       // exp / log tables of FastMath<double> (FAST kernels)
     uint32_t dense_drv;
     unsigned* flags;         // [ndraw] words: bit 0 = any(g_surf > 0) for that draw
 };
@@ -258,6 +259,77 @@ __global__ void __launch_bounds__(kBlock) static_batch_kernel(const StaticBatchA
             if (a.out[0]) a.out[0][row + i] = day;
             if (a.out[1]) a.out[1][row + i] = night;
             if (a.out[2]) a.out[2][row + i] = day + night;      // MOD16._et, :193
+        }
+    }
+}
+
+// ---- the same with the strength-reduced arithmetic (MOD16_MATH_FAST): the
+// parameter-independent part of the pixel function is prepared explicitly
+// (static_pixel_prep), each draw costs ~100 float64 instructions per period
+// instead of ~25 IEEE divisions and a pow(). float32 data are widened, computed
+// in float64 and rounded once.
+template <typename T>
+__device__ __forceinline__ void batch_load_fast(const StaticBatchArgs<T>& a, int64_t i, PixelIn<double>& x) {
+    auto d = [&](int k) { return (double)(((a.dense_drv >> k) & 1u) ? a.drv[k][i] : a.drv[k][0]); };
+    x = {d(0), d(1), d(2), d(3), d(4), d(5), d(6), d(7), d(8), d(9), d(10), d(11), d(12), d(13)};
+}
+template <typename T>
+__device__ __forceinline__ ClassPar<double> batch_params_fast(const StaticBatchArgs<T>& a, int64_t draw) {
+    const T* q = a.params + draw * 11;
+    ClassPar<double> p;
+    p.tmin_close = q[0]; p.tmin_open = q[1]; p.vpd_open = q[2]; p.vpd_close = q[3];
+    p.gl_sh = q[4]; p.gl_wv = q[5]; p.g_cut = q[6]; p.csl = q[7];
+    p.rbl_min = q[8]; p.rbl_max = q[9]; p.beta = q[10];
+    return p;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) static_batch_flag_fast_kernel(const StaticBatchArgs<T> a) {
+    constexpr int kTab = FastMath<double>::kTabDoubles;
+    __shared__ __attribute__((aligned(16))) double tab[kTab];
+    for (int i = threadIdx.x; i < kTab; i += kBlock) tab[i] = a.tab[i];
+    __syncthreads();
+    const int64_t d0 = a.draw0 + (int64_t)blockIdx.y * kBatchDraws;
+    const int64_t d1 = (d0 + kBatchDraws < a.ndraw) ? d0 + kBatchDraws : a.ndraw;
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += step) {
+        PixelIn<double> x;
+        batch_load_fast(a, i, x);
+        const StaticPixel c = static_pixel_prep(x, tab);
+        for (int64_t draw = d0; draw < d1; ++draw) {
+            const ClassPar<double> p = batch_params_fast(a, draw);
+            const StaticDraw d = static_draw_prep(c, p);
+            const bool any = static_gsurf(c.d, d, p) > 0.0;
+            if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(a.flags + draw, 1u);
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) static_batch_fast_kernel(const StaticBatchArgs<T> a) {
+    constexpr int kTab = FastMath<double>::kTabDoubles;
+    __shared__ __attribute__((aligned(16))) double tab[kTab];
+    for (int i = threadIdx.x; i < kTab; i += kBlock) tab[i] = a.tab[i];
+    __syncthreads();
+    const int64_t d0 = a.draw0 + (int64_t)blockIdx.y * kBatchDraws;
+    const int64_t d1 = (d0 + kBatchDraws < a.ndraw) ? d0 + kBatchDraws : a.ndraw;
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += step) {
+        PixelIn<double> x;
+        batch_load_fast(a, i, x);
+        const StaticPixel c = static_pixel_prep(x, tab);
+        for (int64_t draw = d0; draw < d1; ++draw) {
+            const bool any_gs = (a.flags[draw] & 1u) != 0;
+            const ClassPar<double> p = batch_params_fast(a, draw);
+            const StaticDraw d = static_draw_prep(c, p);
+            const int k = d.cond ? 1 : 0;
+            const double day = static_period_eval<true>(c, c.d, d, p, c.rs_d[k], any_gs, tab);
+            // at night g_surf = 0 / r_corr, so any(g_surf > 0) is False: no transpiration (:343-348)
+            const double night = static_period_eval<false>(c, c.n, d, p, c.rs_n[k], false, tab);
+            const int64_t row = draw * a.n;
+            if (a.out[0]) a.out[0][row + i] = (T)day;
+            if (a.out[1]) a.out[1][row + i] = (T)night;
+            if (a.out[2]) a.out[2][row + i] = (T)(day + night);
         }
     }
 }

@@ -399,6 +399,137 @@ __device__ __forceinline__ void et_static_pixel(const PixelIn<T>& x, const Class
     night = period_static<T, false>(x, p, x.t_n, x.vpd_n, x.sw_n, x.lw_n, rs_n, has_rc, rc_n, false);
 }
 
+// ---- static path, strength-reduced and split for batching over parameter
+// vectors (mod16_et_static_batch_*, MOD16_MATH_FAST): what does not depend on
+// the parameters is prepared once per pixel (StaticPeriod / StaticPixel), the
+// rest is evaluated per parameter vector with the arithmetic of the FAST
+// forward run (reciprocal + Newton step, table exp / log, conductances instead
+// of parallel resistances). Same predicates as period_static.
+struct StaticPeriod {
+    double vpd, rad_c, s, gamma, inv_rc, g_rr, rcfv, rh, fw, omw, logrh;
+};
+struct StaticPixel {
+    StaticPeriod d, n;
+    double fpar, omf, lai, tm, t_ann;
+    double rs_d[2], rs_n[2];     // radiation received by the soil without / with soil heat flux
+    bool base_cond, lai_pos;
+};
+
+__device__ __forceinline__ StaticPeriod static_period_prep(double t, double vpd, double sw, double lw,
+                                                           double alb, double fpar, double pa,
+                                                           const double* tb) {
+    typedef FastMath<double> M;
+    StaticPeriod c;
+    c.vpd = vpd;
+    c.rad_c = fpar * __builtin_fma(sw, 1.0 - alb, lw);                       // :272-275
+    const double tc = t - 273.15;
+    const double sv = __builtin_fma(1e3 * 0.6108, M::exp_tab((17.27 * tc) * M::rcp(tc + 237.3), tb), tc * 0.0);
+    const double rsv = M::rcp(sv), avp = sv - vpd;
+    double rh = avp * rsv;
+    rh = __builtin_fma(__builtin_fma(-rh, sv, avp), rsv, rh);                // finished like a division
+    rh = (rh < 0.0) ? 0.0 : rh;                                              // :280-281, no upper clamp
+    const double rh2 = rh * rh;
+    c.rh = rh;
+    c.fw = (rh < 0.7) ? 0.0 : rh2 * rh2;
+    c.omw = 1.0 - c.fw;
+    const double rd = M::rcp((239.0 + t) - 273.15);
+    c.s = ((17.38 * 239.0) * sv) * (rd * rd);
+    const double lhv = (2.501 - 0.002361 * tc) * 1e6;
+    c.gamma = (1013.0 * pa) * M::rcp(lhv * 0.622);
+    c.inv_rc = (pa * (1.0 / 101300.0)) * M::pow_m1p75(t * (1.0 / 293.15));   // 1 / r_corr
+    const double nn = 0.348444 * (pa * 0.01) - (rh * 100.0) * (0.00252 * tc - 0.020582);
+    const double rho_cp = 1013.0 * (nn * M::rcp(t));
+    c.g_rr = (K<double>::sigma4 * ((t * t) * t)) * M::rcp(rho_cp);           // 1 / r_r
+    c.rcfv = rho_cp * vpd;
+    c.logrh = M::log_tab(rh, tb);
+    return c;
+}
+
+__device__ __forceinline__ StaticPixel static_pixel_prep(const PixelIn<double>& x, const double* tb) {
+    StaticPixel c;
+    c.d = static_period_prep(x.t_d, x.vpd_d, x.sw_d, x.lw_d, x.alb, x.fpar, x.pa, tb);
+    c.n = static_period_prep(x.t_n, x.vpd_n, x.sw_n, x.lw_n, x.alb, x.fpar, x.pa, tb);
+    c.fpar = x.fpar; c.omf = 1.0 - x.fpar; c.lai = x.lai; c.lai_pos = x.lai > 0.0;
+    c.tm = x.tmin - 273.15; c.t_ann = x.t_ann;
+    // soil heat flux, :225-252: the condition's parameter-dependent part is applied per draw
+    c.base_cond = (x.t_ann < 273.15 + 25.0) && ((x.t_d - x.t_n) >= 5.0);
+    const double a_d = __builtin_fma(x.sw_d, 1.0 - x.alb, x.lw_d), a_n = x.lw_n;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        double g_d = k ? (4.73 * (x.t_d - 273.15)) - 20.87 : 0.0;
+        g_d = (__builtin_fabs(g_d) > (0.39 * __builtin_fabs(a_d))) ? 0.39 * a_d : g_d;
+        double g_n = k ? (4.73 * (x.t_n - 273.15)) - 20.87 : 0.0;
+        g_n = (__builtin_fabs(g_n) > (0.39 * __builtin_fabs(a_n))) ? 0.39 * a_n : g_n;
+        g_d = ((a_d - g_d < 0.0) && (a_d > 0.0)) ? a_d : g_d;
+        g_n = ((a_d > 0.0) && ((a_n - g_n) < (-0.5 * a_d))) ? a_n + (0.5 * a_d) : g_n;
+        c.rs_d[k] = c.omf * (a_d - g_d);
+        c.rs_n[k] = c.omf * (a_n - g_n);
+    }
+    return c;
+}
+
+// per-draw terms shared by both periods
+struct StaticDraw {
+    double m_tmin, inv_dvpd, rbl_slope, inv_beta;
+    bool cond;
+};
+__device__ __forceinline__ StaticDraw static_draw_prep(const StaticPixel& c, const ClassPar<double>& p) {
+    typedef FastMath<double> M;
+    StaticDraw d;
+    d.m_tmin = (c.tm >= p.tmin_open) ? 1.0
+               : ((c.tm < p.tmin_close) ? 0.0 : (c.tm - p.tmin_close) * M::rcp(p.tmin_open - p.tmin_close));
+    d.inv_dvpd = M::rcp(p.vpd_close - p.vpd_open);
+    d.rbl_slope = (p.rbl_max - p.rbl_min) * d.inv_dvpd;
+    d.inv_beta = M::rcp(p.beta);
+    d.cond = c.base_cond && (c.t_ann > (273.15 + p.tmin_open));              // :230-234 (tmin_open, strict)
+    return d;
+}
+// day-time surface conductance / r_corr (the quantity behind any(g_surf > 0))
+__device__ __forceinline__ double static_gsurf(const StaticPeriod& c, const StaticDraw& d,
+                                               const ClassPar<double>& p) {
+    const double m_vpd = (c.vpd >= p.vpd_close) ? 0.0
+                         : ((c.vpd < p.vpd_open) ? 1.0 : 1.0 - (c.vpd - p.vpd_open) * d.inv_dvpd);
+    return ((p.csl * d.m_tmin) * m_vpd) * c.inv_rc;
+}
+
+template <bool DAY>
+__device__ __forceinline__ double static_period_eval(const StaticPixel& px, const StaticPeriod& c,
+                                                     const StaticDraw& d, const ClassPar<double>& p,
+                                                     double rad_soil, bool any_gs, const double* tb) {
+    typedef FastMath<double> M;
+    const double tiny = 1e-7;
+    const double sx = c.s * c.rad_c, rf = c.rcfv * px.fpar;
+    // wet canopy, :305-320
+    const double lf = px.lai * c.fw;
+    const double g_e = p.gl_wv * lf, g_a = p.gl_sh * lf + c.g_rr;
+    double e_can = ((c.fw * __builtin_fma(rf, g_a, sx)) * g_e) * M::rcp(__builtin_fma(c.s, g_e, c.gamma * g_a));
+    e_can = (lf <= tiny) ? 0.0 : e_can;
+    // transpiration, :325-348
+    double tr = 0.0;
+    if (any_gs) {
+        const double gsc = (DAY ? static_gsurf(c, d, p) : 0.0) + p.g_cut * c.inv_rc;
+        const double gl = (p.gl_sh * px.lai) * c.omw;
+        const bool open = px.lai_pos && (c.omw > 0.0);
+        const double p1 = open ? gl * gsc : tiny, s1 = open ? gl + gsc : 1.0;   // g_canopy = p1 / s1
+        const double g_d = p.gl_sh + c.g_rr;                                    // 1 / r_dry
+        const double num = (c.omw * __builtin_fma(rf, g_d, sx)) * p1;
+        const double den = __builtin_fma(c.s, p1, c.gamma * __builtin_fma(g_d, s1, p1));
+        tr = num * M::rcp(den);
+    }
+    // bare soil, :350-376
+    const double r0 = (c.vpd <= p.vpd_open) ? p.rbl_min
+                      : ((c.vpd >= p.vpd_close) ? p.rbl_max
+                         : __builtin_fma(-(p.vpd_close - c.vpd), d.rbl_slope, p.rbl_max));
+    const double r_tot = r0 * c.inv_rc;
+    const double w = __builtin_fma(r_tot, c.g_rr, 1.0);
+    const double num = __builtin_fma(c.s * rad_soil, r_tot, (c.rcfv * px.omf) * w);
+    const double q = num * M::rcp(r_tot * __builtin_fma(c.gamma, w, c.s));
+    const double yc = __builtin_fmin(c.vpd * d.inv_beta, 1e300);
+    const double pw = M::exp_tab(__builtin_fmax(yc * c.logrh, -746.0), tb);  // rh ** (vpd / beta), :376
+    const double e_soil = q * __builtin_fma(c.omw, pw, c.fw);
+    return (tr + e_can) + e_soil;                                            // :380
+}
+
 // ====================================================================== fast
 // Quantities that do not depend on the period (day / night).
 template <typename T> struct PixelShared {

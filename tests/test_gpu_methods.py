@@ -328,3 +328,41 @@ def test_batched_calibration_float32_and_shapes(m16):
     with pytest.raises(IndexError):
         m16.MOD16._et_batch(np.zeros((3, 10)), *drv)
     assert m16.MOD16._et_batch(np.zeros((0, 11)), *drv).shape == (0, 12, 40)
+
+
+def test_batched_calibration_fast_arithmetic(m16, golden):
+    """MOD16_MATH_FAST on the batched calibration path: the forward run's
+    strength-reduced float64 arithmetic; within 1e-9 of the reference-order rows
+    (and of the oracle) with identical NaN and exact-zero masks, on random tower
+    days with edge cases mixed in and on the reference's own vectors (F7)."""
+    drv, lo, hi, rng = _calibration_inputs(20000, 44)
+    drv[13][::50] = 0.0                       # lai = 0
+    drv[12][::61] = 0.0                       # fpar = 0
+    drv[12][7::61] = 1.0                      # fpar = 1
+    drv[9][::70] = 0.0                        # vpd = 0 (rh = 1)
+    drv[9][3::70] = -50.0                     # vpd < 0 (rh > 1: no upper clamp on this path)
+    drv[10][5::70] = 9000.0                   # beyond saturation (rh clamped at 0)
+    drv[5][::400] = np.nan
+    drv[11][11::500] = 0.0                    # pressure = 0
+    params = rng.uniform(lo, hi, (24, 11))
+    params[2, 7] = 0.0                        # csl = 0: the whole-array switch off
+    exact = m16.MOD16._et_batch(params, *drv, separate=True)
+    fast = m16.MOD16._et_batch(params, *drv, separate=True, math=m16._lib.MATH_FAST)
+    for e, f, what in zip(exact, fast, ('day', 'night')):
+        assert_parity(f, e, 1e-9, 'fast vs exact, ' + what)
+    tot = m16.MOD16._et_batch(params, *drv, math=m16._lib.MATH_FAST)
+    for d in (0, 2, 23):
+        assert_parity(tot[d], oracle.et_static(list(params[d]), *drv), 1e-9, 'oracle, draw %d' % d)
+    # the reference's own vectors (F7: 12 days x 40 sites, one parameter vector per site):
+    # draw j = site j's parameters over all pixels, of which site j's column is the reference's
+    f7 = golden('f7_static_path')
+    got = m16.MOD16._et_batch(f7['params'].T, *list(f7['drivers']), math=m16._lib.MATH_FAST)
+    assert got.shape == (40, 12, 40)
+    mine = np.stack([got[j, :, j] for j in range(40)], axis=1)
+    assert_parity(mine, f7['et'], 1e-9, 'F7')
+    # the fused objective takes the same switch
+    obs = tot[5] + rng.normal(0, 3, 20000)
+    s_e, c_e = m16.MOD16._et_batch(params, *drv, observed=obs)
+    s_f, c_f = m16.MOD16._et_batch(params, *drv, observed=obs, math=m16._lib.MATH_FAST)
+    assert np.array_equal(c_e, c_f)
+    np.testing.assert_allclose(s_f, s_e, rtol=1e-8)

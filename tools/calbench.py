@@ -32,6 +32,10 @@ def main():
     t = time.perf_counter()
     sse, cnt = M._et_batch(params, *drv, observed=obs)
     t_batch = time.perf_counter() - t
+    M._et_batch(params[:4], *drv, observed=obs, math=mod16_amd._lib.MATH_FAST)
+    t = time.perf_counter()
+    sse_f, cnt_f = M._et_batch(params, *drv, observed=obs, math=mod16_amd._lib.MATH_FAST)
+    t_fast = time.perf_counter() - t
     k = min(ndraw, 64)
     t = time.perf_counter()
     for d in range(k):
@@ -42,6 +46,8 @@ def main():
     print(json.dumps({
         'pixels': n, 'draws': ndraw,
         'batched_s': round(t_batch, 4), 'batched_pixel_draws_per_s': round(n * ndraw / t_batch),
+        'batched_fast_s': round(t_fast, 4), 'batched_fast_pixel_draws_per_s': round(n * ndraw / t_fast),
+        'fast_vs_exact_objective_max_rel_diff': float(np.max(np.abs(sse_f - sse) / sse)),
         'single_call_s_per_draw': round(t_loop, 5),
         'single_call_pixel_draws_per_s': round(n / t_loop),
         'batched_vs_single_call': round(t_loop * ndraw / t_batch, 1),
