@@ -56,6 +56,8 @@ struct mod16_ctx {
     hipStream_t streams[kSlots] = {};
     std::mutex launch_mu;            // HOST mode: kernel launches of the staging threads
     void* scalars = nullptr;         // device copies of broadcast scalars
+    void* batch_buf = nullptr;       // HOST-mode workspace of mod16_et_static_batch_*
+    size_t batch_bytes = 0;
     std::string err;
 };
 
@@ -111,6 +113,7 @@ extern "C" int mod16_destroy(mod16_ctx* ctx) {
         if (ctx->streams[s]) (void)hipStreamDestroy(ctx->streams[s]);
     }
     if (ctx->scalars) (void)hipFree(ctx->scalars);
+    if (ctx->batch_buf) (void)hipFree(ctx->batch_buf);
     if (ctx->lut64) (void)hipFree(ctx->lut64);
     if (ctx->lut32) (void)hipFree(ctx->lut32);
     if (ctx->tab64) (void)hipFree(ctx->tab64);
@@ -1175,11 +1178,21 @@ static int static_batch_entry(mod16_ctx* ctx, const T* const* drivers, const int
     const size_t flag_b = (((size_t)ndraw * sizeof(unsigned)) + 255) / 256 * 256;
     const size_t total = per_arr * 16 + par_b + 2 * red_b + flag_b +
                          per_out * ((int)want[0] + (int)want[1] + (int)want[2]);
-    char* base = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&base), total) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(ctx, MOD16_ERR_NOMEM, "mod16_et_static_batch: device memory for the [ndraw][n] outputs");
+    // workspace kept in the context between calls (a calibration loop repeats the same
+    // shape thousands of times); it only grows, up to kBatchKeepBytes it is kept
+    constexpr size_t kBatchKeepBytes = size_t(8) << 30;
+    if (ctx->batch_bytes < total) {
+        if (ctx->batch_buf) HIPCHK(ctx, hipFree(ctx->batch_buf));
+        ctx->batch_buf = nullptr;
+        ctx->batch_bytes = 0;
+        if (hipMalloc(&ctx->batch_buf, total) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->batch_buf = nullptr;
+            return fail(ctx, MOD16_ERR_NOMEM, "mod16_et_static_batch: device memory for the [ndraw][n] outputs");
+        }
+        ctx->batch_bytes = total;
     }
+    char* base = static_cast<char*>(ctx->batch_buf);
     int rc = MOD16_OK;
     auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == MOD16_OK) { rc = MOD16_ERR_HIP; ctx->err = hipGetErrorString(e); } };
     char* cur = base;
@@ -1211,7 +1224,11 @@ static int static_batch_entry(mod16_ctx* ctx, const T* const* drivers, const int
         }
     }
     chk(hipStreamSynchronize(st));
-    (void)hipFree(base);
+    if (ctx->batch_bytes > kBatchKeepBytes) {
+        (void)hipFree(ctx->batch_buf);
+        ctx->batch_buf = nullptr;
+        ctx->batch_bytes = 0;
+    }
     return rc;
 }
 
