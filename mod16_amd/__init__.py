@@ -83,7 +83,7 @@ def _marshal(values, shape, dtype):
     return keep, ptrs, strides
 
 
-def _forward(cls, drivers, params, separate, flags, device, pet=False):
+def _forward(cls, drivers, params, separate, flags, device, pet=False, out=None):
     '''Shared host path of MOD16.evapotranspiration and
     evapotranspiration_raster: marshal numpy inputs, run mod16_et_* in HOST
     mode, shape the outputs as the reference does (mod16/__init__.py:789-793).
@@ -121,12 +121,22 @@ def _forward(cls, drivers, params, separate, flags, device, pet=False):
         if not shape:
             outs = [o[()] for o in outs]
         return tuple(outs)
+    nout = 6 if separate else 2
+    if out is not None:      # caller's arrays (e.g. memory-mapped files), written in place
+        outs = list(out)
+        if len(outs) != nout:
+            raise ValueError('out must hold %d arrays' % nout)
+        for o in outs:
+            if not (isinstance(o, np.ndarray) and o.shape == shape and o.dtype == dtype
+                    and o.flags.c_contiguous and o.flags.writeable):
+                raise ValueError('out arrays must be writeable C-contiguous %s arrays of shape %s'
+                                 % (dtype, shape))
+    else:
+        outs = [np.empty(shape, dtype) for _ in range(nout)]
     if separate:
-        outs = [np.empty(shape, dtype) for _ in range(6)]
         day = night = None
         sep = [o.ctypes.data for o in outs]
     else:
-        outs = [np.empty(shape, dtype) for _ in range(2)]
         day, night = outs[0].ctypes.data, outs[1].ctypes.data
         sep = None
     if n:
@@ -562,7 +572,7 @@ def evapotranspiration_raster(
         bplut, cls, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
         sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
         vpd_night, pressure, fpar, lai, separate=False, beta=None,
-        math=_lib.MATH_FAST, device=0, pet=False):
+        math=_lib.MATH_FAST, device=0, pet=False, out=None):
     r'''
     Forward run over a multi-class raster. Equivalent to the reference idiom
     (forward-run notebook, cell 32)::
@@ -589,6 +599,10 @@ def evapotranspiration_raster(
     pet : bool
         (Extension) True to return ``(day, night, pet_day, pet_night)``, see
         ``MOD16.evapotranspiration_and_pet``
+    out : sequence of numpy.ndarray
+        (Extension) the 2 (or, with ``separate``, 6) output arrays to write
+        into instead of allocating them, e.g. memory-mapped files
+        (``mod16_amd.io``)
 
     Returns
     -------
@@ -608,7 +622,7 @@ def evapotranspiration_raster(
         lw_net_day, lw_net_night, sw_rad_day, sw_rad_night, sw_albedo,
         temp_day, temp_night, temp_annual, tmin, vpd_day, vpd_night,
         pressure, fpar, lai)
-    return _forward(cls, drivers, None, separate, math, device, pet=pet)
+    return _forward(cls, drivers, None, separate, math, device, pet=pet, out=out)
 
 
 def evapotranspiration_raw(

@@ -302,3 +302,28 @@ def test_raw_driver_forward_run(m16, golden, mode):
     raw2[13] = np.full((48, 50), 350.0)
     w2, _ = oracle.evapotranspiration_raw(bplut, f['cls'], raw2, f['fpar_pct'], f['lai_x10'])
     assert_parity(d2, w2, RTOL[mode], 'scalar elevation')
+
+
+def test_rasters_on_disk(m16, tmp_path):
+    """SURVEY.md 8f N4 (.npy memory maps through the HOST mode): same bits as
+    the in-memory call, outputs written in place."""
+    from mod16_amd import io as m16io
+    f = np.load(__import__('os').path.join(__import__('conftest').GOLDEN, 'f3_random64_f64.npz'))
+    cls, drv = synth.drivers((1500, 1700), seed=8)
+    paths = {}
+    for name, d in zip(m16io.DRIVER_NAMES, drv):
+        paths[name] = str(tmp_path / (name + '.npy'))
+        np.save(paths[name], d)
+    np.save(str(tmp_path / 'cls.npy'), cls)
+    day, night = m16io.evapotranspiration_npy(
+        f['table'], str(tmp_path / 'cls.npy'), paths, str(tmp_path / 'day.npy'), str(tmp_path / 'night.npy'))
+    want_d, want_n = m16.evapotranspiration_raster(f['table'], cls, *drv)
+    assert np.array_equal(np.load(str(tmp_path / 'day.npy')), want_d, equal_nan=True)
+    assert np.array_equal(np.load(str(tmp_path / 'night.npy')), want_n, equal_nan=True)
+    assert day.shape == (1500, 1700) and isinstance(day, np.memmap)
+    with pytest.raises(KeyError):
+        m16io.evapotranspiration_npy(f['table'], str(tmp_path / 'cls.npy'), {'lai': paths['lai']},
+                                     str(tmp_path / 'd2.npy'), str(tmp_path / 'n2.npy'))
+    # out= of the in-memory interface: wrong shape / dtype is refused
+    with pytest.raises(ValueError):
+        m16.evapotranspiration_raster(f['table'], cls, *drv, out=[np.empty((3, 3)), np.empty((3, 3))])
