@@ -132,10 +132,11 @@ MOD16_API int mod16_et_f64(mod16_ctx* ctx, const uint8_t* cls,
 /* float32 data: MOD16_MATH_FAST widens to float64 on load, computes in float64 and
  * rounds once on store; MOD16_MATH_EXACT keeps float32 arithmetic in the reference's
  * operation order (what numpy does for the reference on float32 inputs);
- * MOD16_MATH_MIXED (dense class rasters, totals): float64 for the radiation balance,
- * the Tmin ramp and the humidity terms -- every decision behind a NaN or an exact
- * zero -- and packed float32 for the rest; same masks as FAST, median relative
- * difference 1e-7, absolute difference below 1e-6 of the largest value, 1.4x faster */
+ * MOD16_MATH_MIXED (dense class rasters, totals): float64 for the humidity terms (and
+ * for the radiation balance next to its clamps), packed float32 for the rest, every
+ * decision behind a NaN or an exact zero made as in FAST; same masks as FAST, median
+ * relative difference 1e-7, absolute difference below 1e-6 of the largest value,
+ * 1.5x faster */
 MOD16_API int mod16_et_f32(mod16_ctx* ctx, const uint8_t* cls,
                  const float* const* drivers, const int64_t* dstride,
                  const float* const* params, const int64_t* pstride,

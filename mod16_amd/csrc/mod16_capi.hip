@@ -205,6 +205,12 @@ extern "C" int mod16_set_bplut_f64(mod16_ctx* ctx, const double* lut) {
             row[12] = 1.0 / (p[MOD16_VPD_CLOSE] - p[MOD16_VPD_OPEN]);
             row[13] = (p[MOD16_RBL_MAX] - p[MOD16_RBL_MIN]) / (p[MOD16_VPD_CLOSE] - p[MOD16_VPD_OPEN]);
             row[14] = 1.0 / p[MOD16_BETA];
+            // smallest float32 >= 273.15 + tmin_close: for a float32 x,
+            // x >= 273.15 + tmin_close (in float64) <=> x >= this (mixed-precision form)
+            const double thr = 273.15 + p[MOD16_TMIN_CLOSE];
+            float tf = (float)thr;
+            if ((double)tf < thr) tf = std::nextafterf(tf, std::numeric_limits<float>::infinity());
+            row[15] = (double)tf;
         }
         for (int k = 0; k < MOD16_LUT_ROWS; ++k) {
             h64[k * kLutCols + c] = row[k];

@@ -8,14 +8,18 @@
 // on PAIRS of pixels (float2) and keeps float64 only where it decides something
 // or where a difference of nearly equal numbers feeds a quotient:
 //
-//   float64  the radiation balance with its discontinuous soil-heat-flux clamps
-//            (mod16/__init__.py:1033-1052, :1103-1112), the Tmin ramp (:1148), and per
-//            period esat -> avp = esat - vpd -> rh, the rh < 0.7 and 1 - fwet > 0
-//            decisions (:646-673, :763-764, :1245). Every NaN / exact-zero mask that is
-//            decided here is decided exactly as in the FAST form.
-//   float32  everything downstream (slope, densities, conductances, the three
-//            Penman-Monteith quotients), packed; reciprocals, 2^x and log2 x are
-//            the hardware ones (v_rcp_f32, v_exp_f32, v_log_f32, 1 ulp).
+//   float64  per period esat -> avp = esat - vpd -> rh with the rh < 0.7 and
+//            1 - fwet > 0 decisions (mod16/__init__.py:646-673, :763-764, :1245); and the
+//            radiation balance with its discontinuous soil-heat-flux clamps (:1033-1052,
+//            :1103-1112) for the waves in which some pixel sits within 1e-3 W m-2 of one of
+//            those clamps (about 1 wave-iteration in 300).
+//   float32  that radiation balance everywhere else (the comparisons whose operands are
+//            inputs are made exact by rounding the threshold the right way, the computed
+//            ones are the near-tie test), the Tmin ramp, and everything downstream
+//            (slope, densities, conductances, the three Penman-Monteith quotients),
+//            packed; reciprocals, 2^x and log2 x are the hardware ones (v_rcp_f32,
+//            v_exp_f32, v_log_f32, 1 ulp).
+// Every decision behind a NaN or an exact zero is made as in the FAST form.
 //
 // Accuracy against the float64 arithmetic on the same float32 inputs, all 933 M
 // pixels of the global grid x 2 outputs (bench.py --dtype float32 --math mixed):
@@ -154,37 +158,70 @@ __device__ __forceinline__ f2 period_mixed(const ClassPar2& p, const Shared2& sh
 __device__ __forceinline__ void et_pair_mixed(const float (&in)[14][2], const double* l0,
                                               const double* l1, int ls, const double* tb,
                                               f2& day, f2& night) {
-    const double* l[2] = {l0, l1};
-    float a_d[2], rs_d[2], rs_n[2], rn_n[2], m_tmin[2];
+    const f2 zero = splat(0.f);
+    auto col = [&](int k) { return f2{in[k][0], in[k][1]}; };
+    auto par = [&](int row) { return f2{(float)l0[row * ls], (float)l1[row * ls]}; };
+    // ---- radiation received by the soil, :963-1119, float32
+    const f2 lw_d = col(0), lw_n = col(1), sw_d = col(2), sw_n = col(3), alb = col(4);
+    const f2 t_d = col(5), t_n = col(6), t_ann = col(7), fpar = col(12);
+    const f2 oma = splat(1.f) - alb, omf = splat(1.f) - fpar;
+    f2 a_d = __builtin_elementwise_fma(sw_d, oma, lw_d);
+    const f2 a_n = lw_n;
+    // x < 298.15 (float64) <=> x < RU(298.15); x >= 273.15 + tmin_close <=> x >= row 15 of
+    // the table; t_d - t_n is exact in float32 for temperatures within a factor 2
+    const i2 cond = (t_ann < splat(298.150024f)) & (t_ann >= par(15)) & ((t_d - t_n) >= splat(5.f));
+    // t - 273.15 as (t - 273) - 0.15: both differences are exact or correctly rounded
+    const f2 gd0 = cond ? __builtin_elementwise_fma(splat(4.73f), (t_d - splat(273.f)) - splat(0.15f), splat(-20.87f)) : zero;
+    const f2 gn0 = cond ? __builtin_elementwise_fma(splat(4.73f), (t_n - splat(273.f)) - splat(0.15f), splat(-20.87f)) : zero;
+    const f2 lim_d = splat(0.39f) * __builtin_elementwise_abs(a_d), lim_n = splat(0.39f) * __builtin_elementwise_abs(a_n);
+    const f2 agd = __builtin_elementwise_abs(gd0), agn = __builtin_elementwise_abs(gn0);
+    const f2 gd1 = (agd > lim_d) ? splat(0.39f) * a_d : gd0;
+    const f2 gn1 = (agn > lim_n) ? splat(0.39f) * a_n : gn0;
+    const f2 dd = a_d - gd1;
+    const f2 gd2 = ((dd < zero) & (a_d > zero)) ? a_d : gd1;
+    const f2 dn = (a_n - gn1) + splat(0.5f) * a_d;
+    const f2 gn2 = ((a_d > zero) & (dn < zero)) ? a_n + splat(0.5f) * a_d : gn1;
+    f2 rs_d = omf * (a_d - gd2), rs_n = omf * (a_n - gn2);
+    f2 rn_n = __builtin_elementwise_fma(sw_n, oma, lw_n);
+    // near-ties of the computed comparisons: operands within 1e-3 W m-2 (their float32
+    // errors are below 1e-4) -> this wave redoes the balance in float64 for these pixels
+    const f2 tol = splat(1e-3f);
+    const i2 near = (__builtin_elementwise_abs(agd - lim_d) <= tol) | (__builtin_elementwise_abs(agn - lim_n) <= tol) |
+                    (__builtin_elementwise_abs(dd) <= tol) | (__builtin_elementwise_abs(a_d) <= tol) |
+                    (__builtin_elementwise_abs(dn) <= tol);
+    if (__any((near.x | near.y) != 0)) {
+        float r[4][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double xlw_d = in[0][j], xlw_n = in[1][j], xsw_d = in[2][j], xsw_n = in[3][j], xalb = in[4][j];
+            const double xt_d = in[5][j], xt_n = in[6][j], xt_ann = in[7][j], xfpar = in[12][j];
+            const double tmin_close = (j ? l1 : l0)[0 * ls];
+            const double xoma = 1.0 - xalb, xomf = 1.0 - xfpar;
+            const double ad = __builtin_fma(xsw_d, xoma, xlw_d);
+            const double an = xlw_n;
+            const bool cnd = (xt_ann < 273.15 + 25.0) && (xt_ann >= (273.15 + tmin_close)) && ((xt_d - xt_n) >= 5.0);
+            double g_d = cnd ? (4.73 * (xt_d - 273.15)) - 20.87 : 0.0;
+            g_d = (__builtin_fabs(g_d) > (0.39 * __builtin_fabs(ad))) ? 0.39 * ad : g_d;
+            double g_n = cnd ? (4.73 * (xt_n - 273.15)) - 20.87 : 0.0;
+            g_n = (__builtin_fabs(g_n) > (0.39 * __builtin_fabs(an))) ? 0.39 * an : g_n;
+            g_d = ((ad - g_d < 0.0) && (ad > 0.0)) ? ad : g_d;
+            g_n = ((ad > 0.0) && ((an - g_n) < (-0.5 * ad))) ? an + (0.5 * ad) : g_n;
+            r[0][j] = (float)ad;
+            r[1][j] = (float)(xomf * (ad - g_d));
+            r[2][j] = (float)(xomf * (an - g_n));
+            r[3][j] = (float)__builtin_fma(xsw_n, xoma, xlw_n);
+        }
+        a_d = f2{r[0][0], r[0][1]}; rs_d = f2{r[1][0], r[1][1]};
+        rs_n = f2{r[2][0], r[2][1]}; rn_n = f2{r[3][0], r[3][1]};
+    }
+    // ---- float64: humidity of both periods
     Humid2 hd, hn;
     bool dry_d[2], dry_n[2], open_d[2], open_n[2];
     float esat_d[2], rh_d[2], fwet_d[2], omw_d[2], esat_n[2], rh_n[2], fwet_n[2], omw_n[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        // ---- float64: radiation received by the soil, :963-1119 (predicates verbatim)
-        const double lw_d = in[0][j], lw_n = in[1][j], sw_d = in[2][j], sw_n = in[3][j], alb = in[4][j];
-        const double t_d = in[5][j], t_n = in[6][j], t_ann = in[7][j], tmin = in[8][j];
-        const double fpar = in[12][j];
-        const double tmin_close = l[j][0 * ls], tmin_open = l[j][1 * ls], inv_dtmin = l[j][11 * ls];
-        const double oma = 1.0 - alb, omf = 1.0 - fpar;
-        const double ad = __builtin_fma(sw_d, oma, lw_d);
-        const double an = lw_n;
-        const bool cond = (t_ann < 273.15 + 25.0) && (t_ann >= (273.15 + tmin_close)) && ((t_d - t_n) >= 5.0);
-        double g_d = cond ? (4.73 * (t_d - 273.15)) - 20.87 : 0.0;
-        g_d = (__builtin_fabs(g_d) > (0.39 * __builtin_fabs(ad))) ? 0.39 * ad : g_d;
-        double g_n = cond ? (4.73 * (t_n - 273.15)) - 20.87 : 0.0;
-        g_n = (__builtin_fabs(g_n) > (0.39 * __builtin_fabs(an))) ? 0.39 * an : g_n;
-        g_d = ((ad - g_d < 0.0) && (ad > 0.0)) ? ad : g_d;
-        g_n = ((ad > 0.0) && ((an - g_n) < (-0.5 * ad))) ? an + (0.5 * ad) : g_n;
-        a_d[j] = (float)ad;
-        rs_d[j] = (float)(omf * (ad - g_d));
-        rs_n[j] = (float)(omf * (an - g_n));
-        rn_n[j] = (float)__builtin_fma(sw_n, oma, lw_n);
-        const double tm = tmin - 273.15;
-        m_tmin[j] = (float)((tm >= tmin_open) ? 1.0 : ((tm < tmin_close) ? 0.0 : (tm - tmin_close) * inv_dtmin));
-        // ---- float64: humidity of both periods
-        humid64(t_d, (double)in[9][j], tb, esat_d[j], rh_d[j], fwet_d[j], omw_d[j], dry_d[j], open_d[j]);
-        humid64(t_n, (double)in[10][j], tb, esat_n[j], rh_n[j], fwet_n[j], omw_n[j], dry_n[j], open_n[j]);
+        humid64((double)in[5][j], (double)in[9][j], tb, esat_d[j], rh_d[j], fwet_d[j], omw_d[j], dry_d[j], open_d[j]);
+        humid64((double)in[6][j], (double)in[10][j], tb, esat_n[j], rh_n[j], fwet_n[j], omw_n[j], dry_n[j], open_n[j]);
     }
     hd.esat = f2{esat_d[0], esat_d[1]}; hd.rh = f2{rh_d[0], rh_d[1]};
     hd.fwet = f2{fwet_d[0], fwet_d[1]}; hd.omw = f2{omw_d[0], omw_d[1]};
@@ -194,15 +231,14 @@ __device__ __forceinline__ void et_pair_mixed(const float (&in)[14][2], const do
     hn.dry = mask2(dry_n[0], dry_n[1]); hn.open_w = mask2(open_n[0], open_n[1]);
 
     // ---- float32, packed
-    auto par = [&](int row) { return f2{(float)l0[row * ls], (float)l1[row * ls]}; };
     ClassPar2 p;
     p.vpd_open = par(2); p.vpd_close = par(3); p.gl_sh = par(4); p.gl_wv = par(5);
     p.g_cut = par(6); p.csl = par(7); p.rbl_min = par(8); p.rbl_max = par(9);
     p.inv_dvpd = par(12); p.rbl_slope = par(13); p.inv_beta = par(14);
-    const f2 pa = f2{in[11][0], in[11][1]}, lai = f2{in[13][0], in[13][1]};
+    const f2 pa = col(11), lai = col(13);
     Shared2 sh;
-    sh.fpar = f2{in[12][0], in[12][1]};
-    sh.omf = splat(1.f) - sh.fpar;
+    sh.fpar = fpar;
+    sh.omf = omf;
     sh.p_rel = pa * splat((float)(1.0 / 101300.0));
     sh.k_p = pa * splat((float)(1013.0 / 0.622));
     sh.p_mbar_k = pa * splat((float)(0.348444 / 100.0));
@@ -212,11 +248,12 @@ __device__ __forceinline__ void et_pair_mixed(const float (&in)[14][2], const do
     sh.glsh_l = p.gl_sh * l_wet;
     sh.glwv_l = p.gl_wv * l_wet;
     sh.glsh_lai = p.gl_sh * lai;
-    sh.m_tmin = f2{m_tmin[0], m_tmin[1]};
-    day = period_mixed<true>(p, sh, hd, f2{in[5][0], in[5][1]}, f2{in[9][0], in[9][1]},
-                             f2{a_d[0], a_d[1]}, f2{rs_d[0], rs_d[1]});
-    night = period_mixed<false>(p, sh, hn, f2{in[6][0], in[6][1]}, f2{in[10][0], in[10][1]},
-                                f2{rn_n[0], rn_n[1]}, f2{rs_n[0], rs_n[1]});
+    // Tmin ramp, :1148 (continuous: a float32 tie decides nothing)
+    const f2 tm = (col(8) - splat(273.f)) - splat(0.15f);
+    const f2 tmin_close = par(0), tmin_open = par(1);
+    sh.m_tmin = (tm >= tmin_open) ? splat(1.f) : ((tm < tmin_close) ? zero : (tm - tmin_close) * par(11));
+    day = period_mixed<true>(p, sh, hd, t_d, col(9), a_d, rs_d);
+    night = period_mixed<false>(p, sh, hn, t_n, col(10), rn_n, rs_n);
 }
 
 }  // namespace mod16

@@ -37,7 +37,7 @@ template <typename T> struct ClassPar {
         inv_beta = T(1) / beta;
     }
 };
-#define MOD16_LUT_ROWS 15  // 11 parameters + 4 derived, LDS layout [row][16]
+#define MOD16_LUT_ROWS 16  // 11 parameters + 5 derived, LDS layout [row][16]
 
 template <typename T> struct PixelOut {
     T canopy_d, soil_d, trans_d, canopy_n, soil_n, trans_n;
