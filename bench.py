@@ -121,6 +121,8 @@ def main():
     ap.add_argument('--dtype', default='float64', choices=['float64', 'float32'])
     ap.add_argument('--math', default='fast', choices=['fast', 'exact', 'mixed'],
                     help="'mixed': the mixed-precision form for --dtype float32 (configs[4])")
+    ap.add_argument('--no-graph', action='store_true',
+                    help='enqueue the step kernel by kernel instead of replaying its HIP graph')
     ap.add_argument('--no-tune', action='store_true',
                     help='arrays of the raster slab back to back instead of the measured best spacing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -184,7 +186,7 @@ def main():
     # step s runs on a side stream under the kernel of step s + 1 (for N > 1;
     # the kernel of step s + 2, which reuses the vector, waits for it).
     diags = [torch.zeros(8, dtype=torch.float64, device='cuda') for _ in range(2)]
-    launches = [eng.bind(cls, drv, day, night, d) for d in diags]
+    launches = [eng.bind(cls, drv, day, night, d, graph=not args.no_graph) for d in diags]
     diag, launch = diags[0], launches[0]
     main_stream = torch.cuda.current_stream()
     comm_stream = torch.cuda.Stream() if world > 1 else None
@@ -364,8 +366,8 @@ def main():
                                args.rows // world, -(-args.rows // world)),
                 'pixels': total, 'pixels_per_gpu': n, 'parallelism': 'tile-dp%d' % world,
                 'math': args.math, 'bplut': os.path.basename(COLLECTION61_BPLUT),
-                'step': 'fused ET kernel with in-kernel diagnostics + fixed-order final sum + all-reduce(8 doubles) '
-                        'overlapped with the next step on a side stream',
+                'step': 'fused ET kernel with in-kernel diagnostics + fixed-order final sum (one HIP graph launch) + '
+                        'all-reduce(8 doubles) overlapped with the next step on a side stream',
                 'slab_layout': dict(layout, note='rank 0; set-up, not timed: spacing between the arrays '
                                                  'of the raster slab chosen by measurement'),
             },

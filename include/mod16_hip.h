@@ -222,6 +222,27 @@ MOD16_API int mod16_et_diag_f32(mod16_ctx* ctx, const uint8_t* cls,
                       unsigned flags, double* ddiag, void* stream);
 
 /*
+ * mod16_et_diag_* for a raster that is processed again and again (one call per
+ * time step of a series): the launch sequence -- ticket-counter reset, pipeline
+ * kernel, staged fixed-order sum of the diagnostics -- is captured once into a
+ * HIP graph and replayed by mod16_graph_launch on any stream. All pointers are
+ * DEVICE pointers and must stay valid and in place; the raster's contents may
+ * change between launches. Replays of one graph must be ordered (one stream, or
+ * events); deferred errors surface through mod16_check_status as usual.
+ */
+typedef struct mod16_graph mod16_graph;
+MOD16_API int mod16_graph_et_diag_f64(mod16_ctx* ctx, const uint8_t* cls,
+                      const double* const* drivers, const int64_t* dstride,
+                      int64_t n, double* out_day, double* out_night,
+                      unsigned flags, double* ddiag, mod16_graph** out);
+MOD16_API int mod16_graph_et_diag_f32(mod16_ctx* ctx, const uint8_t* cls,
+                      const float* const* drivers, const int64_t* dstride,
+                      int64_t n, float* out_day, float* out_night,
+                      unsigned flags, double* ddiag, mod16_graph** out);
+MOD16_API int mod16_graph_launch(mod16_graph* graph, void* stream);
+MOD16_API int mod16_graph_destroy(mod16_graph* graph);
+
+/*
  * The sub-methods of the reference's class surface (mod16/__init__.py:384-673,
  * :795-1258, :1261-1397), reference operation order. `method` selects one;
  * `in` holds MOD16_METHOD_MAX_IN pointers in the order of the reference

@@ -78,6 +78,14 @@ PROTOTYPES = {
     'mod16_et_diag_f32': (C.c_int, [
         C.c_void_p, C.c_void_p, _PP, _I64P, C.c_int64, C.c_void_p, C.c_void_p,
         C.c_uint, C.c_void_p, C.c_void_p]),
+    'mod16_graph_et_diag_f64': (C.c_int, [
+        C.c_void_p, C.c_void_p, _PP, _I64P, C.c_int64, C.c_void_p, C.c_void_p,
+        C.c_uint, C.c_void_p, C.POINTER(C.c_void_p)]),
+    'mod16_graph_et_diag_f32': (C.c_int, [
+        C.c_void_p, C.c_void_p, _PP, _I64P, C.c_int64, C.c_void_p, C.c_void_p,
+        C.c_uint, C.c_void_p, C.POINTER(C.c_void_p)]),
+    'mod16_graph_launch': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mod16_graph_destroy': (C.c_int, [C.c_void_p]),
     'mod16_method_f64': (C.c_int, [
         C.c_void_p, C.c_int, _PP, _I64P, _PP, _I64P, C.c_int64, _PP, C.c_double,
         C.c_int, C.c_void_p]),

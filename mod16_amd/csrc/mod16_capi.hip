@@ -56,6 +56,7 @@ struct mod16_ctx {
     hipStream_t streams[kSlots] = {};
     std::mutex launch_mu;            // HOST mode: kernel launches of the staging threads
     void* scalars = nullptr;         // device copies of broadcast scalars
+    unsigned long long* force_counter = nullptr;   // ticket counter to use instead of the ring (graph capture)
     void* batch_buf = nullptr;       // HOST-mode workspace of mod16_et_static_batch_*
     size_t batch_bytes = 0;
     std::string err;
@@ -297,7 +298,8 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     s.lut64 = ctx->lut64;
     s.tab = ctx->tab64;
     s.status = ctx->status;
-    unsigned long long* ctr = ctx->dyn_counters + 16 * (ctx->dyn_next++ % 64);
+    unsigned long long* ctr = ctx->force_counter ? ctx->force_counter
+                                                 : ctx->dyn_counters + 16 * (ctx->dyn_next++ % 64);
     HIPCHK(ctx, hipMemsetAsync(ctr, 0, sizeof(unsigned long long), st));
     s.dyn_counter = ctr;
     const int64_t npiece = (s.n / V + 63) / 64;
@@ -646,6 +648,80 @@ extern "C" int mod16_et_diag_f32(mod16_ctx* ctx, const uint8_t* cls, const float
                                  const int64_t* dstride, int64_t n, float* out_day,
                                  float* out_night, unsigned flags, double* ddiag, void* stream) {
     return et_diag_entry<float>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, stream);
+}
+
+// ---- the forward run + diagnostics of one raster as a HIP graph: the launch
+// sequence of mod16_et_diag_* (counter reset, pipeline kernel, staged fixed-order
+// sum) captured once and replayed with one call per time step.
+struct mod16_graph {
+    mod16_ctx* ctx = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    unsigned long long* counter = nullptr;   // its own ticket counter: replays never meet the ring
+};
+
+extern "C" int mod16_graph_destroy(mod16_graph* g) {
+    if (!g) return MOD16_OK;
+    if (g->ctx) (void)hipSetDevice(g->ctx->device);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    if (g->counter) (void)hipFree(g->counter);
+    delete g;
+    return MOD16_OK;
+}
+
+template <typename T>
+static int graph_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drivers,
+                       const int64_t* dstride, int64_t n, T* out_day, T* out_night, unsigned flags,
+                       double* ddiag, mod16_graph** out) {
+    if (!ctx || !out) return MOD16_ERR_ARG;
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->streams[0]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking));
+    hipStream_t st = ctx->streams[0];
+    mod16_graph* g = new (std::nothrow) mod16_graph;
+    if (!g) return MOD16_ERR_NOMEM;
+    g->ctx = ctx;
+    int rc = [&]() -> int {
+        HIPCHK(ctx, hipMalloc(&g->counter, 128));
+        ctx->force_counter = g->counter;
+        // once outside a capture: validates the arguments and brings the workspace to size
+        int r = et_diag_entry<T>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, st);
+        if (r != MOD16_OK) return r;
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        r = et_diag_entry<T>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, st);
+        hipError_t e = hipStreamEndCapture(st, &g->graph);
+        if (r != MOD16_OK) return r;
+        HIPCHK(ctx, e);
+        HIPCHK(ctx, hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
+        return MOD16_OK;
+    }();
+    ctx->force_counter = nullptr;
+    if (rc != MOD16_OK) {
+        mod16_graph_destroy(g);
+        return rc;
+    }
+    *out = g;
+    return MOD16_OK;
+}
+
+extern "C" int mod16_graph_et_diag_f64(mod16_ctx* ctx, const uint8_t* cls, const double* const* drivers,
+                                       const int64_t* dstride, int64_t n, double* out_day,
+                                       double* out_night, unsigned flags, double* ddiag,
+                                       mod16_graph** out) {
+    return graph_entry<double>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, out);
+}
+extern "C" int mod16_graph_et_diag_f32(mod16_ctx* ctx, const uint8_t* cls, const float* const* drivers,
+                                       const int64_t* dstride, int64_t n, float* out_day,
+                                       float* out_night, unsigned flags, double* ddiag,
+                                       mod16_graph** out) {
+    return graph_entry<float>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, out);
+}
+extern "C" int mod16_graph_launch(mod16_graph* g, void* stream) {
+    if (!g || !g->exec) return MOD16_ERR_ARG;
+    HIPCHK(g->ctx, hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream)));
+    return MOD16_OK;
 }
 
 extern "C" int mod16_et_pet_f64(mod16_ctx* ctx, const uint8_t* cls, const double* const* drivers,

@@ -25,6 +25,21 @@ def _torch():
     return torch
 
 
+class _GraphHandle(object):
+    '''Owns a ``mod16_graph`` (destroyed with the bound launch that uses it).'''
+
+    def __init__(self, lib, handle):
+        self.lib, self.handle = lib, handle
+
+    def __del__(self):
+        try:
+            if self.handle and self.handle.value:
+                self.lib.mod16_graph_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 class RasterEngine(object):
     '''
     Parameters
@@ -313,11 +328,15 @@ class RasterEngine(object):
             return out_day, out_night, out_total8
         return out_day, out_night
 
-    def bind(self, cls, drivers, out_day, out_night, diag):
+    def bind(self, cls, drivers, out_day, out_night, diag, graph=True):
         '''Pre-marshal one ``run(..., diag=diag)`` call and return a function
         that enqueues it on the then-current stream with a single library call
         (the per-step host cost of a time loop: no tensor checks, no ctypes
-        array construction). The tensors must stay alive and in place.'''
+        array construction). With ``graph`` the launch sequence (counter
+        reset, pipeline kernel, staged sum of the diagnostics) is captured
+        into a HIP graph once (``mod16_graph_et_diag_*``) and a step is one
+        ``hipGraphLaunch``. The tensors must stay alive and in place; their
+        contents may change between steps.'''
         torch = _torch()
         n = cls.numel()
         cptr = self._check_tensor(cls, torch.uint8, n, 'cls')
@@ -326,10 +345,20 @@ class RasterEngine(object):
                 self._check_tensor(out_day, self.dtype, n, 'out_day'),
                 self._check_tensor(out_night, self.dtype, n, 'out_night'), int(self.math),
                 self._check_tensor(diag, torch.float64, 8, 'diag'))
-        fn = self.ctx.lib.mod16_et_diag_f32 if self.np_dtype == np.float32 \
-            else self.ctx.lib.mod16_et_diag_f64
-        check, device = self.ctx.check, self.device
+        f32 = self.np_dtype == np.float32
+        check, device, lib = self.ctx.check, self.device, self.ctx.lib
         keepalive = (keep, cls, out_day, out_night, diag)
+        if graph:
+            handle = C.c_void_p()
+            make = lib.mod16_graph_et_diag_f32 if f32 else lib.mod16_graph_et_diag_f64
+            check(make(*args, C.byref(handle)))
+            owner = _GraphHandle(lib, handle)
+
+            def launch():
+                check(lib.mod16_graph_launch(owner.handle, torch.cuda.current_stream(device).cuda_stream))
+                return keepalive[2], keepalive[3]
+            return launch
+        fn = lib.mod16_et_diag_f32 if f32 else lib.mod16_et_diag_f64
 
         def launch():
             check(fn(*args, torch.cuda.current_stream(device).cuda_stream))

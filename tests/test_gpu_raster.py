@@ -232,7 +232,8 @@ def test_time_series_streaming_ring(env):
     assert not torch.equal(diag[0], diag[1])
 
 
-def test_bound_launch_equals_run(env):
+@pytest.mark.parametrize('graph', [True, False])
+def test_bound_launch_equals_run(env, graph):
     torch, RasterEngine, table = env
     eng = RasterEngine(table)
     n = 200000
@@ -241,13 +242,21 @@ def test_bound_launch_equals_run(env):
     a, b = eng.run(cls, drv, diag=d1)
     day, night = eng.empty(n, 2)
     d2 = torch.zeros(8, dtype=torch.float64, device='cuda')
-    launch = eng.bind(cls, drv, day, night, d2)
+    launch = eng.bind(cls, drv, day, night, d2, graph=graph)
     for _ in range(3):
         launch()
     eng.check()
     assert torch.equal(d1, d2)
     assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(day))
     assert torch.equal(torch.nan_to_num(b), torch.nan_to_num(night))
+    # a bound launch follows the raster's contents (the graph holds pointers, not values)
+    eng.synth(n, seed=10, out=(cls, drv))
+    launch()
+    a2, b2 = eng.run(cls, drv, diag=d1)
+    eng.check()
+    assert torch.equal(d1, d2) and not torch.equal(torch.nan_to_num(a), torch.nan_to_num(a2))
+    assert torch.equal(torch.nan_to_num(a2), torch.nan_to_num(day))
+    assert torch.equal(torch.nan_to_num(b2), torch.nan_to_num(night))
 
 
 def test_unaligned_device_pointers_take_the_scalar_path(env):
