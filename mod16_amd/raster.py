@@ -351,13 +351,19 @@ class RasterEngine(object):
         if graph:
             handle = C.c_void_p()
             make = lib.mod16_graph_et_diag_f32 if f32 else lib.mod16_graph_et_diag_f64
-            check(make(*args, C.byref(handle)))
-            owner = _GraphHandle(lib, handle)
+            rc = make(*args, C.byref(handle))
+            if rc == _lib.OK:
+                owner = _GraphHandle(lib, handle)
 
-            def launch():
-                check(lib.mod16_graph_launch(owner.handle, torch.cuda.current_stream(device).cuda_stream))
-                return keepalive[2], keepalive[3]
-            return launch
+                def launch():
+                    check(lib.mod16_graph_launch(owner.handle, torch.cuda.current_stream(device).cuda_stream))
+                    return keepalive[2], keepalive[3]
+                return launch
+            if rc != _lib.ERR_HIP:      # argument errors are the caller's; a refused capture is not
+                check(rc)
+            import warnings
+            warnings.warn('HIP graph capture failed (%s); the bound launch enqueues its kernels one by one'
+                          % self.ctx.lib.mod16_last_error(self.ctx.handle).decode())
         fn = lib.mod16_et_diag_f32 if f32 else lib.mod16_et_diag_f64
 
         def launch():
