@@ -180,7 +180,12 @@ def main():
         cls, drv, day, night = eng.alloc_raster(n)
         layout = {'chosen_extra_bytes': 0}
     else:
-        (cls, drv, day, night), layout = eng.alloc_raster_tuned(n)
+        try:
+            (cls, drv, day, night), layout = eng.alloc_raster_tuned(n)
+        except RuntimeError as exc:      # no room for the candidates' slack: back-to-back layout
+            torch.cuda.empty_cache()
+            cls, drv, day, night = eng.alloc_raster(n)
+            layout = {'chosen_extra_bytes': 0, 'tuning_failed': str(exc)[:200]}
     eng.synth(n, seed=SEED, step=0, pixel_offset=offset, out=(cls, drv))
     # ET + diagnostics in one pass. Two diagnostics vectors: the all-reduce of
     # step s runs on a side stream under the kernel of step s + 1 (for N > 1;
