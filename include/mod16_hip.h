@@ -81,7 +81,7 @@ enum mod16_where { MOD16_HOST = 0, MOD16_DEVICE = 1 };
 #define MOD16_MATH_EXACT  1u  /* reference operation order, IEEE divide/pow     */
 #define MOD16_MATH_MIXED  2u  /* float32 rasters: float64 where it decides a mask or
                                  feeds the humidity terms, packed float32 elsewhere
-                                 (dense class-raster totals; other forms run FAST)  */
+                                 (dense class rasters; other shapes run FAST)       */
 
 typedef struct mod16_ctx mod16_ctx;
 
@@ -132,8 +132,9 @@ MOD16_API int mod16_et_f64(mod16_ctx* ctx, const uint8_t* cls,
 /* float32 data: MOD16_MATH_FAST widens to float64 on load, computes in float64 and
  * rounds once on store; MOD16_MATH_EXACT keeps float32 arithmetic in the reference's
  * operation order (what numpy does for the reference on float32 inputs);
- * MOD16_MATH_MIXED (dense class rasters, totals): float64 for the humidity terms (and
- * for the radiation balance next to its clamps), packed float32 for the rest, every
+ * MOD16_MATH_MIXED (dense class rasters: totals, components, potential ET): float64 for
+ * the humidity terms (and for the radiation balance next to its clamps), packed float32
+ * for the rest, every
  * decision behind a NaN or an exact zero made as in FAST; same masks as FAST, median
  * relative difference 1e-7, absolute difference below 1e-6 of the largest value,
  * 1.5x faster */

@@ -403,15 +403,29 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
             } else {
                 rc = launch_stream<T, kStreamTotals>(ctx, s, st, fused_diag ? ddiag : nullptr);
             }
-        } else if (smode == kStreamPet) {
-            s.out[0] = a.out[0]; s.out[1] = a.out[1]; s.out[2] = a.out[8]; s.out[3] = a.out[9];
-            rc = launch_stream<T, kStreamPet>(ctx, s, st);
-        } else if (smode == kStreamSep8) {
-            for (int k = 0; k < 8; ++k) s.out[k] = a.out[k];
-            rc = launch_stream<T, kStreamSep8>(ctx, s, st);
         } else {
-            for (int k = 0; k < 6; ++k) s.out[k] = a.out[k + 2];
-            rc = launch_stream<T, kStreamSep6>(ctx, s, st);
+            // float32 rasters: MOD16_MATH_MIXED selects the mixed-precision pixel function
+            bool mixed = false;
+            if constexpr (std::is_same<T, float>::value) mixed = (flags & MOD16_MATH_MIXED) != 0;
+            if (smode == kStreamPet) {
+                s.out[0] = a.out[0]; s.out[1] = a.out[1]; s.out[2] = a.out[8]; s.out[3] = a.out[9];
+            } else if (smode == kStreamSep8) {
+                for (int k = 0; k < 8; ++k) s.out[k] = a.out[k];
+            } else {
+                for (int k = 0; k < 6; ++k) s.out[k] = a.out[k + 2];
+            }
+            rc = MOD16_OK;
+            if constexpr (std::is_same<T, float>::value) {
+                if (mixed) {
+                    rc = smode == kStreamPet ? launch_stream<T, kStreamPetMixed>(ctx, s, st)
+                         : smode == kStreamSep8 ? launch_stream<T, kStreamSep8Mixed>(ctx, s, st)
+                                                : launch_stream<T, kStreamSep6Mixed>(ctx, s, st);
+                }
+            }
+            if (!mixed)
+                rc = smode == kStreamPet ? launch_stream<T, kStreamPet>(ctx, s, st)
+                     : smode == kStreamSep8 ? launch_stream<T, kStreamSep8>(ctx, s, st)
+                                            : launch_stream<T, kStreamSep6>(ctx, s, st);
         }
         if (rc != MOD16_OK) return rc;
     } else if (nbody) {

@@ -90,9 +90,15 @@ __device__ __forceinline__ void humid64(double t, double vpd, const double* tb, 
     esat_f = (float)esat; rh_f = (float)rh; fwet_f = (float)fwet; omw_f = (float)omw;
 }
 
-template <bool DAY>
-__device__ __forceinline__ f2 period_mixed(const ClassPar2& p, const Shared2& sh, const Humid2& h,
-                                           f2 t, f2 vpd, f2 rad_net, f2 rad_soil) {
+// the three components of one period [kg m-2 s-1] and, with PET, the potential
+// ET of the period (as period_fast, reference README.md:404-424)
+struct Parts2 {
+    f2 canopy, soil, trans, pet;
+};
+
+template <bool DAY, bool PET = false>
+__device__ __forceinline__ Parts2 period_mixed(const ClassPar2& p, const Shared2& sh, const Humid2& h,
+                                               f2 t, f2 vpd, f2 rad_net, f2 rad_soil) {
     const f2 zero = splat(0.f), one = splat(1.f), tiny = splat(1e-7f);
     f2 tc = t - splat(273.15f);
     f2 ta = (splat(239.0f) + t) - splat(273.15f);
@@ -149,15 +155,27 @@ __device__ __forceinline__ f2 period_mixed(const ClassPar2& p, const Shared2& sh
     f2 numt = (h.omw * ((rcfv * sh.fpar) * g_d + s * rad_c)) * p1;
     f2 dent = slhv * p1 + sh.k_p * (g_d * s1 + p1);
     f2 tr = numt * rcp2(dent);
-    f2 trans = shut ? zero : tr;
-    return (canopy + soil) + trans;                                          // :792
+    Parts2 o;
+    o.canopy = canopy;
+    o.soil = soil;
+    o.trans = shut ? zero : tr;
+    o.pet = zero;
+    if (PET) {
+        // sat + unsat without the rh^(vpd/beta) factor (two products, so that inf * 0 is
+        // NaN as in :541-543) + Priestley-Taylor potential transpiration (:546-602)
+        f2 pot_soil = (q < zero) ? zero : __builtin_elementwise_fma(q, h.fwet, q * h.omw);
+        f2 pot_tr = (splat((float)kPriestleyTaylorAlpha) * (s * radc_raw) * h.omw) * rcp2(slhv + sh.k_p);
+        o.pet = (canopy + pot_soil) + pot_tr;
+    }
+    return o;
 }
 
 // Two pixels. in[k][j]: driver k of pixel j; l0 / l1: the pixels' columns of
 // the float64 BPLUT table in LDS ([row][kLutCols] layout, row stride `ls`).
-__device__ __forceinline__ void et_pair_mixed(const float (&in)[14][2], const double* l0,
-                                              const double* l1, int ls, const double* tb,
-                                              f2& day, f2& night) {
+template <bool PET>
+__device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], const double* l0,
+                                                    const double* l1, int ls, const double* tb,
+                                                    Parts2& day, Parts2& night) {
     const f2 zero = splat(0.f);
     auto col = [&](int k) { return f2{in[k][0], in[k][1]}; };
     auto par = [&](int row) { return f2{(float)l0[row * ls], (float)l1[row * ls]}; };
@@ -252,8 +270,18 @@ __device__ __forceinline__ void et_pair_mixed(const float (&in)[14][2], const do
     const f2 tm = (col(8) - splat(273.f)) - splat(0.15f);
     const f2 tmin_close = par(0), tmin_open = par(1);
     sh.m_tmin = (tm >= tmin_open) ? splat(1.f) : ((tm < tmin_close) ? zero : (tm - tmin_close) * par(11));
-    day = period_mixed<true>(p, sh, hd, t_d, col(9), a_d, rs_d);
-    night = period_mixed<false>(p, sh, hn, t_n, col(10), rn_n, rs_n);
+    day = period_mixed<true, PET>(p, sh, hd, t_d, col(9), a_d, rs_d);
+    night = period_mixed<false, PET>(p, sh, hn, t_n, col(10), rn_n, rs_n);
+}
+
+// totals only (mod16/__init__.py:792: (canopy + soil) + transpiration)
+__device__ __forceinline__ void et_pair_mixed(const float (&in)[14][2], const double* l0,
+                                              const double* l1, int ls, const double* tb,
+                                              f2& day, f2& night) {
+    Parts2 d, n;
+    et_pair_mixed_parts<false>(in, l0, l1, ls, tb, d, n);
+    day = (d.canopy + d.soil) + d.trans;
+    night = (n.canopy + n.soil) + n.trans;
 }
 
 }  // namespace mod16

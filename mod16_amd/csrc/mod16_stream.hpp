@@ -58,13 +58,18 @@ constexpr int kDynRun = MOD16_DYN_RUN;
 enum StreamMode {
     kStreamPet = 0, kStreamSep8, kStreamSep6, kStreamRaw, kStreamRawTotal, kStreamRawTotalHours,
     kStreamTotals,
-    kStreamTotalsMixed      // float32 rasters only: mixed-precision pixel function (mod16_mixed.hpp)
+    // float32 rasters only: the mixed-precision pixel function (mod16_mixed.hpp)
+    kStreamTotalsMixed, kStreamPetMixed, kStreamSep8Mixed, kStreamSep6Mixed
 };
+constexpr bool stream_is_mixed(int mode) { return mode >= kStreamTotalsMixed; }
 
 // NW 16-byte-per-lane arrays, NB byte arrays (class raster first), NOUT outputs
 template <int MODE> struct StreamSpec;
 template <> struct StreamSpec<kStreamTotals> { static constexpr int NW = 14, NB = 1, NOUT = 2; };
 template <> struct StreamSpec<kStreamTotalsMixed> { static constexpr int NW = 14, NB = 1, NOUT = 2; };
+template <> struct StreamSpec<kStreamPetMixed> { static constexpr int NW = 14, NB = 1, NOUT = 4; };
+template <> struct StreamSpec<kStreamSep8Mixed> { static constexpr int NW = 14, NB = 1, NOUT = 8; };
+template <> struct StreamSpec<kStreamSep6Mixed> { static constexpr int NW = 14, NB = 1, NOUT = 6; };
 template <> struct StreamSpec<kStreamPet> { static constexpr int NW = 14, NB = 1, NOUT = 4; };
 template <> struct StreamSpec<kStreamSep8> { static constexpr int NW = 14, NB = 1, NOUT = 8; };
 template <> struct StreamSpec<kStreamSep6> { static constexpr int NW = 14, NB = 1, NOUT = 6; };
@@ -278,8 +283,8 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
 
         if (v < nvec) {   // only the last piece is ragged
             VT res[NOUT];
-            if constexpr (MODE == kStreamTotalsMixed) {
-                static_assert(V == 4 || MODE != kStreamTotalsMixed, "the mixed form is for float32 rasters");
+            if constexpr (stream_is_mixed(MODE)) {
+                static_assert(V == 4 || !stream_is_mixed(MODE), "the mixed form is for float32 rasters");
 #pragma unroll
                 for (int jj = 0; jj < V; jj += 2) {   // pairs of pixels: packed float32 arithmetic
                     float pin[14][2];
@@ -291,13 +296,25 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
                         c0 = c0 >= 13u ? 13u : c0;
                         c1 = c1 >= 13u ? 13u : c1;
                     }
-                    f2 day2, night2;
-                    et_pair_mixed(pin, lut + c0, lut + c1, kLutCols, tab, day2, night2);
-                    res[0][jj] = day2.x; res[0][jj + 1] = day2.y;
-                    res[1][jj] = night2.x; res[1][jj + 1] = night2.y;
+                    Parts2 pd, pn;
+                    et_pair_mixed_parts<MODE == kStreamPetMixed>(pin, lut + c0, lut + c1, kLutCols, tab, pd, pn);
+                    const f2 day2 = (pd.canopy + pd.soil) + pd.trans;        // :792
+                    const f2 night2 = (pn.canopy + pn.soil) + pn.trans;
+                    auto put = [&](int k, f2 v) { res[k][jj] = v.x; res[k][jj + 1] = v.y; };
+                    if constexpr (MODE == kStreamSep6Mixed) {
+                        put(0, pd.canopy); put(1, pd.soil); put(2, pd.trans);
+                        put(3, pn.canopy); put(4, pn.soil); put(5, pn.trans);
+                    } else {
+                        put(0, day2); put(1, night2);
+                    }
+                    if constexpr (MODE == kStreamPetMixed) { put(2, pd.pet); put(3, pn.pet); }
+                    if constexpr (MODE == kStreamSep8Mixed) {
+                        put(2, pd.canopy); put(3, pd.soil); put(4, pd.trans);
+                        put(5, pn.canopy); put(6, pn.soil); put(7, pn.trans);
+                    }
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const double d = (double)res[0][jj + e], g = (double)res[1][jj + e];
+                        const double d = (double)day2[e], g = (double)night2[e];
                         const bool dn = d != d, gn = g != g;
                         nan_d += (unsigned)__builtin_popcountll(__ballot(dn));
                         nan_n += (unsigned)__builtin_popcountll(__ballot(gn));

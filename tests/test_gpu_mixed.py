@@ -90,8 +90,38 @@ def test_mixed_edge_cases_keep_their_masks(env):
         assert rel.max() < 5e-6, rel.max()
 
 
+def test_mixed_components_and_potential_et(env):
+    """The component and potential-ET forms of the pipeline with the mixed arithmetic,
+    against the float64 arithmetic on the same float32 rasters."""
+    torch, _lib, RasterEngine, table = env
+    n = 1200 * 900 + 4
+    mixed = RasterEngine(table, dtype='float32', math=_lib.MATH_MIXED)
+    fast64 = RasterEngine(table, dtype='float64')
+    cls, drv32 = mixed.synth(n, seed=54)
+    drv64 = [d.double() for d in drv32]
+    sep_m, sep_f = mixed.empty(n, 6), fast64.empty(n, 6)
+    d_m, n_m = mixed.empty(n, 2)
+    mixed.run(cls, drv32, d_m, n_m, out_sep=sep_m)            # totals + six components
+    fast64.run(cls, drv64, out_sep=sep_f)                    # six components
+    pet_m = mixed.run_pet(cls, drv32)
+    pet_f = fast64.run_pet(cls, drv64)
+    mixed.check()
+    fast64.check()
+    for got, want in list(zip(sep_m, sep_f)) + list(zip(pet_m, pet_f)) + [(d_m, pet_f[0]), (n_m, pet_f[1])]:
+        s = stats(got.cpu().numpy(), want.cpu().numpy())
+        assert s['zero_mismatch'] == 0, s
+        # single components carry the cancellation tail undiluted: 99 % within 2e-5
+        assert s['median'] < 3e-7 and s['p99'] < 2e-5 and s['abs_over_scale'] < 2e-6, s
+    # the totals of these forms are the totals of the totals form (same arithmetic; the
+    # compiler may fuse multiply-adds differently per instantiation: a float32 ulp or two)
+    d0, n0 = mixed.run(cls, drv32)
+    for got, want in ((d_m, d0), (n_m, n0), (pet_m[0], d0), (pet_m[1], n0)):
+        s = stats(got.cpu().numpy(), want.cpu().numpy())
+        assert s['zero_mismatch'] == 0 and s['median'] < 1e-7 and s['abs_over_scale'] < 5e-7, s
+
+
 def test_mixed_falls_back_to_fast_elsewhere(env):
-    """float64 rasters and the forms the mixed pixel function does not cover run FAST."""
+    """float64 rasters and the raw-driver form run FAST."""
     torch, _lib, RasterEngine, table = env
     n = 100000
     e_m = RasterEngine(table, dtype='float64', math=_lib.MATH_MIXED)
@@ -101,14 +131,6 @@ def test_mixed_falls_back_to_fast_elsewhere(env):
     c, d = e_f.run(cls, drv)
     assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(c))
     assert torch.equal(torch.nan_to_num(b), torch.nan_to_num(d))
-    e32m = RasterEngine(table, dtype='float32', math=_lib.MATH_MIXED)
-    e32f = RasterEngine(table, dtype='float32')
-    drv32 = [x.float() for x in drv]
-    sep_m, sep_f = e32m.empty(n, 6), e32f.empty(n, 6)
-    e32m.run(cls, drv32, out_sep=sep_m)
-    e32f.run(cls, drv32, out_sep=sep_f)
-    for x, y in zip(sep_m, sep_f):
-        assert torch.equal(torch.nan_to_num(x), torch.nan_to_num(y))
 
 
 def test_mixed_diagnostics_and_class_range(env):

@@ -5,7 +5,7 @@ each on the production pipeline (et_stream_kernel) and on the plain kernels
 of the same library (a MOD16_NO_DMA=1 context). torch events on the launch
 stream; bytes per pixel are the algorithmic ones.
 
-  python tools/variantbench.py [rows=10800] [dtype=float64]
+  python tools/variantbench.py [rows=10800] [dtype=float64] [mixed]
 """
 import json
 import os
@@ -36,9 +36,10 @@ def timed(fn, reps=5):
 def main():
     rows = int(sys.argv[1]) if len(sys.argv) > 1 else 10800
     dtype = sys.argv[2] if len(sys.argv) > 2 else 'float64'
+    math = {'mixed': _lib.MATH_MIXED}.get(sys.argv[3] if len(sys.argv) > 3 else '', _lib.MATH_FAST)
     n = rows * 43200
     table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
-    eng = RasterEngine(table, dtype=dtype)
+    eng = RasterEngine(table, dtype=dtype, math=math)
     os.environ['MOD16_NO_DMA'] = '1'
     plain = RasterEngine(table, dtype=dtype)
     plain.ctx = _lib.Context(0)
@@ -74,7 +75,7 @@ def main():
         ms0 = timed(lambda: fn(plain))
         eng.check()
         plain.check()
-        print(json.dumps({'form': label, 'dtype': dtype, 'pixels': n, 'bytes_per_pixel': bpp,
+        print(json.dumps({'form': label, 'dtype': dtype, 'math': 'mixed' if math == _lib.MATH_MIXED else 'fast', 'pixels': n, 'bytes_per_pixel': bpp,
                           'pipeline_ms': round(ms, 3), 'pipeline_GBps': round(bpp * n / ms / 1e6, 1),
                           'pipeline_frac_8TBs': round(bpp * n / ms / 1e6 / 8000, 4),
                           'plain_ms': round(ms0, 3), 'plain_GBps': round(bpp * n / ms0 / 1e6, 1)}),
