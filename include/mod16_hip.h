@@ -132,7 +132,7 @@ MOD16_API int mod16_et_f64(mod16_ctx* ctx, const uint8_t* cls,
 /* float32 data: MOD16_MATH_FAST widens to float64 on load, computes in float64 and
  * rounds once on store; MOD16_MATH_EXACT keeps float32 arithmetic in the reference's
  * operation order (what numpy does for the reference on float32 inputs);
- * MOD16_MATH_MIXED (dense class rasters: totals, components, potential ET): float64 for
+ * MOD16_MATH_MIXED (dense class rasters: totals, components, potential ET, raw drivers): float64 for
  * the humidity terms (and for the radiation balance next to its clamps), packed float32
  * for the rest, every
  * decision behind a NaN or an exact zero made as in FAST; same masks as FAST, median

@@ -987,7 +987,17 @@ static int raw_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* raw,
             for (int k = 0; k < 3; ++k) s.out[k] = d.out[k];
             s.hours = host_hours ? (double)*host_hours : 0.0;
             s.n = nbody;
-            int rc = mode == kStreamRaw ? launch_stream<T, kStreamRaw>(ctx, s, st)
+            int rc = MOD16_OK;
+            bool mixed = false;
+            if constexpr (std::is_same<T, float>::value) {
+                mixed = (flags & MOD16_MATH_MIXED) != 0;
+                if (mixed)
+                    rc = mode == kStreamRaw ? launch_stream<T, kStreamRawMixed>(ctx, s, st)
+                         : mode == kStreamRawTotal ? launch_stream<T, kStreamRawTotalMixed>(ctx, s, st)
+                                                   : launch_stream<T, kStreamRawTotalHoursMixed>(ctx, s, st);
+            }
+            if (!mixed)
+                rc = mode == kStreamRaw ? launch_stream<T, kStreamRaw>(ctx, s, st)
                      : mode == kStreamRawTotal ? launch_stream<T, kStreamRawTotal>(ctx, s, st)
                                                : launch_stream<T, kStreamRawTotalHours>(ctx, s, st);
             if (rc != MOD16_OK) return rc;

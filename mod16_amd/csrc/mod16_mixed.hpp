@@ -172,10 +172,13 @@ __device__ __forceinline__ Parts2 period_mixed(const ClassPar2& p, const Shared2
 
 // Two pixels. in[k][j]: driver k of pixel j; l0 / l1: the pixels' columns of
 // the float64 BPLUT table in LDS ([row][kLutCols] layout, row stride `ls`).
+// vpd64: the two periods' VPD in float64 where the caller has it (raw drivers:
+// it is a difference of two exponentials), else NULL = the float32 inputs widened.
 template <bool PET>
 __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], const double* l0,
                                                     const double* l1, int ls, const double* tb,
-                                                    Parts2& day, Parts2& night) {
+                                                    Parts2& day, Parts2& night,
+                                                    const double (*vpd64)[2] = nullptr) {
     const f2 zero = splat(0.f);
     auto col = [&](int k) { return f2{in[k][0], in[k][1]}; };
     auto par = [&](int row) { return f2{(float)l0[row * ls], (float)l1[row * ls]}; };
@@ -238,8 +241,9 @@ __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], co
     float esat_d[2], rh_d[2], fwet_d[2], omw_d[2], esat_n[2], rh_n[2], fwet_n[2], omw_n[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        humid64((double)in[5][j], (double)in[9][j], tb, esat_d[j], rh_d[j], fwet_d[j], omw_d[j], dry_d[j], open_d[j]);
-        humid64((double)in[6][j], (double)in[10][j], tb, esat_n[j], rh_n[j], fwet_n[j], omw_n[j], dry_n[j], open_n[j]);
+        const double vd = vpd64 ? vpd64[0][j] : (double)in[9][j], vn = vpd64 ? vpd64[1][j] : (double)in[10][j];
+        humid64((double)in[5][j], vd, tb, esat_d[j], rh_d[j], fwet_d[j], omw_d[j], dry_d[j], open_d[j]);
+        humid64((double)in[6][j], vn, tb, esat_n[j], rh_n[j], fwet_n[j], omw_n[j], dry_n[j], open_n[j]);
     }
     hd.esat = f2{esat_d[0], esat_d[1]}; hd.rh = f2{rh_d[0], rh_d[1]};
     hd.fwet = f2{fwet_d[0], fwet_d[1]}; hd.omw = f2{omw_d[0], omw_d[1]};
@@ -272,6 +276,39 @@ __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], co
     sh.m_tmin = (tm >= tmin_open) ? splat(1.f) : ((tm < tmin_close) ? zero : (tm - tmin_close) * par(11));
     day = period_mixed<true, PET>(p, sh, hd, t_d, col(9), a_d, rs_d);
     night = period_mixed<false, PET>(p, sh, hn, t_n, col(10), rn_n, rs_n);
+}
+
+// Raw drivers (calibration.py:380-423) for the mixed form: the
+// pixel-function inputs of two pixels from their raw fields. VPD = svp(T) - avp
+// is a difference of nearly equal numbers in humid air and feeds rh, so it is
+// float64 (and handed on in float64); air pressure from elevation and the byte
+// decodings are float32.
+__device__ __forceinline__ void raw_pair_mixed(const float (&raw)[14][2], const unsigned (&fpar_pct)[2],
+                                               const unsigned (&lai_x10)[2], const double* tb,
+                                               float (&in)[14][2], double (&vpd64)[2][2]) {
+    typedef FastMath<double> M;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { in[k][0] = raw[k][0]; in[k][1] = raw[k][1]; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        auto vpd = [&](double qv, double ps, double t) {                     // MOD16.vpd, :604-644
+            const double tc = t - 273.15;
+            const double avp = (qv * ps) * M::rcp(0.622 + 0.379 * qv);
+            const double sv = __builtin_fma(610.7, M::exp_tab((17.38 * tc) * M::rcp(239.0 + tc), tb), tc * 0.0);
+            return sv - avp;
+        };
+        vpd64[0][j] = vpd(raw[9][j], raw[11][j], raw[5][j]);
+        const double vn = vpd(raw[10][j], raw[12][j], raw[6][j]);
+        vpd64[1][j] = (vn < 0.0) ? 0.0 : vn;                                 // calibration.py:401
+        in[9][j] = (float)vpd64[0][j];
+        in[10][j] = (float)vpd64[1][j];
+        in[12][j] = (fpar_pct[j] >= 249u) ? __builtin_nanf("") : (float)fpar_pct[j] * 0.01f;
+        in[13][j] = (lai_x10[j] >= 249u) ? __builtin_nanf("") : (float)lai_x10[j] * 0.1f;
+    }
+    // 101325 (1 - 0.0065 z / 288.15)^5.2559, MOD16.air_pressure :414-447
+    const f2 ratio = __builtin_elementwise_fma(f2{raw[13][0], raw[13][1]}, splat((float)(-0.0065 / 288.15)), splat(1.f));
+    const f2 pa = splat(101325.f) * exp2_2(splat((float)(9.80665 / (0.0065 * (8.3143 / 28.9644e-3)))) * log2_2(ratio));
+    in[11][0] = pa.x; in[11][1] = pa.y;
 }
 
 // totals only (mod16/__init__.py:792: (canopy + soil) + transpiration)

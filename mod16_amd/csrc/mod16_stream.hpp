@@ -59,7 +59,8 @@ enum StreamMode {
     kStreamPet = 0, kStreamSep8, kStreamSep6, kStreamRaw, kStreamRawTotal, kStreamRawTotalHours,
     kStreamTotals,
     // float32 rasters only: the mixed-precision pixel function (mod16_mixed.hpp)
-    kStreamTotalsMixed, kStreamPetMixed, kStreamSep8Mixed, kStreamSep6Mixed
+    kStreamTotalsMixed, kStreamPetMixed, kStreamSep8Mixed, kStreamSep6Mixed,
+    kStreamRawMixed, kStreamRawTotalMixed, kStreamRawTotalHoursMixed
 };
 constexpr bool stream_is_mixed(int mode) { return mode >= kStreamTotalsMixed; }
 
@@ -70,6 +71,9 @@ template <> struct StreamSpec<kStreamTotalsMixed> { static constexpr int NW = 14
 template <> struct StreamSpec<kStreamPetMixed> { static constexpr int NW = 14, NB = 1, NOUT = 4; };
 template <> struct StreamSpec<kStreamSep8Mixed> { static constexpr int NW = 14, NB = 1, NOUT = 8; };
 template <> struct StreamSpec<kStreamSep6Mixed> { static constexpr int NW = 14, NB = 1, NOUT = 6; };
+template <> struct StreamSpec<kStreamRawMixed> { static constexpr int NW = 14, NB = 3, NOUT = 2; };
+template <> struct StreamSpec<kStreamRawTotalMixed> { static constexpr int NW = 14, NB = 3, NOUT = 3; };
+template <> struct StreamSpec<kStreamRawTotalHoursMixed> { static constexpr int NW = 15, NB = 3, NOUT = 3; };
 template <> struct StreamSpec<kStreamPet> { static constexpr int NW = 14, NB = 1, NOUT = 4; };
 template <> struct StreamSpec<kStreamSep8> { static constexpr int NW = 14, NB = 1, NOUT = 8; };
 template <> struct StreamSpec<kStreamSep6> { static constexpr int NW = 14, NB = 1, NOUT = 6; };
@@ -297,7 +301,18 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
                         c1 = c1 >= 13u ? 13u : c1;
                     }
                     Parts2 pd, pn;
-                    et_pair_mixed_parts<MODE == kStreamPetMixed>(pin, lut + c0, lut + c1, kLutCols, tab, pd, pn);
+                    constexpr bool kRawMixed = MODE == kStreamRawMixed || MODE == kStreamRawTotalMixed ||
+                                               MODE == kStreamRawTotalHoursMixed;
+                    if constexpr (kRawMixed) {
+                        const unsigned fp[2] = {(bits[1] >> (8 * jj)) & 0xffu, (bits[1] >> (8 * jj + 8)) & 0xffu};
+                        const unsigned lx[2] = {(bits[2] >> (8 * jj)) & 0xffu, (bits[2] >> (8 * jj + 8)) & 0xffu};
+                        float din[14][2];
+                        double vpd64[2][2];
+                        raw_pair_mixed(pin, fp, lx, tab, din, vpd64);
+                        et_pair_mixed_parts<false>(din, lut + c0, lut + c1, kLutCols, tab, pd, pn, vpd64);
+                    } else {
+                        et_pair_mixed_parts<MODE == kStreamPetMixed>(pin, lut + c0, lut + c1, kLutCols, tab, pd, pn);
+                    }
                     const f2 day2 = (pd.canopy + pd.soil) + pd.trans;        // :792
                     const f2 night2 = (pn.canopy + pn.soil) + pn.trans;
                     auto put = [&](int k, f2 v) { res[k][jj] = v.x; res[k][jj + 1] = v.y; };
@@ -308,6 +323,13 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
                         put(0, day2); put(1, night2);
                     }
                     if constexpr (MODE == kStreamPetMixed) { put(2, pd.pet); put(3, pn.pet); }
+                    if constexpr (MODE == kStreamRawTotalMixed || MODE == kStreamRawTotalHoursMixed) {
+                        // tests/verification/verify2.py:113-115
+                        f2 h = splat((float)a.hours);
+                        if constexpr (MODE == kStreamRawTotalHoursMixed) h = f2{in[14][jj], in[14][jj + 1]};
+                        const f2 k8 = splat(8.f * 3600.f);
+                        put(2, (day2 * h) * k8 + (night2 * (splat(24.f) - h)) * k8);
+                    }
                     if constexpr (MODE == kStreamSep8Mixed) {
                         put(2, pd.canopy); put(3, pd.soil); put(4, pd.trans);
                         put(5, pn.canopy); put(6, pn.soil); put(7, pn.trans);

@@ -120,8 +120,32 @@ def test_mixed_components_and_potential_et(env):
         assert s['zero_mismatch'] == 0 and s['median'] < 1e-7 and s['abs_over_scale'] < 5e-7, s
 
 
+@pytest.mark.parametrize('hours_kind', ['none', 'array', 'scalar'])
+def test_mixed_raw_drivers(env, hours_kind):
+    """Raw float32 drivers (specific humidity, surface pressure, elevation, uint8 fPAR /
+    LAI with fill codes) through the mixed form against the float64 arithmetic."""
+    torch, _lib, RasterEngine, table = env
+    from test_gpu_stream import raw_inputs
+    n = 64 * 8 * 2 * 37 * 4 + 64 * 5 + 3
+    cls, raw, fpar, lai, hours = raw_inputs(n, 55, np.float32)
+    dev = lambda a: torch.from_numpy(a).cuda()
+    mixed = RasterEngine(table, dtype='float32', math=_lib.MATH_MIXED)
+    fast64 = RasterEngine(table, dtype='float64')
+    h32 = {'none': None, 'array': dev(hours), 'scalar': 11.5}[hours_kind]
+    h64 = {'none': None, 'array': dev(hours.astype(np.float64)), 'scalar': 11.5}[hours_kind]
+    got = mixed.run_raw(dev(cls), [dev(a) for a in raw], dev(fpar), dev(lai), day_hours=h32)
+    want = fast64.run_raw(dev(cls), [dev(a.astype(np.float64)) for a in raw], dev(fpar), dev(lai), day_hours=h64)
+    mixed.check()
+    fast64.check()
+    assert len(got) == len(want) == (2 if hours_kind == 'none' else 3)
+    for g, w in zip(got, want):
+        s = stats(g.cpu().numpy(), w.cpu().numpy())
+        assert s['zero_mismatch'] == 0, s
+        assert s['median'] < 3e-7 and s['p99'] < 5e-6 and s['abs_over_scale'] < 2e-6, s
+
+
 def test_mixed_falls_back_to_fast_elsewhere(env):
-    """float64 rasters and the raw-driver form run FAST."""
+    """float64 rasters run FAST."""
     torch, _lib, RasterEngine, table = env
     n = 100000
     e_m = RasterEngine(table, dtype='float64', math=_lib.MATH_MIXED)
