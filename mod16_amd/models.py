@@ -13,20 +13,17 @@ MOD16_DIR = os.path.dirname(os.path.abspath(__file__))
 COLLECTION61_BPLUT = os.path.join(
     DATA_DIR, 'MOD16_BPLUT_C5.1_05deg_MCD43B_Albedo_MERRA_GMAO.csv')
 
-# MCD12Q1 LC_Type2 names -> numeric PFT code (reference mod16/models.py:13-25)
-PFT_ALL = {
-    'Evergreen Needleleaf Forest (ENF)': 1,
-    'Evergreen Broadleaf Forest (EBF)': 2,
-    'Deciduous Needleleaf Forest (DNF)': 3,
-    'Deciduous Broadleaf Forest (DBF)': 4,
-    'Mixed Forest (MF) ': 5,
-    'Closed Shrublands (CSH)': 6,
-    'Open Shrublands (OSH)': 7,
-    'Woody Savannas (WSV)': 8,
-    'Savannas (SAV)': 9,
-    'Grasslands (GRS)': 10,
-    'Croplands (CRO)': 12
-}
+# MCD12Q1 LC_Type2 classes that are Plant Functional Types: (code, name, acronym).
+# PFT_ALL maps the reference's display names to the codes (same keys as
+# reference mod16/models.py:13-25, including the trailing blank of the MF key).
+_LC_TYPE2_PFT = (
+    (1, 'Evergreen Needleleaf Forest', 'ENF'), (2, 'Evergreen Broadleaf Forest', 'EBF'),
+    (3, 'Deciduous Needleleaf Forest', 'DNF'), (4, 'Deciduous Broadleaf Forest', 'DBF'),
+    (5, 'Mixed Forest', 'MF'), (6, 'Closed Shrublands', 'CSH'), (7, 'Open Shrublands', 'OSH'),
+    (8, 'Woody Savannas', 'WSV'), (9, 'Savannas', 'SAV'), (10, 'Grasslands', 'GRS'),
+    (12, 'Croplands', 'CRO'))
+PFT_ALL = dict(('%s (%s)%s' % (name, abbr, ' ' if abbr == 'MF' else ''), code)
+               for code, name, abbr in _LC_TYPE2_PFT)
 
 
 class MOD16Collection61(MOD16):
