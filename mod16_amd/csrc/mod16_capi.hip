@@ -668,7 +668,8 @@ extern "C" int mod16_et_diag_f32(mod16_ctx* ctx, const uint8_t* cls, const float
 // sequence of mod16_et_diag_* (counter reset, pipeline kernel, staged fixed-order
 // sum) captured once and replayed with one call per time step.
 struct mod16_graph {
-    mod16_ctx* ctx = nullptr;
+    mod16_ctx* ctx = nullptr;                // for error text at launch; not touched by destroy
+    int device = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     unsigned long long* counter = nullptr;   // its own ticket counter: replays never meet the ring
@@ -676,7 +677,7 @@ struct mod16_graph {
 
 extern "C" int mod16_graph_destroy(mod16_graph* g) {
     if (!g) return MOD16_OK;
-    if (g->ctx) (void)hipSetDevice(g->ctx->device);
+    (void)hipSetDevice(g->device);           // the context may be gone already (interpreter exit)
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     if (g->counter) (void)hipFree(g->counter);
@@ -696,6 +697,7 @@ static int graph_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drive
     mod16_graph* g = new (std::nothrow) mod16_graph;
     if (!g) return MOD16_ERR_NOMEM;
     g->ctx = ctx;
+    g->device = ctx->device;
     int rc = [&]() -> int {
         HIPCHK(ctx, hipMalloc(&g->counter, 128));
         ctx->force_counter = g->counter;

@@ -28,8 +28,9 @@ def _torch():
 class _GraphHandle(object):
     '''Owns a ``mod16_graph`` (destroyed with the bound launch that uses it).'''
 
-    def __init__(self, lib, handle):
+    def __init__(self, lib, handle, ctx=None):
         self.lib, self.handle = lib, handle
+        self.ctx = ctx          # keeps the context alive as long as its graph
 
     def __del__(self):
         try:
@@ -353,7 +354,7 @@ class RasterEngine(object):
             make = lib.mod16_graph_et_diag_f32 if f32 else lib.mod16_graph_et_diag_f64
             rc = make(*args, C.byref(handle))
             if rc == _lib.OK:
-                owner = _GraphHandle(lib, handle)
+                owner = _GraphHandle(lib, handle, self.ctx)
 
                 def launch():
                     check(lib.mod16_graph_launch(owner.handle, torch.cuda.current_stream(device).cuda_stream))
