@@ -239,29 +239,41 @@ template <> struct VecOf<float> { static constexpr int v = 4; };
 template <typename T, int V>
 static void launch_variant(const EtArgs<T>& a, bool lut, bool fast, bool sep, bool dense,
                            int grid, hipStream_t st) {
+    // FAST on float32 with 4 pixels per thread is never built (see launch_et): EXACT only
+    constexpr bool kFastOk = !(std::is_same<T, float>::value && V == 4);
     if (a.out[8] || a.out[9]) {   // potential ET wanted: the generic all-outputs form
 #define MOD16_LAUNCH_PET(LUT, FAST) \
     hipLaunchKernelGGL((et_kernel<T, V, LUT, FAST, true, false, true>), dim3(grid), dim3(kBlock), 0, st, a)
-        if (lut) { if (fast) MOD16_LAUNCH_PET(true, true); else MOD16_LAUNCH_PET(true, false); }
-        else     { if (fast) MOD16_LAUNCH_PET(false, true); else MOD16_LAUNCH_PET(false, false); }
+        if constexpr (kFastOk) {
+            if (fast) {
+                if (lut) MOD16_LAUNCH_PET(true, true); else MOD16_LAUNCH_PET(false, true);
+                return;
+            }
+        }
+        if (lut) MOD16_LAUNCH_PET(true, false); else MOD16_LAUNCH_PET(false, false);
 #undef MOD16_LAUNCH_PET
         return;
     }
 #define MOD16_LAUNCH(LUT, FAST, SEP, DENSE) \
     hipLaunchKernelGGL((et_kernel<T, V, LUT, FAST, SEP, DENSE>), dim3(grid), dim3(kBlock), 0, st, a)
-    if (fast && V > 1) {
-        if (lut) {
-            if (sep) { if (dense) MOD16_LAUNCH(true, true, true, true); else MOD16_LAUNCH(true, true, true, false); }
-            else     { if (dense) MOD16_LAUNCH(true, true, false, true); else MOD16_LAUNCH(true, true, false, false); }
-        } else {
-            if (sep) { if (dense) MOD16_LAUNCH(false, true, true, true); else MOD16_LAUNCH(false, true, true, false); }
-            else     { if (dense) MOD16_LAUNCH(false, true, false, true); else MOD16_LAUNCH(false, true, false, false); }
+    if constexpr (kFastOk && V > 1) {
+        if (fast) {
+            if (lut) {
+                if (sep) { if (dense) MOD16_LAUNCH(true, true, true, true); else MOD16_LAUNCH(true, true, true, false); }
+                else     { if (dense) MOD16_LAUNCH(true, true, false, true); else MOD16_LAUNCH(true, true, false, false); }
+            } else {
+                if (sep) { if (dense) MOD16_LAUNCH(false, true, true, true); else MOD16_LAUNCH(false, true, true, false); }
+                else     { if (dense) MOD16_LAUNCH(false, true, false, true); else MOD16_LAUNCH(false, true, false, false); }
+            }
+            return;
         }
-    } else if (fast) {
-        if (lut) MOD16_LAUNCH(true, true, true, false); else MOD16_LAUNCH(false, true, true, false);
-    } else {
-        if (lut) MOD16_LAUNCH(true, false, true, false); else MOD16_LAUNCH(false, false, true, false);
+    } else if constexpr (kFastOk) {
+        if (fast) {
+            if (lut) MOD16_LAUNCH(true, true, true, false); else MOD16_LAUNCH(false, true, true, false);
+            return;
+        }
     }
+    if (lut) MOD16_LAUNCH(true, false, true, false); else MOD16_LAUNCH(false, false, true, false);
 #undef MOD16_LAUNCH
 }
 
@@ -431,7 +443,14 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
     } else if (nbody) {
         EtArgs<T> b = a;
         b.n = nbody;
-        launch_variant<T, V>(b, lut, fast, sep, dense, grid_for(ctx, nbody / V), st);
+        // float32 rasters with the FAST (float64) arithmetic: 2 pixels per thread. With 4
+        // the kernel needs ~400 registers and spills inside divergent code, and hipcc 7.2
+        // then miscompiles it (wrong values in ~10 % of the pixels of the potential-ET
+        // variant, found by tests/test_gpu_stream.py's boundary-size test).
+        if (fast && std::is_same<T, float>::value)
+            launch_variant<T, 2>(b, lut, fast, sep, dense, grid_for(ctx, nbody / 2), st);
+        else
+            launch_variant<T, V>(b, lut, fast, sep, dense, grid_for(ctx, nbody / V), st);
     }
     if (nbody < a.n) {   // ragged tail (or unaligned input): scalar variant
         EtArgs<T> t = a;

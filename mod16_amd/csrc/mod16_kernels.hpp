@@ -38,6 +38,7 @@ template <typename T, int V> struct Vec;
 template <> struct Vec<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
 template <> struct Vec<double, 1> { typedef double type; };
 template <> struct Vec<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct Vec<float, 2> { typedef float type __attribute__((ext_vector_type(2))); };
 template <> struct Vec<float, 1> { typedef float type; };
 
 template <typename T, int V, bool DENSE>

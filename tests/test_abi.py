@@ -86,3 +86,25 @@ def test_product_never_imports_the_oracle():
                 if f.endswith(('.py', '.hip', '.hpp', '.h')):
                     text = open(os.path.join(dirpath, f)).read()
                     assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f
+
+
+def test_no_kernel_spills_vector_registers(tmp_path):
+    """hipcc 7.2 miscompiled a float32 kernel that needed ~400 vector registers
+    and spilled inside divergent code (wrong values in a few percent of the
+    pixels; tests/test_gpu_stream.py found it). No kernel of the library may
+    spill vector registers -- checked on the gfx950 listing."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    src = os.path.join(ROOT, 'mod16_amd', 'csrc', 'mod16_capi.hip')
+    out = str(tmp_path / 'capi.s')
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S',
+                           '--cuda-device-only', '-o', out, src],
+                          stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    kernels = re.findall(r'\.name:\s+(\S+)\n(?:.*\n){0,12}?\s*\.vgpr_spill_count:\s*(\d+)', text)
+    assert len(kernels) > 50
+    spilling = [name for name, count in kernels if int(count) > 0]
+    assert not spilling, spilling

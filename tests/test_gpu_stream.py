@@ -182,3 +182,40 @@ def test_class_range_flag_from_the_pipeline(env):
     eng.run_pet(cls, drv)
     with pytest.raises(IndexError):
         eng.check()
+
+
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_pipeline_at_piece_run_and_chip_boundaries(env, dtype):
+    """Sizes around one vector, one 64-vector piece, one run, one run per wave of
+    the chip and one more: the pipeline's work distribution (run length, claimed
+    runs, ragged last piece, scalar tail) against the plain kernels, all forms."""
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table, dtype=dtype)
+    plain = plain_engine(RasterEngine, table, dtype)
+    v = 2 if dtype == 'float64' else 4
+    piece = 64 * v
+    chip = 2048 * 2 * piece                      # every wave of the chip gets a 2-piece run
+    sizes = [v, piece - v, piece, piece + 1, 2 * piece, 8 * piece - 1, 8 * piece, 8 * piece + v + 1,
+             17 * piece + 3, chip - piece, chip, chip + piece + 1, 3 * chip + 5 * piece + 2]
+    big = max(sizes)
+    cls, drv = eng.synth(big, seed=71)
+    for n in sizes:
+        c, d = cls[:n], [x[:n] for x in drv]
+        diag = torch.zeros(8, dtype=torch.float64, device='cuda')
+        day, night = eng.run(c, d, diag=diag)
+        pd, pn = plain.run(c, d)
+        assert torch.equal(torch.nan_to_num(day), torch.nan_to_num(pd)), n
+        assert torch.equal(torch.nan_to_num(night), torch.nan_to_num(pn)), n
+        want = eng.diagnostics(day, night)
+        assert torch.equal(diag[2:], want[2:]), n
+        assert torch.allclose(diag[:2], want[:2], rtol=1e-12, atol=0), n
+        if n <= 17 * piece + 3 or n == chip + piece + 1:
+            sep, psep = eng.empty(n, 6), plain.empty(n, 6)
+            eng.run(c, d, out_sep=sep)
+            plain.run(c, d, out_sep=psep)
+            for a, b in zip(sep, psep):
+                assert_parity(a.cpu().numpy(), b.cpu().numpy(), 1e-12, 'components, n = %d' % n)
+            for a, b in zip(eng.run_pet(c, d), plain.run_pet(c, d)):
+                assert_parity(a.cpu().numpy(), b.cpu().numpy(), 1e-12, 'potential ET, n = %d' % n)
+    eng.check()
+    plain.check()
