@@ -219,3 +219,13 @@ def test_pipeline_at_piece_run_and_chip_boundaries(env, dtype):
                 assert_parity(a.cpu().numpy(), b.cpu().numpy(), 1e-12, 'potential ET, n = %d' % n)
     eng.check()
     plain.check()
+    # the raw-driver forms at the same boundaries
+    rcls, raw, fpar, lai, hours = raw_inputs(17 * piece + 3, 72, np.dtype(dtype).type)
+    dev = lambda a: torch.from_numpy(a).cuda()
+    rcls, raw, fpar, lai, hours = dev(rcls), [dev(a) for a in raw], dev(fpar), dev(lai), dev(hours)
+    for n in [s for s in sizes if s <= 17 * piece + 3]:
+        for h in (None, hours[:n], 11.5):
+            got = eng.run_raw(rcls[:n], [a[:n] for a in raw], fpar[:n], lai[:n], day_hours=h)
+            want = plain.run_raw(rcls[:n], [a[:n] for a in raw], fpar[:n], lai[:n], day_hours=h)
+            for a, b in zip(got, want):
+                assert_parity(a.cpu().numpy(), b.cpu().numpy(), 1e-12, 'raw drivers, n = %d' % n)
