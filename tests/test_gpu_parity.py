@@ -327,3 +327,31 @@ def test_rasters_on_disk(m16, tmp_path):
     # out= of the in-memory interface: wrong shape / dtype is refused
     with pytest.raises(ValueError):
         m16.evapotranspiration_raster(f['table'], cls, *drv, out=[np.empty((3, 3)), np.empty((3, 3))])
+
+
+def test_float32_class_interface_is_float64_arithmetic_rounded_once(m16, golden):
+    """MOD16(params).evapotranspiration on float32 arrays (scalar and per-pixel
+    parameters: the plain kernels, not the class-raster pipeline), totals,
+    components and potential ET: the float64 result rounded once, bit for bit."""
+    f = golden('f3_random64_f64')
+    cls, drv32 = synth.drivers((333, 517), seed=9, dtype=np.float32)
+    drv64 = [d.astype(np.float64) for d in drv32]
+    bplut = {k: f['table'][:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    # scalar parameters reach the float32 kernel rounded to float32: give the float64 run the same values
+    scalar = m16.MOD16({k: float(np.float32(bplut[k][7])) for k in oracle.PARAM_NAMES})
+    per_pixel32 = m16.MOD16({k: bplut[k][cls].astype(np.float32) for k in oracle.PARAM_NAMES})
+    per_pixel64 = m16.MOD16({k: bplut[k][cls].astype(np.float32).astype(np.float64) for k in oracle.PARAM_NAMES})
+    for m32, m64 in ((scalar, scalar), (per_pixel32, per_pixel64)):
+        got = m32.evapotranspiration(*drv32)
+        want = m64.evapotranspiration(*drv64)
+        for a, b in zip(got, want):
+            assert a.dtype == np.float32
+            assert np.array_equal(a, b.astype(np.float32), equal_nan=True)
+        got = m32.evapotranspiration(*drv32, separate=True)
+        want = m64.evapotranspiration(*drv64, separate=True)
+        for a, b in zip(got[0] + got[1], want[0] + want[1]):
+            assert np.array_equal(a, b.astype(np.float32), equal_nan=True)
+        got = m32.evapotranspiration_and_pet(*drv32)
+        want = m64.evapotranspiration_and_pet(*drv64)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b.astype(np.float32), equal_nan=True)
