@@ -173,3 +173,24 @@ def test_mixed_diagnostics_and_class_range(env):
     eng.run(cls, drv)
     with pytest.raises(IndexError):
         eng.check()
+
+
+def test_mixed_at_piece_and_run_boundaries(env):
+    """The mixed form at sizes around one vector, one piece, one run (work distribution
+    and the scalar tail, which runs FAST): masks and absolute error against FAST."""
+    torch, _lib, RasterEngine, table = env
+    mixed = RasterEngine(table, dtype='float32', math=_lib.MATH_MIXED)
+    fast = RasterEngine(table, dtype='float32')
+    piece = 256
+    sizes = [4, piece - 4, piece, piece + 1, 2 * piece, 8 * piece - 1, 8 * piece, 8 * piece + 5, 17 * piece + 3]
+    cls, drv = mixed.synth(max(sizes), seed=56)
+    for n in sizes:
+        c, d = cls[:n], [x[:n] for x in drv]
+        for got, want in zip(mixed.run(c, d), fast.run(c, d)):
+            g, w = got.cpu().numpy(), want.cpu().numpy()
+            assert np.array_equal(np.isnan(g), np.isnan(w)), n
+            assert np.array_equal(g == 0, w == 0), n
+            scale = np.nanmax(np.abs(w))
+            assert np.nanmax(np.abs(g.astype(np.float64) - w)) <= 2e-6 * scale, n
+    mixed.check()
+    fast.check()
