@@ -366,3 +366,16 @@ def test_batched_calibration_fast_arithmetic(m16, golden):
     s_f, c_f = m16.MOD16._et_batch(params, *drv, observed=obs, math=m16._lib.MATH_FAST)
     assert np.array_equal(c_e, c_f)
     np.testing.assert_allclose(s_f, s_e, rtol=1e-8)
+
+
+def test_batched_calibration_fast_float32(m16):
+    """float32 tower-day arrays on the FAST batched path: float64 arithmetic on the
+    widened inputs, rounded once."""
+    drv, lo, hi, rng = _calibration_inputs(4000, 45, np.float32)
+    params = rng.uniform(lo, hi, (7, 11)).astype(np.float32)
+    got = m16.MOD16._et_batch(params, *drv, separate=True, math=m16._lib.MATH_FAST)
+    want = m16.MOD16._et_batch(params.astype(np.float64), *[d.astype(np.float64) for d in drv],
+                               separate=True, math=m16._lib.MATH_FAST)
+    for a, b in zip(got, want):
+        assert a.dtype == np.float32 and b.dtype == np.float64
+        assert np.array_equal(a, b.astype(np.float32), equal_nan=True)
