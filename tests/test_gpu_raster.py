@@ -350,3 +350,34 @@ def test_host_path_over_many_tiles_equals_device_path(env, dtype):
     eng.check()
     for got, want in zip((cd, sd, td, cn, sn, tn), to_np(sep)):
         assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_more_than_two_to_the_31_pixels(env):
+    """64-bit indexing end to end: a float32 raster of 2^31 + 12345 pixels (137 GB
+    on the device); windows on both sides of 2^31 and at the end equal small runs
+    on copies of the same pixels, and the diagnostics count every pixel once."""
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table, dtype='float32')
+    n = 2 ** 31 + 12345
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150e9:
+        pytest.skip('needs 150 GB of free device memory')
+    cls, drv, day, night = eng.alloc_raster(n)
+    eng.synth(n, seed=81, out=(cls, drv))
+    diag = torch.zeros(8, dtype=torch.float64, device='cuda')
+    eng.run(cls, drv, day, night, diag=diag)
+    eng.check()
+    d = diag.cpu().numpy()
+    assert d[2] + d[4] == n and d[3] + d[5] == n            # n_valid + n_nan, day and night
+    m = 4096
+    for off in (0, 2 ** 31 - 2048, 2 ** 31 + 4, n - m):
+        sub_d, sub_n = eng.run(cls[off:off + m].clone(), [x[off:off + m].clone() for x in drv])
+        assert torch.equal(torch.nan_to_num(day[off:off + m]), torch.nan_to_num(sub_d)), off
+        assert torch.equal(torch.nan_to_num(night[off:off + m]), torch.nan_to_num(sub_n)), off
+    # the generator itself is keyed on the global pixel index: the tail equals a direct call
+    c2, d2 = eng.synth(m, seed=81, pixel_offset=n - m)
+    assert torch.equal(c2, cls[n - m:])
+    assert torch.equal(torch.nan_to_num(d2[5]), torch.nan_to_num(drv[5][n - m:]))
+    eng.check()
+    del cls, drv, day, night
+    torch.cuda.empty_cache()
