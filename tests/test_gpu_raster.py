@@ -381,3 +381,22 @@ def test_more_than_two_to_the_31_pixels(env):
     eng.check()
     del cls, drv, day, night
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_diagnostics_of_an_all_nan_raster(env, dtype):
+    """Every pixel of an invalid class (NaN parameters): sums 0, no valid pixel, the
+    maxima stay at their start value -inf; fused and stand-alone reductions agree."""
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table, dtype=dtype)
+    n = 300000
+    cls, drv = eng.synth(n, seed=6)
+    cls.fill_(11)
+    fused = torch.zeros(8, dtype=torch.float64, device='cuda')
+    day, night = eng.run(cls, drv, diag=fused)
+    alone = eng.diagnostics(day, night)
+    eng.check()
+    assert bool(torch.isnan(day).all()) and bool(torch.isnan(night).all())
+    want = np.array([0.0, 0.0, 0.0, 0.0, n, n, -np.inf, -np.inf])
+    assert np.array_equal(fused.cpu().numpy(), want)
+    assert np.array_equal(alone.cpu().numpy(), want)
