@@ -355,3 +355,22 @@ def test_float32_class_interface_is_float64_arithmetic_rounded_once(m16, golden)
         want = m64.evapotranspiration_and_pet(*drv64)
         for a, b in zip(got, want):
             assert np.array_equal(a, b.astype(np.float32), equal_nan=True)
+
+
+def test_scalar_drivers_over_many_tiles(m16, golden):
+    """Broadcast scalars (here sw_rad_night = 0 and one albedo) with rasters that span
+    several staged tiles: the plain kernels under the staging threads against the same
+    call with the scalars expanded (the pipeline), totals and potential ET."""
+    f = golden('f3_random64_f64')
+    n = 3 * (1 << 21) + 7
+    cls, drv = synth.drivers((n,), seed=10)
+    drv_s = list(drv)
+    drv_s[3] = 0.0
+    drv_s[4] = 0.17
+    drv_d = list(drv)
+    drv_d[3] = np.zeros(n)
+    drv_d[4] = np.full(n, 0.17)
+    got = m16.evapotranspiration_raster(f['table'], cls, *drv_s, pet=True)
+    want = m16.evapotranspiration_raster(f['table'], cls, *drv_d, pet=True)
+    for a, b, what in zip(got, want, ('day', 'night', 'pet day', 'pet night')):
+        assert_parity(a, b, 1e-12, what)
