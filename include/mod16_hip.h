@@ -18,7 +18,10 @@
  *   - `where` says whether the data pointers are HOST (pageable or pinned
  *     memory; the call stages tiles through the GPU and is synchronous) or
  *     DEVICE (zero-copy, asynchronous on `stream`, a hipStream_t or NULL);
- *   - one ctx per host thread and GPU; a ctx is not thread-safe.
+ *   - a ctx serialises the calls made on it (every entry point holds the ctx's
+ *     mutex), so sharing one between host threads is safe; for concurrency use
+ *     one ctx per host thread and GPU (each owns its staging slabs, streams,
+ *     BPLUT copy and workspace).
  */
 #ifndef MOD16_HIP_H
 #define MOD16_HIP_H
@@ -29,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MOD16_ABI_VERSION 1
+#define MOD16_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define MOD16_API __attribute__((visibility("default")))
@@ -251,7 +254,9 @@ MOD16_API int mod16_graph_destroy(mod16_graph* graph);
  * the reference does); istride 0 = broadcast scalar, 1 = dense; `params` as in
  * mod16_et_* (may be NULL for the static / module-level methods); `out` holds 2
  * pointers (second NULL unless the method returns a pair); `alpha` is used by
- * POT_TRANSPIRATION only. `where` as in mod16_et_*.
+ * POT_TRANSPIRATION only, `tiny` (the reference's argument of that name,
+ * :869, :1157; default 1e-7) by EVAP_WET_CANOPY and TRANSPIRATION_*. `where` as
+ * in mod16_et_*.
  *
  *   SVP                 temp_k                                     :1340
  *   SVP_SLOPE           temp_k, s?                                 :1370
@@ -283,13 +288,13 @@ enum mod16_method {
 MOD16_API int mod16_method_f64(mod16_ctx* ctx, int method,
                      const double* const* in, const int64_t* istride,
                      const double* const* params, const int64_t* pstride,
-                     int64_t n, double* const* out, double alpha, int where,
-                     void* stream);
+                     int64_t n, double* const* out, double alpha, double tiny,
+                     int where, void* stream);
 MOD16_API int mod16_method_f32(mod16_ctx* ctx, int method,
                      const float* const* in, const int64_t* istride,
                      const float* const* params, const int64_t* pstride,
-                     int64_t n, float* const* out, float alpha, int where,
-                     void* stream);
+                     int64_t n, float* const* out, float alpha, float tiny,
+                     int where, void* stream);
 
 /*
  * The vectorised calibration path MOD16._evapotranspiration (reference
@@ -298,18 +303,19 @@ MOD16_API int mod16_method_f32(mod16_ctx* ctx, int method,
  * is a different algorithm from mod16_et_* (other clamps, tmin_open in the
  * soil-heat-flux condition, transpiration switched for the whole array on
  * any(g_surf > 0)). `rcorr` = NULL or two arrays (day, night), the reference's
- * `r_corr_list`; strides as elsewhere. HOST or DEVICE; synchronous in HOST.
+ * `r_corr_list`; `tiny` is the reference's argument of that name (:199,
+ * default 1e-7); strides as elsewhere. HOST or DEVICE; synchronous in HOST.
  */
 MOD16_API int mod16_et_static_f64(mod16_ctx* ctx, const double* const* drivers,
                         const int64_t* dstride, const double* const* params,
                         const int64_t* pstride, const double* const* rcorr,
                         const int64_t* rstride, int64_t n, double* out_day,
-                        double* out_night, int where, void* stream);
+                        double* out_night, double tiny, int where, void* stream);
 MOD16_API int mod16_et_static_f32(mod16_ctx* ctx, const float* const* drivers,
                         const int64_t* dstride, const float* const* params,
                         const int64_t* pstride, const float* const* rcorr,
                         const int64_t* rstride, int64_t n, float* out_day,
-                        float* out_night, int where, void* stream);
+                        float* out_night, float tiny, int where, void* stream);
 
 /*
  * The calibration path batched over parameter vectors:
@@ -393,6 +399,68 @@ MOD16_API int mod16_time_et(mod16_ctx* ctx, int is_f32, const uint8_t* cls,
                   int64_t n, void* out_day, void* out_night,
                   void* const* out_sep, unsigned flags, double* ddiag,
                   int launches, void* stream, float* ms);
+
+/*
+ * Tiled rasters: the engine's own layout for rasters that stay resident on the
+ * device (DEVICE pointers only). The reference passes 16 separate arrays
+ * (14 drivers, day, night); streamed side by side they lie GiB apart in HBM and
+ * the 14-read + 2-write mix reaches 5.7 TB/s. Cut into tiles of `tile` pixels
+ * and interleaved -- [tile][field][tile pixels], every array keeps its own base
+ * pointer and reads as a 2-D strided view -- the same bytes stream at 6.5 TB/s
+ * (tools/probe_layout.hip, tile = 32-64 KiB per field). Pixel i of an array:
+ *
+ *     base[(i / tile) * row + (i % tile)]
+ *
+ * `tile` is a power of two (>= 8 KiB per field); `driver_row`, `out_row` are in
+ * elements and apply to every driver / output array, `cls_row` in bytes to the
+ * class raster; rows are multiples of the 16-byte vector width, bases 16-byte
+ * aligned, n a multiple of the vector width (the storage is padded to whole
+ * tiles by whoever allocates it). tile = 0 in mod16_synth_tiled_* means plain
+ * arrays. mod16_et_tiled_* = mod16_et_diag_* on that layout (ddiag may be NULL;
+ * MOD16_MATH_FAST or, float32, MOD16_MATH_MIXED); mod16_graph_et_tiled_* captures
+ * it for replay with mod16_graph_launch. Host arrays reach the layout with 2-D
+ * copies (hipMemcpy2DAsync, width = tile, destination pitch = row).
+ */
+typedef struct mod16_layout {
+    int64_t tile;        /* pixels per tile */
+    int64_t driver_row;  /* elements between successive tiles of a driver array */
+    int64_t out_row;     /* elements between successive tiles of an output array */
+    int64_t cls_row;     /* bytes between successive tiles of the class raster */
+} mod16_layout;
+MOD16_API int mod16_et_tiled_f64(mod16_ctx* ctx, const mod16_layout* layout,
+                       const uint8_t* cls, const double* const* drivers, int64_t n,
+                       double* out_day, double* out_night, unsigned flags,
+                       double* ddiag, void* stream);
+MOD16_API int mod16_et_tiled_f32(mod16_ctx* ctx, const mod16_layout* layout,
+                       const uint8_t* cls, const float* const* drivers, int64_t n,
+                       float* out_day, float* out_night, unsigned flags,
+                       double* ddiag, void* stream);
+MOD16_API int mod16_graph_et_tiled_f64(mod16_ctx* ctx, const mod16_layout* layout,
+                       const uint8_t* cls, const double* const* drivers, int64_t n,
+                       double* out_day, double* out_night, unsigned flags,
+                       double* ddiag, mod16_graph** out);
+MOD16_API int mod16_graph_et_tiled_f32(mod16_ctx* ctx, const mod16_layout* layout,
+                       const uint8_t* cls, const float* const* drivers, int64_t n,
+                       float* out_day, float* out_night, unsigned flags,
+                       double* ddiag, mod16_graph** out);
+MOD16_API int mod16_synth_tiled_f64(mod16_ctx* ctx, const mod16_layout* layout,
+                       uint64_t seed, int64_t step, int64_t pixel_offset, int64_t n,
+                       uint8_t* cls, double* const* drivers, void* stream);
+MOD16_API int mod16_synth_tiled_f32(mod16_ctx* ctx, const mod16_layout* layout,
+                       uint64_t seed, int64_t step, int64_t pixel_offset, int64_t n,
+                       uint8_t* cls, float* const* drivers, void* stream);
+
+/* Mean milliseconds per replay of a captured step: `launches` back-to-back
+ * mod16_graph_launch calls bracketed by HIP events on `stream`. Synchronous. */
+MOD16_API int mod16_time_graph(mod16_graph* graph, int launches, void* stream, float* ms);
+
+/*
+ * Measurement aid for bench.py ("roofline vs measured
+ * copy bandwidth"): allocates two device buffers of `bytes`, times a one-shot
+ * 16-byte-per-lane copy kernel `reps` times with HIP events and returns the
+ * best rate, (bytes read + bytes written) / time, in GB/s. Synchronous.
+ */
+MOD16_API int mod16_measure_copy(mod16_ctx* ctx, int64_t bytes, int reps, float* gbps);
 
 #ifdef __cplusplus
 }

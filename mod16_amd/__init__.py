@@ -149,7 +149,7 @@ def _forward(cls, drivers, params, separate, flags, device, pet=False, out=None)
     return (outs[0], outs[1])
 
 
-def _call_method(method, inputs, params=None, nout=1, alpha=1.26, device=0):
+def _call_method(method, inputs, params=None, nout=1, alpha=1.26, device=0, tiny=1e-7):
     '''Runs one sub-method of the class surface on the GPU (``mod16_method_*``,
     reference operation order). ``inputs`` follows the reference signature,
     ``None`` = optional argument not given; ``params`` maps parameter name ->
@@ -177,17 +177,11 @@ def _call_method(method, inputs, params=None, nout=1, alpha=1.26, device=0):
     outs = [np.empty(shape, dtype) for _ in range(nout)]
     if n:
         ctx.method(dtype, method, iptr, istr, pptr, pstr, n,
-                   [o.ctypes.data for o in outs] + [None] * (2 - nout), alpha=alpha)
+                   [o.ctypes.data for o in outs] + [None] * (2 - nout), alpha=alpha,
+                   tiny=tiny)
     if not shape:
         outs = [o[()] for o in outs]
     return outs[0] if nout == 1 else tuple(outs)
-
-
-def _check_tiny(tiny):
-    if tiny != 1e-7:
-        raise NotImplementedError(
-            'the GPU kernels fix tiny = 1e-7 (the reference default, '
-            'mod16/__init__.py:869, :1157)')
 
 
 class MOD16(object):
@@ -337,7 +331,6 @@ class MOD16(object):
         numerically different algorithm from ``MOD16.evapotranspiration()``;
         ``f_wet`` is ignored as in the reference (:282).
         '''
-        _check_tiny(tiny)
         drivers = [lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
                    sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
                    vpd_night, pressure, fpar, lai]
@@ -363,7 +356,7 @@ class MOD16(object):
                 _lib.ptr_array(pptr), _lib.i64_array(pstr),
                 _lib.ptr_array(rptr) if rc else None,
                 _lib.i64_array(rstr) if rc else None, n, day.ctypes.data,
-                night.ctypes.data, _lib.HOST, None))
+                night.ctypes.data, float(tiny), _lib.HOST, None))
         if not shape:
             return [day[()], night[()]]
         return [day, night]
@@ -374,7 +367,9 @@ class MOD16(object):
             vpd_night, pressure, fpar, lai, f_wet=None, tiny=1e-7,
             r_corr_list=None):
         '''Total (day + night) latent heat flux [W m-2], for calibration
-        (reference mod16/__init__.py:162-193).'''
+        (reference mod16/__init__.py:162-193). As in the reference, ``f_wet``
+        and ``tiny`` are accepted and NOT passed on (:190-192 calls
+        ``_evapotranspiration`` with ``tiny = 1e-7``).'''
         day, night = MOD16._evapotranspiration(
             params, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
             sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
@@ -498,11 +493,10 @@ class MOD16(object):
             self, pressure, temp_k, vpd, lai, fpar, rad_canopy, lhv=None,
             rhumidity=None, f_wet=None, tiny=1e-7):
         'Wet-canopy evaporation [kg m-2 s-1], reference :866-961.'
-        _check_tiny(tiny)
         return _call_method(
             _lib.M_EVAP_WET_CANOPY,
             [pressure, temp_k, vpd, lai, fpar, rad_canopy, lhv, rhumidity, f_wet],
-            self._p('gl_sh', 'gl_wv'), device=self.device)
+            self._p('gl_sh', 'gl_wv'), device=self.device, tiny=tiny)
 
     def radiation_soil(
             self, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night, sw_albedo,
@@ -534,13 +528,12 @@ class MOD16(object):
             r_corr=None, lhv=None, rhumidity=None, f_wet=None, daytime=True,
             tiny=1e-7):
         'Plant transpiration [kg m-2 s-1], reference :1152-1258.'
-        _check_tiny(tiny)
         return _call_method(
             _lib.M_TRANSPIRATION_DAY if daytime else _lib.M_TRANSPIRATION_NIGHT,
             [pressure, temp_k, vpd, lai, fpar, rad_canopy, tmin, r_corr, lhv,
              rhumidity, f_wet],
             self._p('tmin_close', 'tmin_open', 'vpd_open', 'vpd_close', 'gl_sh',
-                    'g_cuticular', 'csl'), device=self.device)
+                    'g_cuticular', 'csl'), device=self.device, tiny=tiny)
 
 
 def latent_heat_vaporization(temp_k):

@@ -6,6 +6,7 @@ when a computation is requested, the call fails loudly.
 '''
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -26,6 +27,7 @@ OK = 0
 ERR_ARG, ERR_HIP, ERR_CLASS_RANGE, ERR_NOMEM, ERR_NO_DEVICE, ERR_NO_BPLUT = \
     -1, -2, -3, -4, -5, -6
 
+ABI_VERSION = 2
 LIB_NAME = 'libmod16hip.so'
 # MOD16_LIB: alternative build of the same library (kernel experiments only)
 LIB_PATH = os.environ.get('MOD16_LIB') or os.path.join(
@@ -42,6 +44,16 @@ class Mod16Error(RuntimeError):
 
 _PP = C.POINTER(C.c_void_p)
 _I64P = C.POINTER(C.c_int64)
+
+
+class Layout(C.Structure):
+    '''``mod16_layout`` (include/mod16_hip.h): pixel i of an array of a tiled
+    raster lives at ``base[(i // tile) * row + (i % tile)]``.'''
+    _fields_ = [('tile', C.c_int64), ('driver_row', C.c_int64),
+                ('out_row', C.c_int64), ('cls_row', C.c_int64)]
+
+
+_LAYP = C.POINTER(Layout)
 
 # name -> (restype, argtypes); one entry per function declared in the header
 PROTOTYPES = {
@@ -88,16 +100,16 @@ PROTOTYPES = {
     'mod16_graph_destroy': (C.c_int, [C.c_void_p]),
     'mod16_method_f64': (C.c_int, [
         C.c_void_p, C.c_int, _PP, _I64P, _PP, _I64P, C.c_int64, _PP, C.c_double,
-        C.c_int, C.c_void_p]),
+        C.c_double, C.c_int, C.c_void_p]),
     'mod16_method_f32': (C.c_int, [
         C.c_void_p, C.c_int, _PP, _I64P, _PP, _I64P, C.c_int64, _PP, C.c_float,
-        C.c_int, C.c_void_p]),
+        C.c_float, C.c_int, C.c_void_p]),
     'mod16_et_static_f64': (C.c_int, [
         C.c_void_p, _PP, _I64P, _PP, _I64P, _PP, _I64P, C.c_int64, C.c_void_p,
-        C.c_void_p, C.c_int, C.c_void_p]),
+        C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
     'mod16_et_static_f32': (C.c_int, [
         C.c_void_p, _PP, _I64P, _PP, _I64P, _PP, _I64P, C.c_int64, C.c_void_p,
-        C.c_void_p, C.c_int, C.c_void_p]),
+        C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
     'mod16_et_static_batch_f64': (C.c_int, [
         C.c_void_p, _PP, _I64P, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -119,6 +131,26 @@ PROTOTYPES = {
     'mod16_synth_f32': (C.c_int, [
         C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
         _PP, C.c_void_p]),
+    'mod16_et_tiled_f64': (C.c_int, [
+        C.c_void_p, _LAYP, C.c_void_p, _PP, C.c_int64, C.c_void_p, C.c_void_p,
+        C.c_uint, C.c_void_p, C.c_void_p]),
+    'mod16_et_tiled_f32': (C.c_int, [
+        C.c_void_p, _LAYP, C.c_void_p, _PP, C.c_int64, C.c_void_p, C.c_void_p,
+        C.c_uint, C.c_void_p, C.c_void_p]),
+    'mod16_graph_et_tiled_f64': (C.c_int, [
+        C.c_void_p, _LAYP, C.c_void_p, _PP, C.c_int64, C.c_void_p, C.c_void_p,
+        C.c_uint, C.c_void_p, C.POINTER(C.c_void_p)]),
+    'mod16_graph_et_tiled_f32': (C.c_int, [
+        C.c_void_p, _LAYP, C.c_void_p, _PP, C.c_int64, C.c_void_p, C.c_void_p,
+        C.c_uint, C.c_void_p, C.POINTER(C.c_void_p)]),
+    'mod16_synth_tiled_f64': (C.c_int, [
+        C.c_void_p, _LAYP, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+        _PP, C.c_void_p]),
+    'mod16_synth_tiled_f32': (C.c_int, [
+        C.c_void_p, _LAYP, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+        _PP, C.c_void_p]),
+    'mod16_time_graph': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+    'mod16_measure_copy': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
     'mod16_time_et': (C.c_int, [
         C.c_void_p, C.c_int, C.c_void_p, _PP, _I64P, _PP, _I64P, C.c_int64,
         C.c_void_p, C.c_void_p, _PP, C.c_uint, C.c_void_p, C.c_int, C.c_void_p,
@@ -170,9 +202,9 @@ def load():
             raise
         fn.restype = res
         fn.argtypes = args
-    if lib.mod16_version() != 1:
-        raise ImportError('libmod16hip ABI version %d, expected 1'
-                          % lib.mod16_version())
+    if lib.mod16_version() != ABI_VERSION:
+        raise ImportError('libmod16hip ABI version %d, expected %d'
+                          % (lib.mod16_version(), ABI_VERSION))
     _lib = lib
     return lib
 
@@ -260,7 +292,7 @@ class Context:
             int(flags), int(where), stream))
 
     def method(self, dtype, method, inputs, istride, params, pstride, n, outs,
-               alpha=1.26, where=HOST, stream=None):
+               alpha=1.26, tiny=1e-7, where=HOST, stream=None):
         '''Thin wrapper of mod16_method_f64 / _f32 (raw addresses or None).'''
         fn = self.lib.mod16_method_f32 if np.dtype(dtype) == np.float32 \
             else self.lib.mod16_method_f64
@@ -268,18 +300,28 @@ class Context:
             self.handle, int(method), ptr_array(inputs), i64_array(istride),
             ptr_array(params) if params is not None else None,
             i64_array(pstride) if pstride is not None else None,
-            int(n), ptr_array(outs), float(alpha), int(where), stream))
+            int(n), ptr_array(outs), float(alpha), float(tiny), int(where), stream))
 
     def check_status(self, stream=None):
         self.check(self.lib.mod16_check_status(self.handle, stream))
 
 
-_contexts = {}
+_local = threading.local()
 
 
 def context(device=0):
-    '''Process-wide context per device (created on first use).'''
-    ctx = _contexts.get(device)
+    '''The calling thread's context on ``device`` (created on first use).
+
+    One context per host thread and GPU: the reference's functions are pure and
+    may be called from several threads at once; a context
+    owns staging slabs, streams, a BPLUT copy and a workspace, so threads that
+    shared one would take turns (the library serialises calls on a ctx) and
+    would see each other's ``set_bplut``. Contexts of finished threads are
+    destroyed with the thread's locals.'''
+    table = getattr(_local, 'contexts', None)
+    if table is None:
+        table = _local.contexts = {}
+    ctx = table.get(device)
     if ctx is None:
-        ctx = _contexts[device] = Context(device)
+        ctx = table[device] = Context(device)
     return ctx

@@ -29,7 +29,17 @@ constexpr int kSlots = 4;                           // staging slots = host thre
 constexpr size_t kStagger = 33 * 1024;              // see RasterEngine.STAGGER_BYTES
 }  // namespace
 
+// Workspace of the per-run diagnostics partials of et_stream_kernel (and of the
+// stand-alone reduction). The context owns one, sized on demand; a captured
+// graph owns its own, so growing the context's never pulls memory from under
+// a graph that is replayed later.
+struct DiagWs {
+    double* partial = nullptr;   // device [capacity][kDiag]
+    int64_t capacity = 0;        // in partials
+};
+
 struct mod16_ctx {
+    std::recursive_mutex api_mu;     // every entry point holds it: a ctx may be shared by threads
     int device = 0;
     int cus = 256;
     int grid_mult = 64;              // blocks per CU in the grid-stride launches of the plain kernels
@@ -46,8 +56,11 @@ struct mod16_ctx {
     unsigned* status = nullptr;      // device status word
     unsigned* status_host = nullptr; // pinned mirror
     unsigned* static_flag = nullptr; // device word of mod16_et_static_*
-    double* diag_partial = nullptr;  // device [diag_capacity][kDiag]
-    int64_t diag_capacity = 0;       // in blocks
+    DiagWs ws;                       // diagnostics partials of launches outside a graph
+    DiagWs* force_ws = nullptr;      // workspace to use instead (graph capture)
+    hipEvent_t ws_event = nullptr;   // recorded behind the last launch that produced diagnostics in `ws`
+    hipStream_t ws_stream = nullptr; // ... and the stream it ran on
+    bool ws_pending = false;
     double* diag_dev = nullptr;      // device [kDiag]
     double* diag_host = nullptr;     // pinned [kDiag]
     // HOST-mode staging: per slot one device slab + one stream
@@ -73,6 +86,10 @@ struct mod16_ctx {
             return MOD16_ERR_HIP;                                                  \
         }                                                                          \
     } while (0)
+
+// every entry point that takes a ctx holds its mutex for the duration of the call
+#define MOD16_LOCK(ctx) std::unique_lock<std::recursive_mutex> api_lock_; \
+    if (ctx) api_lock_ = std::unique_lock<std::recursive_mutex>((ctx)->api_mu)
 
 static int fail(mod16_ctx* ctx, int code, const char* msg) {
     if (ctx) ctx->err = msg;
@@ -122,7 +139,8 @@ extern "C" int mod16_destroy(mod16_ctx* ctx) {
     if (ctx->status) (void)hipFree(ctx->status);
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     if (ctx->static_flag) (void)hipFree(ctx->static_flag);
-    if (ctx->diag_partial) (void)hipFree(ctx->diag_partial);
+    if (ctx->ws.partial) (void)hipFree(ctx->ws.partial);
+    if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
     if (ctx->diag_dev) (void)hipFree(ctx->diag_dev);
     if (ctx->diag_host) (void)hipHostFree(ctx->diag_host);
     delete ctx;
@@ -173,8 +191,9 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
         HIPCHK(ctx, hipMalloc(&ctx->status, sizeof(unsigned)));
         HIPCHK(ctx, hipMemset(ctx->status, 0, sizeof(unsigned)));
         HIPCHK(ctx, hipHostMalloc(&ctx->status_host, sizeof(unsigned)));
-        HIPCHK(ctx, hipMalloc(&ctx->diag_partial, sizeof(double) * kDiagBlocks * kDiag));
-        ctx->diag_capacity = kDiagBlocks;
+        HIPCHK(ctx, hipMalloc(&ctx->ws.partial, sizeof(double) * kDiagBlocks * kDiag));
+        ctx->ws.capacity = kDiagBlocks;
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming));
         HIPCHK(ctx, hipMalloc(&ctx->diag_dev, sizeof(double) * kDiag));
         HIPCHK(ctx, hipHostMalloc(&ctx->diag_host, sizeof(double) * kDiag));
         HIPCHK(ctx, hipMalloc(&ctx->scalars, 32 * sizeof(double)));
@@ -191,6 +210,7 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
 }
 
 extern "C" int mod16_set_bplut_f64(mod16_ctx* ctx, const double* lut) {
+    MOD16_LOCK(ctx);
     if (!ctx || !lut) return fail(ctx, MOD16_ERR_ARG, "mod16_set_bplut_f64: NULL argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const double nan = std::numeric_limits<double>::quiet_NaN();
@@ -284,20 +304,72 @@ static int grid_for(const mod16_ctx* ctx, int64_t nvec) {
 }
 
 // All pointers are device pointers here.
-static int reserve_diag(mod16_ctx* ctx, int64_t blocks) {
-    if (blocks <= ctx->diag_capacity) return MOD16_OK;
+// -> the workspace for `blocks` partials: the forced one (graph capture; it was
+// sized by its owner) or the context's, grown if need be. Captured graphs never
+// point into the context's workspace, so it can be replaced once the device is idle.
+static int reserve_diag(mod16_ctx* ctx, int64_t blocks, DiagWs** out = nullptr) {
+    if (ctx->force_ws) {
+        if (blocks > ctx->force_ws->capacity)
+            return fail(ctx, MOD16_ERR_ARG, "internal: graph workspace smaller than its launch");
+        if (out) *out = ctx->force_ws;
+        return MOD16_OK;
+    }
+    if (out) *out = &ctx->ws;
+    if (blocks <= ctx->ws.capacity) return MOD16_OK;
     HIPCHK(ctx, hipDeviceSynchronize());   // growing only: earlier launches may still use it
-    HIPCHK(ctx, hipFree(ctx->diag_partial));
-    ctx->diag_partial = nullptr;
-    ctx->diag_capacity = 0;
-    HIPCHK(ctx, hipMalloc(&ctx->diag_partial, sizeof(double) * blocks * kDiag));
-    ctx->diag_capacity = blocks;
+    HIPCHK(ctx, hipFree(ctx->ws.partial));
+    ctx->ws.partial = nullptr;
+    ctx->ws.capacity = 0;
+    ctx->ws_pending = false;
+    HIPCHK(ctx, hipMalloc(&ctx->ws.partial, sizeof(double) * blocks * kDiag));
+    ctx->ws.capacity = blocks;
+    return MOD16_OK;
+}
+
+// The context's workspace is shared by its launches (every pipeline launch
+// writes per-run partials, wanted or not). Launches on ONE stream are ordered
+// anyway; a launch on another stream than the previous one waits for it, so the
+// previous launch's final sum has read its partials before they are overwritten.
+// Inside a graph capture the graph's own workspace is used instead.
+static int ws_acquire(mod16_ctx* ctx, hipStream_t st) {
+    if (ctx->force_ws) return MOD16_OK;
+    if (ctx->ws_pending && st != ctx->ws_stream)
+        HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ws_event, 0));
+    return MOD16_OK;
+}
+static int ws_release(mod16_ctx* ctx, hipStream_t st) {
+    if (ctx->force_ws) return MOD16_OK;
+    HIPCHK(ctx, hipEventRecord(ctx->ws_event, st));
+    ctx->ws_stream = st;
+    ctx->ws_pending = true;
     return MOD16_OK;
 }
 
 template <typename T>
 static int reduce_entry(mod16_ctx* ctx, const T* day, const T* night, int64_t n, double* diag,
                         double* ddiag, void* stream);
+
+// Launch geometry of the production pipeline for n pixels, V per 16-byte vector.
+struct StreamGeom { int run_shift; int64_t npiece, nruns; int grid; };
+static StreamGeom stream_geom(const mod16_ctx* ctx, int64_t n, int V, int tile_shift = kNoTile) {
+    StreamGeom g;
+    g.npiece = (n / V + 63) / 64;
+    // run length: kDynRun pieces, halved for small rasters until every wave the
+    // chip holds (2 blocks of 4 per CU) gets at least one run
+    const int64_t chip_waves = (int64_t)ctx->cus * 2 * (kBlock / 64);
+    int run_shift = 0;
+    while ((1 << run_shift) < kDynRun) ++run_shift;
+    while (run_shift > 1 && (g.npiece >> run_shift) < chip_waves) --run_shift;   // >= 2 pieces: the claim of a run is consumed in its second iteration
+    if (ctx->run_shift > 0) run_shift = ctx->run_shift;
+    run_shift = std::min(run_shift, tile_shift);     // a run never straddles two tiles
+    g.run_shift = run_shift;
+    g.nruns = (g.npiece + (int64_t(1) << run_shift) - 1) >> run_shift;
+    // persistent waves: 2 blocks per CU is what the LDS slots allow
+    g.grid = (int)std::max<int64_t>(1, std::min<int64_t>(
+        (g.nruns + (kBlock / 64) - 1) / (kBlock / 64), (int64_t)ctx->cus * 2));
+    return g;
+}
+constexpr int kStage = 1024;     // slices of the two-level sum of the per-run partials
 
 // The production pipeline for dense class rasters (mod16_stream.hpp). s.n must
 // be a multiple of the vector width. ddiag != NULL: also the fixed-order sum
@@ -306,7 +378,6 @@ static int reduce_entry(mod16_ctx* ctx, const T* day, const T* night, int64_t n,
 template <typename T, int MODE>
 static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double* ddiag = nullptr) {
     constexpr int V = VecOf<T>::v;
-    constexpr int kStage = 1024;
     s.lut64 = ctx->lut64;
     s.tab = ctx->tab64;
     s.status = ctx->status;
@@ -314,22 +385,20 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
                                                  : ctx->dyn_counters + 16 * (ctx->dyn_next++ % 64);
     HIPCHK(ctx, hipMemsetAsync(ctr, 0, sizeof(unsigned long long), st));
     s.dyn_counter = ctr;
-    const int64_t npiece = (s.n / V + 63) / 64;
-    // run length: kDynRun pieces, halved for small rasters until every wave the
-    // chip holds (2 blocks of 4 per CU) gets at least one run
-    const int64_t chip_waves = (int64_t)ctx->cus * 2 * (kBlock / 64);
-    int run_shift = 0;
-    while ((1 << run_shift) < kDynRun) ++run_shift;
-    while (run_shift > 1 && (npiece >> run_shift) < chip_waves) --run_shift;   // >= 2 pieces: the claim of a run is consumed in its second iteration
-    if (ctx->run_shift > 0) run_shift = ctx->run_shift;
-    s.run_shift = run_shift;
-    const int64_t nruns = (npiece + (int64_t(1) << run_shift) - 1) >> run_shift;
-    // persistent waves: 2 blocks per CU is what the LDS slots allow
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(
-        (nruns + (kBlock / 64) - 1) / (kBlock / 64), (int64_t)ctx->cus * 2));
-    int rc = reserve_diag(ctx, nruns + kStage);
+    if (s.tile_shift <= 0) {       // plain arrays: one "tile"
+        s.tile_shift = kNoTile;
+        s.wide_row = s.out_row = s.byte_row = 0;
+    }
+    const StreamGeom g = stream_geom(ctx, s.n, V, s.tile_shift);
+    s.run_shift = g.run_shift;
+    const int64_t nruns = g.nruns;
+    const int grid = g.grid;
+    DiagWs* ws = nullptr;
+    int rc = reserve_diag(ctx, nruns + kStage, &ws);
     if (rc != MOD16_OK) return rc;
-    s.diag_partial = ctx->diag_partial;
+    rc = ws_acquire(ctx, st);
+    if (rc != MOD16_OK) return rc;
+    s.diag_partial = ws->partial;
     // equally spaced wide arrays (one slab): scalar base + k * pitch
     constexpr int NW = StreamSpec<MODE>::NW;
     const ptrdiff_t pitch_b = reinterpret_cast<const char*>(s.wide[1]) - reinterpret_cast<const char*>(s.wide[0]);
@@ -340,10 +409,10 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     if (pitched) hipLaunchKernelGGL((et_stream_kernel<T, MODE, true>), dim3(grid), dim3(kBlock), 0, st, s);
     else hipLaunchKernelGGL((et_stream_kernel<T, MODE, false>), dim3(grid), dim3(kBlock), 0, st, s);
     if (ddiag) {
-        const double* fin = ctx->diag_partial;
+        const double* fin = ws->partial;
         int64_t count = nruns;
         if (count > 4 * kStage) {   // two-level: 1024 fixed slices, then one block
-            double* stage = ctx->diag_partial + nruns * kDiag;
+            double* stage = ws->partial + nruns * kDiag;
             const int64_t per = (count + kStage - 1) / kStage;
             hipLaunchKernelGGL(diag_stage_kernel, dim3(kStage), dim3(kBlock), 0, st, fin, count, per, stage);
             fin = stage;
@@ -352,7 +421,7 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
         hipLaunchKernelGGL(diag_final_fused_kernel, dim3(1), dim3(kFinalBlock), 0, st,
                            fin, (int)count, s.n, ddiag);
     }
-    return MOD16_OK;
+    return ws_release(ctx, st);
 }
 
 // ddiag != NULL: also produce the diagnostics vector (device, 8 doubles).
@@ -646,6 +715,7 @@ extern "C" int mod16_et_f64(mod16_ctx* ctx, const uint8_t* cls, const double* co
                             const int64_t* pstride, int64_t n, double* out_day,
                             double* out_night, double* const* out_sep, unsigned flags,
                             int where, void* stream) {
+    MOD16_LOCK(ctx);
     return et_entry<double>(ctx, cls, drivers, dstride, params, pstride, n, out_day, out_night,
                             out_sep, flags, where, stream);
 }
@@ -654,6 +724,7 @@ extern "C" int mod16_et_f32(mod16_ctx* ctx, const uint8_t* cls, const float* con
                             const int64_t* dstride, const float* const* params,
                             const int64_t* pstride, int64_t n, float* out_day, float* out_night,
                             float* const* out_sep, unsigned flags, int where, void* stream) {
+    MOD16_LOCK(ctx);
     return et_entry<float>(ctx, cls, drivers, dstride, params, pstride, n, out_day, out_night,
                            out_sep, flags, where, stream);
 }
@@ -675,11 +746,13 @@ static int et_diag_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* dri
 extern "C" int mod16_et_diag_f64(mod16_ctx* ctx, const uint8_t* cls, const double* const* drivers,
                                  const int64_t* dstride, int64_t n, double* out_day,
                                  double* out_night, unsigned flags, double* ddiag, void* stream) {
+    MOD16_LOCK(ctx);
     return et_diag_entry<double>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, stream);
 }
 extern "C" int mod16_et_diag_f32(mod16_ctx* ctx, const uint8_t* cls, const float* const* drivers,
                                  const int64_t* dstride, int64_t n, float* out_day,
                                  float* out_night, unsigned flags, double* ddiag, void* stream) {
+    MOD16_LOCK(ctx);
     return et_diag_entry<float>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, stream);
 }
 
@@ -692,6 +765,7 @@ struct mod16_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     unsigned long long* counter = nullptr;   // its own ticket counter: replays never meet the ring
+    DiagWs ws;                               // its own diagnostics workspace (freed with the graph)
 };
 
 extern "C" int mod16_graph_destroy(mod16_graph* g) {
@@ -700,6 +774,7 @@ extern "C" int mod16_graph_destroy(mod16_graph* g) {
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     if (g->counter) (void)hipFree(g->counter);
+    if (g->ws.partial) (void)hipFree(g->ws.partial);
     delete g;
     return MOD16_OK;
 }
@@ -720,6 +795,11 @@ static int graph_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drive
     int rc = [&]() -> int {
         HIPCHK(ctx, hipMalloc(&g->counter, 128));
         ctx->force_counter = g->counter;
+        // the graph's kernel nodes keep pointing at this workspace for as long as
+        // the graph lives, whatever the context's own workspace does meanwhile
+        g->ws.capacity = std::max<int64_t>(kDiagBlocks, stream_geom(ctx, std::max<int64_t>(n, 0), VecOf<T>::v).nruns + kStage);
+        HIPCHK(ctx, hipMalloc(&g->ws.partial, sizeof(double) * g->ws.capacity * kDiag));
+        ctx->force_ws = &g->ws;
         // once outside a capture: validates the arguments and brings the workspace to size
         int r = et_diag_entry<T>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, st);
         if (r != MOD16_OK) return r;
@@ -733,6 +813,7 @@ static int graph_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drive
         return MOD16_OK;
     }();
     ctx->force_counter = nullptr;
+    ctx->force_ws = nullptr;
     if (rc != MOD16_OK) {
         mod16_graph_destroy(g);
         return rc;
@@ -745,12 +826,14 @@ extern "C" int mod16_graph_et_diag_f64(mod16_ctx* ctx, const uint8_t* cls, const
                                        const int64_t* dstride, int64_t n, double* out_day,
                                        double* out_night, unsigned flags, double* ddiag,
                                        mod16_graph** out) {
+    MOD16_LOCK(ctx);
     return graph_entry<double>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, out);
 }
 extern "C" int mod16_graph_et_diag_f32(mod16_ctx* ctx, const uint8_t* cls, const float* const* drivers,
                                        const int64_t* dstride, int64_t n, float* out_day,
                                        float* out_night, unsigned flags, double* ddiag,
                                        mod16_graph** out) {
+    MOD16_LOCK(ctx);
     return graph_entry<float>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, out);
 }
 extern "C" int mod16_graph_launch(mod16_graph* g, void* stream) {
@@ -764,6 +847,7 @@ extern "C" int mod16_et_pet_f64(mod16_ctx* ctx, const uint8_t* cls, const double
                                 const int64_t* pstride, int64_t n, double* out_day,
                                 double* out_night, double* pet_day, double* pet_night,
                                 unsigned flags, int where, void* stream) {
+    MOD16_LOCK(ctx);
     if (ctx && !pet_day && !pet_night) return fail(ctx, MOD16_ERR_ARG, "mod16_et_pet: no PET output given");
     return et_entry<double>(ctx, cls, drivers, dstride, params, pstride, n, out_day, out_night,
                             nullptr, flags, where, stream, pet_day, pet_night);
@@ -773,12 +857,14 @@ extern "C" int mod16_et_pet_f32(mod16_ctx* ctx, const uint8_t* cls, const float*
                                 const int64_t* pstride, int64_t n, float* out_day,
                                 float* out_night, float* pet_day, float* pet_night,
                                 unsigned flags, int where, void* stream) {
+    MOD16_LOCK(ctx);
     if (ctx && !pet_day && !pet_night) return fail(ctx, MOD16_ERR_ARG, "mod16_et_pet: no PET output given");
     return et_entry<float>(ctx, cls, drivers, dstride, params, pstride, n, out_day, out_night,
                            nullptr, flags, where, stream, pet_day, pet_night);
 }
 
 extern "C" int mod16_check_status(mod16_ctx* ctx, void* stream) {
+    MOD16_LOCK(ctx);
     if (!ctx) return MOD16_ERR_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return read_status(ctx, static_cast<hipStream_t>(stream));
@@ -790,6 +876,7 @@ extern "C" int mod16_time_et(mod16_ctx* ctx, int is_f32, const uint8_t* cls,
                              void* out_day, void* out_night, void* const* out_sep,
                              unsigned flags, double* ddiag, int launches, void* stream,
                              float* ms) {
+    MOD16_LOCK(ctx);
     if (!ctx || !ms || launches <= 0) return fail(ctx, MOD16_ERR_ARG, "mod16_time_et: bad argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -828,11 +915,50 @@ extern "C" int mod16_time_et(mod16_ctx* ctx, int is_f32, const uint8_t* cls,
     return rc;
 }
 
+extern "C" int mod16_measure_copy(mod16_ctx* ctx, int64_t bytes, int reps, float* gbps) {
+    MOD16_LOCK(ctx);
+    if (!ctx || !gbps || bytes < 16 || reps <= 0) return fail(ctx, MOD16_ERR_ARG, "mod16_measure_copy: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t nvec = bytes / 16;
+    void *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, nvec * 16) != hipSuccess || hipMalloc(&b, nvec * 16) != hipSuccess) {
+        (void)hipGetLastError();
+        if (a) (void)hipFree(a);
+        return fail(ctx, MOD16_ERR_NOMEM, "mod16_measure_copy: device memory for the two buffers");
+    }
+    int rc = [&]() -> int {
+        HIPCHK(ctx, hipMemset(a, 1, nvec * 16));
+        HIPCHK(ctx, hipMemset(b, 0, nvec * 16));
+        hipEvent_t e0, e1;
+        HIPCHK(ctx, hipEventCreate(&e0));
+        HIPCHK(ctx, hipEventCreate(&e1));
+        const unsigned grid = (unsigned)((nvec + kBlock - 1) / kBlock);
+        float best = 1e30f;
+        for (int r = 0; r <= reps; ++r) {      // the first launch is a warm-up
+            HIPCHK(ctx, hipEventRecord(e0, nullptr));
+            hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(kBlock), 0, nullptr,
+                               static_cast<const copy_vec_t*>(a), static_cast<copy_vec_t*>(b), nvec);
+            HIPCHK(ctx, hipEventRecord(e1, nullptr));
+            HIPCHK(ctx, hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0 && ms < best) best = ms;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *gbps = (float)(2.0 * (double)nvec * 16.0 / (best * 1e-3) / 1e9);
+        return MOD16_OK;
+    }();
+    (void)hipFree(a);
+    (void)hipFree(b);
+    return rc;
+}
+
 // ------------------------------------------------------- class-surface methods
 template <typename T>
 static int method_entry(mod16_ctx* ctx, int method, const T* const* in, const int64_t* istride,
                         const T* const* params, const int64_t* pstride, int64_t n,
-                        T* const* out, T alpha, int where, void* stream) {
+                        T* const* out, T alpha, T tiny, int where, void* stream) {
     if (!ctx) return MOD16_ERR_ARG;
     if (method < 0 || method >= MOD16_M_COUNT || !in || !istride || !out || !out[0] || n < 0)
         return fail(ctx, MOD16_ERR_ARG, "mod16_method: bad argument");
@@ -840,6 +966,7 @@ static int method_entry(mod16_ctx* ctx, int method, const T* const* in, const in
     memset(&a, 0, sizeof a);
     a.method = method;
     a.alpha = alpha;
+    a.tiny = tiny;
     a.n = n;
     static const T nan_param = std::numeric_limits<T>::quiet_NaN();
     for (int k = 0; k < kMethodMaxIn; ++k) {
@@ -936,14 +1063,16 @@ static int method_entry(mod16_ctx* ctx, int method, const T* const* in, const in
 extern "C" int mod16_method_f64(mod16_ctx* ctx, int method, const double* const* in,
                                 const int64_t* istride, const double* const* params,
                                 const int64_t* pstride, int64_t n, double* const* out,
-                                double alpha, int where, void* stream) {
-    return method_entry<double>(ctx, method, in, istride, params, pstride, n, out, alpha, where, stream);
+                                double alpha, double tiny, int where, void* stream) {
+    MOD16_LOCK(ctx);
+    return method_entry<double>(ctx, method, in, istride, params, pstride, n, out, alpha, tiny, where, stream);
 }
 extern "C" int mod16_method_f32(mod16_ctx* ctx, int method, const float* const* in,
                                 const int64_t* istride, const float* const* params,
                                 const int64_t* pstride, int64_t n, float* const* out, float alpha,
-                                int where, void* stream) {
-    return method_entry<float>(ctx, method, in, istride, params, pstride, n, out, alpha, where, stream);
+                                float tiny, int where, void* stream) {
+    MOD16_LOCK(ctx);
+    return method_entry<float>(ctx, method, in, istride, params, pstride, n, out, alpha, tiny, where, stream);
 }
 
 // ----------------------------------------------------- raw drivers (N1)
@@ -1113,6 +1242,7 @@ extern "C" int mod16_et_raw_f64(mod16_ctx* ctx, const uint8_t* cls, const double
                                 const uint8_t* lai_x10, const double* day_hours, int64_t hstride,
                                 int64_t n, double* out_day, double* out_night, double* out_total8,
                                 unsigned flags, int where, void* stream) {
+    MOD16_LOCK(ctx);
     return raw_entry<double>(ctx, cls, raw, rstride, fpar_pct, lai_x10, day_hours, hstride, n,
                              out_day, out_night, out_total8, flags, where, stream);
 }
@@ -1121,6 +1251,7 @@ extern "C" int mod16_et_raw_f32(mod16_ctx* ctx, const uint8_t* cls, const float*
                                 const uint8_t* lai_x10, const float* day_hours, int64_t hstride,
                                 int64_t n, float* out_day, float* out_night, float* out_total8,
                                 unsigned flags, int where, void* stream) {
+    MOD16_LOCK(ctx);
     return raw_entry<float>(ctx, cls, raw, rstride, fpar_pct, lai_x10, day_hours, hstride, n,
                             out_day, out_night, out_total8, flags, where, stream);
 }
@@ -1129,8 +1260,8 @@ extern "C" int mod16_et_raw_f32(mod16_ctx* ctx, const uint8_t* cls, const float*
 template <typename T>
 static int static_entry(mod16_ctx* ctx, const T* const* drivers, const int64_t* dstride,
                         const T* const* params, const int64_t* pstride, const T* const* rcorr,
-                        const int64_t* rstride, int64_t n, T* out_day, T* out_night, int where,
-                        void* stream) {
+                        const int64_t* rstride, int64_t n, T* out_day, T* out_night, T tiny,
+                        int where, void* stream) {
     if (!ctx) return MOD16_ERR_ARG;
     if (!drivers || !dstride || !params || !pstride || !out_day || !out_night || n < 0)
         return fail(ctx, MOD16_ERR_ARG, "mod16_et_static: bad argument");
@@ -1156,6 +1287,7 @@ static int static_entry(mod16_ctx* ctx, const T* const* drivers, const int64_t* 
     a.out[0] = out_day;
     a.out[1] = out_night;
     a.n = n;
+    a.tiny = tiny;
     if (n == 0) return MOD16_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!ctx->static_flag) HIPCHK(ctx, hipMalloc(&ctx->static_flag, sizeof(unsigned)));
@@ -1217,15 +1349,17 @@ extern "C" int mod16_et_static_f64(mod16_ctx* ctx, const double* const* drivers,
                                    const int64_t* dstride, const double* const* params,
                                    const int64_t* pstride, const double* const* rcorr,
                                    const int64_t* rstride, int64_t n, double* out_day,
-                                   double* out_night, int where, void* stream) {
-    return static_entry<double>(ctx, drivers, dstride, params, pstride, rcorr, rstride, n, out_day, out_night, where, stream);
+                                   double* out_night, double tiny, int where, void* stream) {
+    MOD16_LOCK(ctx);
+    return static_entry<double>(ctx, drivers, dstride, params, pstride, rcorr, rstride, n, out_day, out_night, tiny, where, stream);
 }
 extern "C" int mod16_et_static_f32(mod16_ctx* ctx, const float* const* drivers,
                                    const int64_t* dstride, const float* const* params,
                                    const int64_t* pstride, const float* const* rcorr,
                                    const int64_t* rstride, int64_t n, float* out_day,
-                                   float* out_night, int where, void* stream) {
-    return static_entry<float>(ctx, drivers, dstride, params, pstride, rcorr, rstride, n, out_day, out_night, where, stream);
+                                   float* out_night, float tiny, int where, void* stream) {
+    MOD16_LOCK(ctx);
+    return static_entry<float>(ctx, drivers, dstride, params, pstride, rcorr, rstride, n, out_day, out_night, tiny, where, stream);
 }
 
 // ---------------------- calibration path batched over parameter vectors (N2)
@@ -1365,6 +1499,7 @@ extern "C" int mod16_et_static_batch_f64(mod16_ctx* ctx, const double* const* dr
                                          double* out_total, const double* observed,
                                          const double* weights, double* sse, double* count,
                                          unsigned flags, int where, void* stream) {
+    MOD16_LOCK(ctx);
     return static_batch_entry<double>(ctx, drivers, dstride, n, params, ndraw, out_day, out_night,
                                       out_total, observed, weights, sse, count, flags, where, stream);
 }
@@ -1374,6 +1509,7 @@ extern "C" int mod16_et_static_batch_f32(mod16_ctx* ctx, const float* const* dri
                                          float* out_total, const float* observed,
                                          const float* weights, double* sse, double* count,
                                          unsigned flags, int where, void* stream) {
+    MOD16_LOCK(ctx);
     return static_batch_entry<float>(ctx, drivers, dstride, n, params, ndraw, out_day, out_night,
                                      out_total, observed, weights, sse, count, flags, where, stream);
 }
@@ -1386,10 +1522,17 @@ static int reduce_entry(mod16_ctx* ctx, const T* day, const T* night, int64_t n,
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(kDiagBlocks, (n + kBlock - 1) / kBlock));
-    hipLaunchKernelGGL((diag_partial_kernel<T>), dim3(blocks), dim3(kBlock), 0, st, day, night, n, ctx->diag_partial);
+    DiagWs* ws = nullptr;
+    int rc = reserve_diag(ctx, blocks, &ws);
+    if (rc != MOD16_OK) return rc;
+    rc = ws_acquire(ctx, st);
+    if (rc != MOD16_OK) return rc;
+    hipLaunchKernelGGL((diag_partial_kernel<T>), dim3(blocks), dim3(kBlock), 0, st, day, night, n, ws->partial);
     double* dst = ddiag ? ddiag : ctx->diag_dev;
-    hipLaunchKernelGGL(diag_final_kernel, dim3(1), dim3(kBlock), 0, st, ctx->diag_partial, blocks, dst);
+    hipLaunchKernelGGL(diag_final_kernel, dim3(1), dim3(kBlock), 0, st, ws->partial, blocks, dst);
     HIPCHK(ctx, hipGetLastError());
+    rc = ws_release(ctx, st);
+    if (rc != MOD16_OK) return rc;
     if (diag) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->diag_host, dst, sizeof(double) * kDiag, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
@@ -1400,19 +1543,38 @@ static int reduce_entry(mod16_ctx* ctx, const T* day, const T* night, int64_t n,
 
 extern "C" int mod16_reduce_diag_f64(mod16_ctx* ctx, const double* day, const double* night,
                                      int64_t n, double* diag, double* ddiag, void* stream) {
+    MOD16_LOCK(ctx);
     return reduce_entry<double>(ctx, day, night, n, diag, ddiag, stream);
 }
 extern "C" int mod16_reduce_diag_f32(mod16_ctx* ctx, const float* day, const float* night,
                                      int64_t n, double* diag, double* ddiag, void* stream) {
+    MOD16_LOCK(ctx);
     return reduce_entry<float>(ctx, day, night, n, diag, ddiag, stream);
 }
 
 // ---------------------------------------------------------------- generator
+// tile (pixels) -> log2, or -1 if it is not a power of two >= lo
+static int tile_log2(int64_t tile, int64_t lo) {
+    if (tile < lo || (tile & (tile - 1)) != 0) return -1;
+    int sh = 0;
+    while ((int64_t(1) << sh) < tile) ++sh;
+    return sh;
+}
+
 template <typename T>
 static int synth_entry(mod16_ctx* ctx, uint64_t seed, int64_t step, int64_t pixel_offset,
-                       int64_t n, uint8_t* cls, T* const* drivers, void* stream) {
+                       int64_t n, uint8_t* cls, T* const* drivers, void* stream,
+                       const mod16_layout* lay = nullptr) {
     if (!ctx || !drivers || n < 0) return fail(ctx, MOD16_ERR_ARG, "mod16_synth: bad argument");
     SynthArgs<T> a;
+    a.tile_shift = 62;
+    a.drv_row = a.cls_row = 0;
+    if (lay && lay->tile > 0) {
+        a.tile_shift = tile_log2(lay->tile, 1);
+        if (a.tile_shift < 0) return fail(ctx, MOD16_ERR_ARG, "mod16_synth_tiled: tile must be a power of two");
+        a.drv_row = lay->driver_row;
+        a.cls_row = lay->cls_row;
+    }
     a.cls = cls;
     for (int k = 0; k < 14; ++k) {
         if (!drivers[k]) return fail(ctx, MOD16_ERR_ARG, "mod16_synth: NULL driver array");
@@ -1432,9 +1594,166 @@ static int synth_entry(mod16_ctx* ctx, uint64_t seed, int64_t step, int64_t pixe
 
 extern "C" int mod16_synth_f64(mod16_ctx* ctx, uint64_t seed, int64_t step, int64_t pixel_offset,
                                int64_t n, uint8_t* cls, double* const* drivers, void* stream) {
+    MOD16_LOCK(ctx);
     return synth_entry<double>(ctx, seed, step, pixel_offset, n, cls, drivers, stream);
 }
 extern "C" int mod16_synth_f32(mod16_ctx* ctx, uint64_t seed, int64_t step, int64_t pixel_offset,
                                int64_t n, uint8_t* cls, float* const* drivers, void* stream) {
+    MOD16_LOCK(ctx);
     return synth_entry<float>(ctx, seed, step, pixel_offset, n, cls, drivers, stream);
+}
+
+extern "C" int mod16_synth_tiled_f64(mod16_ctx* ctx, const mod16_layout* layout, uint64_t seed,
+                                     int64_t step, int64_t pixel_offset, int64_t n, uint8_t* cls,
+                                     double* const* drivers, void* stream) {
+    MOD16_LOCK(ctx);
+    return synth_entry<double>(ctx, seed, step, pixel_offset, n, cls, drivers, stream, layout);
+}
+extern "C" int mod16_synth_tiled_f32(mod16_ctx* ctx, const mod16_layout* layout, uint64_t seed,
+                                     int64_t step, int64_t pixel_offset, int64_t n, uint8_t* cls,
+                                     float* const* drivers, void* stream) {
+    MOD16_LOCK(ctx);
+    return synth_entry<float>(ctx, seed, step, pixel_offset, n, cls, drivers, stream, layout);
+}
+
+// ------------------------------------------------ tiled rasters (device resident)
+// The production pipeline on the engine's own raster layout: fields interleaved in
+// tiles ([tile][field][tile pixels]) so that the 16 streams of a wave lie within one
+// ~1 MiB block of HBM instead of 16 places GiB apart (tools/probe_layout.hip: 6.5 TB/s
+// against 5.7 for the same bytes).
+template <typename T>
+static int tiled_entry(mod16_ctx* ctx, const mod16_layout* lay, const uint8_t* cls,
+                       const T* const* drivers, int64_t n, T* out_day, T* out_night,
+                       unsigned flags, double* ddiag, void* stream) {
+    constexpr int V = VecOf<T>::v;
+    if (!ctx) return MOD16_ERR_ARG;
+    if (!lay || !cls || !drivers || !out_day || !out_night || n < 0)
+        return fail(ctx, MOD16_ERR_ARG, "mod16_et_tiled: NULL argument or n < 0");
+    if (!ctx->have_lut) return fail(ctx, MOD16_ERR_NO_BPLUT, "mod16_et_tiled: mod16_set_bplut_f64 was not called");
+    if (flags & MOD16_MATH_EXACT) return fail(ctx, MOD16_ERR_ARG, "mod16_et_tiled: MOD16_MATH_EXACT runs on plain arrays only");
+    const int px_shift = tile_log2(lay->tile, (int64_t)64 * V * kDynRun);
+    if (px_shift < 0) return fail(ctx, MOD16_ERR_ARG, "mod16_et_tiled: tile must be a power of two of at least 8 KiB per field");
+    auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    bool ok = al16(out_day) && al16(out_night) && reinterpret_cast<uintptr_t>(cls) % V == 0 &&
+              lay->driver_row >= lay->tile && lay->out_row >= lay->tile && lay->cls_row >= lay->tile &&
+              lay->driver_row % V == 0 && lay->out_row % V == 0 && lay->cls_row % V == 0 && n % V == 0;
+    for (int k = 0; k < 14 && ok; ++k) ok = drivers[k] && al16(drivers[k]);
+    if (!ok) return fail(ctx, MOD16_ERR_ARG, "mod16_et_tiled: arrays must be 16-byte aligned, rows >= tile and multiples of the vector width, n a multiple of it");
+    if (n == 0) return MOD16_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    StreamArgs<T> s;
+    memset(&s, 0, sizeof s);
+    for (int k = 0; k < 14; ++k) s.wide[k] = drivers[k];
+    s.bytes[0] = cls;
+    s.out[0] = out_day;
+    s.out[1] = out_night;
+    s.n = n;
+    int pv = 0;
+    while ((1 << pv) < 64 * V) ++pv;
+    s.tile_shift = px_shift - pv;             // pieces per tile
+    s.wide_row = lay->driver_row;
+    s.out_row = lay->out_row;
+    s.byte_row = lay->cls_row;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc;
+    if constexpr (std::is_same<T, float>::value) {
+        if (flags & MOD16_MATH_MIXED) rc = launch_stream<T, kStreamTotalsMixed>(ctx, s, st, ddiag);
+        else rc = launch_stream<T, kStreamTotals>(ctx, s, st, ddiag);
+    } else {
+        rc = launch_stream<T, kStreamTotals>(ctx, s, st, ddiag);
+    }
+    if (rc != MOD16_OK) return rc;
+    HIPCHK(ctx, hipGetLastError());
+    return MOD16_OK;
+}
+
+extern "C" int mod16_et_tiled_f64(mod16_ctx* ctx, const mod16_layout* layout, const uint8_t* cls,
+                                  const double* const* drivers, int64_t n, double* out_day,
+                                  double* out_night, unsigned flags, double* ddiag, void* stream) {
+    MOD16_LOCK(ctx);
+    return tiled_entry<double>(ctx, layout, cls, drivers, n, out_day, out_night, flags, ddiag, stream);
+}
+extern "C" int mod16_et_tiled_f32(mod16_ctx* ctx, const mod16_layout* layout, const uint8_t* cls,
+                                  const float* const* drivers, int64_t n, float* out_day,
+                                  float* out_night, unsigned flags, double* ddiag, void* stream) {
+    MOD16_LOCK(ctx);
+    return tiled_entry<float>(ctx, layout, cls, drivers, n, out_day, out_night, flags, ddiag, stream);
+}
+
+template <typename T>
+static int graph_tiled_entry(mod16_ctx* ctx, const mod16_layout* lay, const uint8_t* cls,
+                             const T* const* drivers, int64_t n, T* out_day, T* out_night,
+                             unsigned flags, double* ddiag, mod16_graph** out) {
+    if (!ctx || !out) return MOD16_ERR_ARG;
+    *out = nullptr;
+    if (!lay || !ddiag) return fail(ctx, MOD16_ERR_ARG, "mod16_graph_et_tiled: layout and ddiag are required");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->streams[0]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking));
+    hipStream_t st = ctx->streams[0];
+    mod16_graph* g = new (std::nothrow) mod16_graph;
+    if (!g) return MOD16_ERR_NOMEM;
+    g->ctx = ctx;
+    g->device = ctx->device;
+    int rc = [&]() -> int {
+        HIPCHK(ctx, hipMalloc(&g->counter, 128));
+        ctx->force_counter = g->counter;
+        int pv = 0, tsh = lay->tile > 0 ? tile_log2(lay->tile, 1) : -1;
+        while ((1 << pv) < 64 * VecOf<T>::v) ++pv;
+        if (tsh < pv) return fail(ctx, MOD16_ERR_ARG, "mod16_graph_et_tiled: bad tile");
+        g->ws.capacity = std::max<int64_t>(kDiagBlocks, stream_geom(ctx, std::max<int64_t>(n, 0), VecOf<T>::v, tsh - pv).nruns + kStage);
+        HIPCHK(ctx, hipMalloc(&g->ws.partial, sizeof(double) * g->ws.capacity * kDiag));
+        ctx->force_ws = &g->ws;
+        int r = tiled_entry<T>(ctx, lay, cls, drivers, n, out_day, out_night, flags, ddiag, st);
+        if (r != MOD16_OK) return r;
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        r = tiled_entry<T>(ctx, lay, cls, drivers, n, out_day, out_night, flags, ddiag, st);
+        hipError_t e = hipStreamEndCapture(st, &g->graph);
+        if (r != MOD16_OK) return r;
+        HIPCHK(ctx, e);
+        HIPCHK(ctx, hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
+        return MOD16_OK;
+    }();
+    ctx->force_counter = nullptr;
+    ctx->force_ws = nullptr;
+    if (rc != MOD16_OK) {
+        mod16_graph_destroy(g);
+        return rc;
+    }
+    *out = g;
+    return MOD16_OK;
+}
+
+extern "C" int mod16_graph_et_tiled_f64(mod16_ctx* ctx, const mod16_layout* layout, const uint8_t* cls,
+                                        const double* const* drivers, int64_t n, double* out_day,
+                                        double* out_night, unsigned flags, double* ddiag,
+                                        mod16_graph** out) {
+    MOD16_LOCK(ctx);
+    return graph_tiled_entry<double>(ctx, layout, cls, drivers, n, out_day, out_night, flags, ddiag, out);
+}
+extern "C" int mod16_graph_et_tiled_f32(mod16_ctx* ctx, const mod16_layout* layout, const uint8_t* cls,
+                                        const float* const* drivers, int64_t n, float* out_day,
+                                        float* out_night, unsigned flags, double* ddiag,
+                                        mod16_graph** out) {
+    MOD16_LOCK(ctx);
+    return graph_tiled_entry<float>(ctx, layout, cls, drivers, n, out_day, out_night, flags, ddiag, out);
+}
+
+// mean milliseconds per replay of a captured step, HIP events on `stream`
+extern "C" int mod16_time_graph(mod16_graph* g, int launches, void* stream, float* ms) {
+    if (!g || !g->exec || !ms || launches <= 0) return MOD16_ERR_ARG;
+    if (hipSetDevice(g->device) != hipSuccess) return MOD16_ERR_HIP;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return MOD16_ERR_HIP;
+    bool ok = hipEventRecord(e0, st) == hipSuccess;
+    for (int i = 0; i < launches && ok; ++i) ok = hipGraphLaunch(g->exec, st) == hipSuccess;
+    ok = ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+    float t = 0.f;
+    ok = ok && hipEventElapsedTime(&t, e0, e1) == hipSuccess;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (!ok) return MOD16_ERR_HIP;
+    *ms = t / (float)launches;
+    return MOD16_OK;
 }

@@ -311,6 +311,16 @@ __global__ void __launch_bounds__(kFinalBlock) diag_final_fused_kernel(const dou
     }
 }
 
+// ------------------------------------------------------- copy (measurement aid)
+// One-shot 16-byte-per-lane copy, the reference point "measured copy bandwidth"
+// of SURVEY.md section 8d next to the 8 TB/s nominal peak (mod16_measure_copy).
+typedef float copy_vec_t __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(kBlock) copy_kernel(const copy_vec_t* __restrict__ src,
+                                                      copy_vec_t* __restrict__ dst, int64_t nvec) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < nvec) dst[i] = src[i];
+}
+
 // --------------------------------------------------------- synthetic fields
 // Counter-based generator: value = f(seed, step,
 // variable, global pixel index) through a splitmix64 finaliser, so a raster
@@ -331,6 +341,10 @@ template <typename T> struct SynthArgs {
     T* drv[14];
     uint64_t seed;
     int64_t step, offset, n;
+    // tiled rasters: element index of pixel i = (i >> tile_shift) * row + (i & (2^tile_shift - 1));
+    // plain arrays: tile_shift = 62 (one tile)
+    int tile_shift;
+    int64_t drv_row, cls_row;
 };
 
 template <typename T>
@@ -358,21 +372,23 @@ __global__ void __launch_bounds__(kBlock) synth_kernel(const SynthArgs<T> a) {
         unsigned c = (unsigned)(u01(a.seed, 0, 16, pix) * 11.0) % 11u + 1u;   // 1..11
         c = (c == 11u) ? 12u : c;                  // PFT_VALID = 1..10, 12
         c = (rc < 0.01) ? 0u : ((rc < 0.02) ? 11u : c);
-        if (a.cls) a.cls[i] = (uint8_t)c;
-        a.drv[0][i] = (T)U(6, -100.0, 0.0);        // lw_net_day
-        a.drv[1][i] = (T)U(7, -50.0, 0.0);         // lw_net_night
-        a.drv[2][i] = (T)U(8, 0.0, 360.0);         // sw_rad_day
-        a.drv[3][i] = (T)0;                        // sw_rad_night
-        a.drv[4][i] = (T)U(9, 0.1, 0.22);          // sw_albedo
-        a.drv[5][i] = (T)t_d;
-        a.drv[6][i] = (T)t_n;
-        a.drv[7][i] = (T)t_ann;
-        a.drv[8][i] = (T)tmin;
-        a.drv[9][i] = (T)vpd_d;
-        a.drv[10][i] = (T)vpd_n;
-        a.drv[11][i] = (T)U(10, 70000.0, 101340.0);  // pressure
-        a.drv[12][i] = (T)fpar;
-        a.drv[13][i] = (T)lai;
+        const int64_t tile = i >> a.tile_shift, within = i - (tile << a.tile_shift);
+        const int64_t e = tile * a.drv_row + within;
+        if (a.cls) a.cls[tile * a.cls_row + within] = (uint8_t)c;
+        a.drv[0][e] = (T)U(6, -100.0, 0.0);        // lw_net_day
+        a.drv[1][e] = (T)U(7, -50.0, 0.0);         // lw_net_night
+        a.drv[2][e] = (T)U(8, 0.0, 360.0);         // sw_rad_day
+        a.drv[3][e] = (T)0;                        // sw_rad_night
+        a.drv[4][e] = (T)U(9, 0.1, 0.22);          // sw_albedo
+        a.drv[5][e] = (T)t_d;
+        a.drv[6][e] = (T)t_n;
+        a.drv[7][e] = (T)t_ann;
+        a.drv[8][e] = (T)tmin;
+        a.drv[9][e] = (T)vpd_d;
+        a.drv[10][e] = (T)vpd_n;
+        a.drv[11][e] = (T)U(10, 70000.0, 101340.0);  // pressure
+        a.drv[12][e] = (T)fpar;
+        a.drv[13][e] = (T)lai;
     }
 }
 

@@ -20,6 +20,7 @@ template <typename T> struct MethodArgs {
     uint32_t dense_in, present_in, dense_par;
     int method;
     T alpha;
+    T tiny;                  // the reference's `tiny` argument (:869, :1157), default 1e-7
 };
 
 // Input slots per method (order of the reference signatures; "?" = optional,
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(kBlock) method_kernel(const MethodArgs<T> a) {
                 T pa = in(0), t = in(1), vpd = in(2);
                 T rh = rh_or(7, t, vpd);
                 o0 = wet_canopy_exact(p, pa, t, vpd, in(3), in(4), in(5), lhv_or(6, t), rh,
-                                      fwet_or(8, rh));
+                                      fwet_or(8, rh), a.tiny);
                 break;
             }
             case 13: {
@@ -123,8 +124,8 @@ __global__ void __launch_bounds__(kBlock) method_kernel(const MethodArgs<T> a) {
                 T rh = rh_or(9, t, vpd);
                 T rc = rcorr_or(7, pa, t), lhv = lhv_or(8, t), fw = fwet_or(10, rh);
                 o0 = (a.method == 16)
-                         ? transpiration_exact<T, true>(p, pa, t, vpd, in(3), in(4), in(5), in(6), rc, lhv, rh, fw)
-                         : transpiration_exact<T, false>(p, pa, t, vpd, in(3), in(4), in(5), in(6), rc, lhv, rh, fw);
+                         ? transpiration_exact<T, true>(p, pa, t, vpd, in(3), in(4), in(5), in(6), rc, lhv, rh, fw, a.tiny)
+                         : transpiration_exact<T, false>(p, pa, t, vpd, in(3), in(4), in(5), in(6), rc, lhv, rh, fw, a.tiny);
                 break;
             }
             default: break;
@@ -143,6 +144,7 @@ template <typename T> struct StaticArgs {
     int64_t n;
     uint32_t dense_drv, dense_par, dense_rc;
     unsigned* flag;          // device word: bit 0 = any(g_surf > 0) in the day period
+    T tiny;                  // the reference's `tiny` argument (:199), default 1e-7
 };
 
 template <typename T>
@@ -184,7 +186,7 @@ __global__ void __launch_bounds__(kBlock) static_kernel(const StaticArgs<T> a) {
         T rc_d = has_rc ? (((a.dense_rc >> 0) & 1u) ? a.rc[0][i] : a.rc[0][0]) : T(0);
         T rc_n = has_rc ? (((a.dense_rc >> 1) & 1u) ? a.rc[1][i] : a.rc[1][0]) : T(0);
         T day, night;
-        et_static_pixel(x, p, has_rc, rc_d, rc_n, any_gs, day, night);
+        et_static_pixel(x, p, has_rc, rc_d, rc_n, any_gs, day, night, a.tiny);
         a.out[0][i] = day;
         a.out[1][i] = night;
     }

@@ -124,9 +124,9 @@ __device__ __forceinline__ void rad_soil_exact(const PixelIn<T>& x, const ClassP
 // evaporation_wet_canopy, :866-961
 template <typename T>
 __device__ __forceinline__ T wet_canopy_exact(const ClassPar<T>& p, T pa, T t, T vpd, T lai,
-                                              T fpar, T rad_canopy, T lhv, T rh, T fwet) {
+                                              T fpar, T rad_canopy, T lhv, T rh, T fwet,
+                                              T tiny = K<T>::tiny) {
 #pragma clang fp contract(off)
-    const T tiny = K<T>::tiny;
     fwet = (fwet == T(0)) ? fwet + tiny : fwet;                   // :934-935
     lai = (lai == T(0)) ? lai + tiny : lai;
     T s = svp_slope_exact(t);
@@ -237,9 +237,8 @@ template <typename T> __device__ __forceinline__ T ramp_down_exact(T x, T lo, T 
 template <typename T, bool DAY>
 __device__ __forceinline__ T transpiration_exact(const ClassPar<T>& p, T pa, T t, T vpd, T lai,
                                                  T fpar, T rad_canopy, T tmin, T r_corr,
-                                                 T lhv, T rh, T fwet) {
+                                                 T lhv, T rh, T fwet, T tiny = K<T>::tiny) {
 #pragma clang fp contract(off)
-    const T tiny = K<T>::tiny;
     T s = svp_slope_exact(t);
     T rho = rho_exact(t, pa, rh);
     T gamma = gamma_exact(pa, t);
@@ -329,9 +328,8 @@ __device__ __forceinline__ T gsurf_static(const ClassPar<T>& p, T tmin, T vpd) {
 template <typename T, bool DAY>
 __device__ __forceinline__ T period_static(const PixelIn<T>& x, const ClassPar<T>& p, T t, T vpd,
                                            T sw, T lw, T rad_soil, bool has_rc, T rc_in,
-                                           bool any_gs) {
+                                           bool any_gs, T tiny = K<T>::tiny) {
 #pragma clang fp contract(off)
-    const T tiny = K<T>::tiny;
     T rad_net = sw * (T(1) - x.alb) + lw;                          // :272-274
     T rad_c = x.fpar * rad_net;
     T sv = svp_exact(t);
@@ -380,7 +378,7 @@ __device__ __forceinline__ T period_static(const PixelIn<T>& x, const ClassPar<T
 template <typename T>
 __device__ __forceinline__ void et_static_pixel(const PixelIn<T>& x, const ClassPar<T>& p,
                                                 bool has_rc, T rc_d, T rc_n, bool any_gs_day,
-                                                T& day, T& night) {
+                                                T& day, T& night, T tiny = K<T>::tiny) {
 #pragma clang fp contract(off)
     T a_d = x.sw_d * (T(1) - x.alb) + x.lw_d;                      // :225-226
     T a_n = x.lw_n;
@@ -394,9 +392,9 @@ __device__ __forceinline__ void et_static_pixel(const PixelIn<T>& x, const Class
     g_n = ((a_d > T(0)) && ((a_n - g_n) < (T(-0.5) * a_d))) ? a_n + (T(0.5) * a_d) : g_n;
     T rs_d = (T(1) - x.fpar) * (a_d - g_d);
     T rs_n = (T(1) - x.fpar) * (a_n - g_n);
-    day = period_static<T, true>(x, p, x.t_d, x.vpd_d, x.sw_d, x.lw_d, rs_d, has_rc, rc_d, any_gs_day);
+    day = period_static<T, true>(x, p, x.t_d, x.vpd_d, x.sw_d, x.lw_d, rs_d, has_rc, rc_d, any_gs_day, tiny);
     // at night g_surf = 0 / r_corr, so any(g_surf > 0) is False: t = 0 (:343-348)
-    night = period_static<T, false>(x, p, x.t_n, x.vpd_n, x.sw_n, x.lw_n, rs_n, has_rc, rc_n, false);
+    night = period_static<T, false>(x, p, x.t_n, x.vpd_n, x.sw_n, x.lw_n, rs_n, has_rc, rc_n, false, tiny);
 }
 
 // ---- static path, strength-reduced and split for batching over parameter

@@ -95,7 +95,15 @@ template <typename T> struct StreamArgs {
     int64_t wide_pitch;        // PITCHED: wide[k] = wide[0] + k * wide_pitch (elements)
     int run_shift;             // a run is 2^run_shift pieces (kDynRun for large rasters, less for
                                // small ones so that every wave of the chip gets work)
+    // Tiled rasters (2-level layout): pixel i of an array lives at
+    // base[(i >> log2 tile) * row + (i & (tile - 1))]. tile_shift = log2 of the PIECES
+    // per tile (a piece = 64 vectors of 16 B); plain arrays: tile_shift = kNoTile, rows unused.
+    int tile_shift;
+    int64_t wide_row;          // elements between successive tiles of a wide array
+    int64_t out_row;           // ... of an output array
+    int64_t byte_row;          // bytes between successive tiles of a byte array
 };
+constexpr int kNoTile = 40;    // more pieces per "tile" than any raster has: one tile, plain arrays
 static_assert(__builtin_offsetof(StreamArgs<double>, wide) == 0 &&
               __builtin_offsetof(StreamArgs<double>, bytes) == 128 &&
               __builtin_offsetof(StreamArgs<float>, wide) == 0 &&
@@ -185,11 +193,19 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
     unsigned long long ticket = 0;
     int run = 0;
     auto vec_of = [&](int64_t cb, int r) { return (cb + r) * 64 + lane; };
-    auto first_of = [&](int64_t cb, int r) {
-        const int64_t f = (cb + r) * (int64_t)(64 * V);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)f);
-        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)f >> 32));
+    // element offsets of the piece (cb, r) in the wide arrays, the outputs and the byte
+    // arrays (wave-uniform, forced into SGPRs)
+    struct Offs { int64_t w, o, b; };
+    auto uniform64 = [](int64_t x) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)x >> 32));
         return (int64_t)(((unsigned long long)hi << 32) | lo);
+    };
+    auto offs_of = [&](int64_t cb, int r) {
+        const int64_t piece = uniform64(cb + r);
+        const int64_t tile = piece >> a.tile_shift;
+        const int64_t q = (piece - (tile << a.tile_shift)) * (int64_t)(64 * V);
+        return Offs{tile * a.wide_row + q, tile * a.out_row + q, tile * a.byte_row + q};
     };
     const unsigned lane_elem = (unsigned)lane * (unsigned)V;
     auto advance = [&](int64_t& cb, int& r) {
@@ -214,12 +230,13 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
         for (int k = 0; k < NB; ++k)
             p.b[k] = *reinterpret_cast<const char* const __attribute__((address_space(4)))*>(ka + 128 + 8 * k);
     };
-    auto issue = [&](int64_t first, const Ptrs& p) {
+    auto issue = [&](const Offs& of, const Ptrs& p) {
         unsigned lb = lane_elem * (unsigned)sizeof(T);
         unsigned wl = (unsigned)(uintptr_t)(lptr_t)ws;
         asm volatile("" : "+v"(lb));
         asm volatile("" : "+s"(wl));
-        const int64_t first_b = first * (int64_t)sizeof(T);
+        const int64_t first_b = of.w * (int64_t)sizeof(T);
+        const int64_t first = of.b;
         if constexpr (PITCHED) {
             int64_t pitch_b = a.wide_pitch * (int64_t)sizeof(T);
             asm volatile("" : "+s"(pitch_b));     // opaque: keeps 14 addresses from being hoisted
@@ -249,7 +266,7 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
     {
         Ptrs p;
         load_ptrs(p);
-        if (v < nvec) issue(first_of(cbase, run), p);
+        if (v < nvec) issue(offs_of(cbase, run), p);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     bool flushed = false;
@@ -282,7 +299,7 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
         int run_n = run;
         advance(cb_n, run_n);
         const int64_t vn = vec_of(cb_n, run_n);
-        if (vn < nvec) issue(first_of(cb_n, run_n), ptrs);
+        if (vn < nvec) issue(offs_of(cb_n, run_n), ptrs);
         asm volatile("" ::: "memory");
 
         if (v < nvec) {   // only the last piece is ragged
@@ -425,7 +442,7 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
                 }
             }
             }
-            const int64_t first = first_of(cbase, run);
+            const int64_t first = offs_of(cbase, run).o;
 #pragma unroll
             for (int k = 0; k < NOUT; ++k)
                 __builtin_nontemporal_store(res[k], reinterpret_cast<VT*>((a.out[k] + first) + lane_elem));

@@ -41,6 +41,95 @@ class _GraphHandle(object):
             pass
 
 
+class TiledRaster(object):
+    '''
+    A raster resident on the device in the engine's own layout (``mod16_layout``
+    in include/mod16_hip.h): the pixels are cut into tiles of ``tile`` pixels and
+    the 14 driver arrays interleaved tile by tile -- ``[tile][driver][tile
+    pixels]`` -- the two outputs likewise in a block of their own, the class
+    raster as plain bytes. Every array is still an array: ``drivers[k]``, ``day``,
+    ``night`` and ``cls`` are 2-D strided ``torch`` views of shape ``(ntiles,
+    tile)`` into one allocation, so ``drivers[5].copy_(temp.view(-1, tile))``,
+    slicing and reductions work as on any tensor. Why: streamed side by side, 16
+    separate 7 GB arrays lie GiB apart in HBM and the kernel's 14-read + 2-write
+    mix reaches 5.7 TB/s; with the fields of a tile inside one ~1 MiB block the
+    same bytes move at 6.5 TB/s (``tools/probe_layout.hip``).
+    The storage is padded to whole tiles; ``n`` is the number of real pixels.
+    '''
+
+    def __init__(self, engine, n, tile=None):
+        torch = _torch()
+        esz = engine.np_dtype.itemsize
+        self.n = int(n)
+        self.tile = int(tile) if tile else engine.TILE_BYTES // esz
+        if self.tile & (self.tile - 1) or self.tile * esz < 8192:
+            raise ValueError('tile must be a power of two of at least 8 KiB per field')
+        vec = 16 // esz
+        if self.n % vec:
+            raise ValueError('a tiled raster holds a multiple of %d pixels' % vec)
+        self.ntiles = max(1, -(-self.n // self.tile))
+        P, nt = self.tile, self.ntiles
+        in_bytes, out_bytes = nt * 14 * P * esz, nt * 2 * P * esz
+        self.slab = torch.empty(in_bytes + out_bytes + nt * P + 4096, dtype=torch.uint8,
+                                device=engine._dev())
+        wide = self.slab[:in_bytes].view(engine.dtype).view(nt, 14, P)
+        self.drivers = [wide[:, k, :] for k in range(14)]
+        outs = self.slab[in_bytes:in_bytes + out_bytes].view(engine.dtype).view(nt, 2, P)
+        self.day, self.night = outs[:, 0, :], outs[:, 1, :]
+        self.cls = self.slab[in_bytes + out_bytes:in_bytes + out_bytes + nt * P].view(nt, P)
+        self.layout = _lib.Layout(P, 14 * P, 2 * P, P)
+        self.dtype = engine.dtype
+
+    def flat(self, field, lo=0, hi=None):
+        '''Pixels [lo, hi) of one array of the raster as a contiguous 1-D
+        tensor (a copy; only the tiles it touches are read).'''
+        hi = self.n if hi is None else hi
+        P = self.tile
+        t0, t1 = lo // P, -(-hi // P)
+        return field[t0:t1].reshape(-1)[lo - t0 * P:hi - t0 * P]
+
+    def put(self, field, src, lo=0):
+        '''Write the 1-D tensor ``src`` into pixels [lo, lo + len(src)) of one
+        array of the raster.'''
+        P = self.tile
+        pos, end = lo, lo + src.numel()
+        while pos < end:                       # head, whole tiles at once, tail
+            t, w = divmod(pos, P)
+            if w == 0 and end - pos >= P:
+                k = (end - pos) // P
+                field[t:t + k].copy_(src[pos - lo:pos - lo + k * P].view(k, P))
+                pos += k * P
+            else:
+                m = min(P - w, end - pos)
+                field[t, w:w + m].copy_(src[pos - lo:pos - lo + m])
+                pos += m
+
+
+class BoundStep(object):
+    '''A pre-marshalled step (see ``RasterEngine.bind`` / ``bind_tiled``):
+    calling it enqueues the step on the current stream.'''
+
+    def __init__(self, launch, outputs, graph=None, device=0):
+        self._launch, self.outputs, self._graph, self._device = launch, outputs, graph, device
+
+    def __call__(self):
+        self._launch()
+        return self.outputs
+
+    def time(self, launches=10):
+        '''Mean milliseconds per replay of the captured step, HIP events on
+        the current stream (``mod16_time_graph``).'''
+        if self._graph is None:
+            raise RuntimeError('only a step bound as a HIP graph can be timed this way')
+        torch = _torch()
+        ms = C.c_float(0)
+        rc = self._graph.lib.mod16_time_graph(
+            self._graph.handle, int(launches),
+            C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream), C.byref(ms))
+        self._graph.ctx.check(rc)
+        return ms.value
+
+
 class RasterEngine(object):
     '''
     Parameters
@@ -62,12 +151,18 @@ class RasterEngine(object):
             raise _lib.Mod16Error(
                 _lib.ERR_NO_DEVICE, 'RasterEngine needs an MI355X; there is no CPU fallback')
         self.device = torch.cuda.current_device() if device is None else int(device)
-        self.ctx = _lib.context(self.device)
+        # a context of its own: the BPLUT set here is what this engine's launches
+        # (and the graphs bound from it) read at run time, whatever table other
+        # engines or the numpy entry points of the process use meanwhile
+        self.ctx = _lib.Context(self.device)
         self.ctx.set_bplut(table)
         self.np_dtype = np.dtype(dtype)
         self.dtype = {'float64': torch.float64, 'float32': torch.float32}[self.np_dtype.name]
         self.math = math
         self.bytes_per_pixel = BYTES_PER_PIXEL[self.np_dtype.name]
+
+    #: bytes of one field per tile of a ``TiledRaster`` (16-64 KiB measured: 32 KiB best)
+    TILE_BYTES = 32 * 1024
 
     # ---------------------------------------------------------- helpers
     def _dev(self):
@@ -258,7 +353,10 @@ class RasterEngine(object):
         hand-off are what a real ingest would use. Returns ``(diag, day,
         night)``: the [steps, 8] diagnostics series and the outputs of the
         last step. ``on_step(s, day, night)`` is called (compute stream
-        current) after step s has been enqueued, e.g. to accumulate.'''
+        current) after step s has been enqueued, e.g. to accumulate; what it
+        enqueues on the compute stream may read the outputs and the ring slot
+        of step s (``buffers['ring'][s % 2]``), which is handed back to the
+        ingest stream only behind it.'''
         torch = _torch()
         dev = self._dev()
         compute = torch.cuda.current_stream(self.device)
@@ -285,9 +383,9 @@ class RasterEngine(object):
             compute.wait_event(filled[s])
             day, night = outs[s % 2]
             self.run(cls, ring[s % 2], day, night, diag=diag[s])
-            consumed[s].record(compute)
             if on_step is not None:
                 on_step(s, day, night)
+            consumed[s].record(compute)     # behind on_step: it may still read the slot
             if s + 2 < steps:
                 produce(s + 2)
         compute.wait_stream(ingest)
@@ -358,8 +456,9 @@ class RasterEngine(object):
 
                 def launch():
                     check(lib.mod16_graph_launch(owner.handle, torch.cuda.current_stream(device).cuda_stream))
-                    return keepalive[2], keepalive[3]
-                return launch
+                step = BoundStep(launch, (keepalive[2], keepalive[3]), owner, device)
+                step._keep = keepalive
+                return step
             if rc != _lib.ERR_HIP:      # argument errors are the caller's; a refused capture is not
                 check(rc)
             import warnings
@@ -369,8 +468,116 @@ class RasterEngine(object):
 
         def launch():
             check(fn(*args, torch.cuda.current_stream(device).cuda_stream))
-            return keepalive[2], keepalive[3]
-        return launch
+        step = BoundStep(launch, (keepalive[2], keepalive[3]), None, device)
+        step._keep = keepalive
+        return step
+
+    # ------------------------------------------------------ tiled rasters
+    def alloc_tiled(self, n, tile=None):
+        '''A ``TiledRaster`` for n pixels (``tile`` pixels per tile, default
+        ``TILE_BYTES`` per field).'''
+        return TiledRaster(self, n, tile)
+
+    def _tiled_args(self, r):
+        return (C.byref(r.layout), r.cls.data_ptr(),
+                _lib.ptr_array([d.data_ptr() for d in r.drivers]), r.n,
+                r.day.data_ptr(), r.night.data_ptr(), int(self.math))
+
+    def synth_tiled(self, r, seed=16, step=0, pixel_offset=0):
+        '''The synthetic drivers of ``synth`` written straight into the tiled
+        raster ``r`` (``mod16_synth_tiled_*``): same field, pixel for pixel.'''
+        fn = self.ctx.lib.mod16_synth_tiled_f32 if self.np_dtype == np.float32 \
+            else self.ctx.lib.mod16_synth_tiled_f64
+        self.ctx.check(fn(
+            self.ctx.handle, C.byref(r.layout), int(seed), int(step), int(pixel_offset), r.n,
+            r.cls.data_ptr(), _lib.ptr_array([d.data_ptr() for d in r.drivers]), self._stream()))
+        return r
+
+    def to_tiled(self, cls, drivers, r=None):
+        '''Copy plain device arrays (class raster + 14 drivers, 1-D tensors)
+        into a tiled raster (one strided copy per array).'''
+        n = cls.numel()
+        r = r or self.alloc_tiled(n)
+        r.put(r.cls, cls)
+        for k in range(14):
+            r.put(r.drivers[k], drivers[k])
+        return r
+
+    def run_tiled(self, r, diag=None):
+        '''The fused ET kernel over a tiled raster (``mod16_et_tiled_*``),
+        asynchronous on the current stream; outputs in ``r.day`` / ``r.night``,
+        with ``diag`` (float64 tensor of 8 on the device) the diagnostics too.'''
+        torch = _torch()
+        fn = self.ctx.lib.mod16_et_tiled_f32 if self.np_dtype == np.float32 \
+            else self.ctx.lib.mod16_et_tiled_f64
+        dptr = self._check_tensor(diag, torch.float64, 8, 'diag') if diag is not None else None
+        self.ctx.check(fn(self.ctx.handle, *self._tiled_args(r), dptr, self._stream()))
+        return r.day, r.night
+
+    def bind_tiled(self, r, diag):
+        '''``run_tiled(r, diag)`` captured once into a HIP graph
+        (``mod16_graph_et_tiled_*``); the returned ``BoundStep`` replays it with
+        one library call and can time itself.'''
+        torch = _torch()
+        handle = C.c_void_p()
+        lib, check, device = self.ctx.lib, self.ctx.check, self.device
+        make = lib.mod16_graph_et_tiled_f32 if self.np_dtype == np.float32 \
+            else lib.mod16_graph_et_tiled_f64
+        check(make(self.ctx.handle, *self._tiled_args(r),
+                   self._check_tensor(diag, torch.float64, 8, 'diag'), C.byref(handle)))
+        owner = _GraphHandle(lib, handle, self.ctx)
+        keep = (r, diag)
+
+        def launch():
+            check(lib.mod16_graph_launch(owner.handle, torch.cuda.current_stream(device).cuda_stream))
+        step = BoundStep(launch, (r.day, r.night), owner, device)
+        step._keep = keep
+        return step
+
+    def run_series_tiled(self, n, steps, seed=16, pixel_offset=0, on_step=None, ring=None):
+        '''``run_series`` on tiled rasters: a ring of two ``TiledRaster`` slots,
+        the drivers of step s + 1 produced on a second stream while the kernel
+        works on step s. Returns ``(diag, raster of the last step)``.'''
+        torch = _torch()
+        dev = self._dev()
+        compute = torch.cuda.current_stream(self.device)
+        ingest = torch.cuda.Stream(device=dev)
+        ring = ring or [self.alloc_tiled(n), self.alloc_tiled(n)]
+        diag = torch.zeros(steps, 8, dtype=torch.float64, device=dev)
+        filled = [torch.cuda.Event() for _ in range(steps)]
+        consumed = [torch.cuda.Event() for _ in range(steps)]
+        ingest.wait_stream(compute)
+
+        def produce(s):
+            with torch.cuda.stream(ingest):
+                if s >= 2:
+                    ingest.wait_event(consumed[s - 2])
+                self.synth_tiled(ring[s % 2], seed=seed, step=s, pixel_offset=pixel_offset)
+                filled[s].record(ingest)
+
+        for s in range(min(2, steps)):
+            produce(s)
+        last = None
+        for s in range(steps):
+            compute.wait_event(filled[s])
+            last = ring[s % 2]
+            self.run_tiled(last, diag=diag[s])
+            if on_step is not None:
+                on_step(s, last)
+            consumed[s].record(compute)
+            if s + 2 < steps:
+                produce(s + 2)
+        compute.wait_stream(ingest)
+        return diag, last
+
+    def measure_copy(self, nbytes=4 << 30, reps=3):
+        '''GB/s of a plain device-to-device copy kernel on this GPU
+        (``mod16_measure_copy``): the measured reference point next to the
+        nominal HBM peak.'''
+        gbps = C.c_float(0)
+        self.ctx.check(self.ctx.lib.mod16_measure_copy(self.ctx.handle, int(nbytes), int(reps),
+                                                       C.byref(gbps)))
+        return gbps.value
 
     def check(self):
         '''Synchronise and raise deferred errors (IndexError for a class code

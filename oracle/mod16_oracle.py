@@ -314,6 +314,14 @@ def potential_transpiration(lw_net, sw_rad, sw_albedo, pressure, temp_k, vpd,
     return (alpha * (s * rad_canopy) * (1 - f_wet)) / (s + gamma)
 
 
+def radiation_net(sw_rad, sw_albedo, temp_k):
+    """radiation_net (DEPRECATED in the reference), mod16/__init__.py:1293-1337"""
+    emis_surface = 0.97
+    emis_atmos = 1 - 0.26 * np.exp(-7.77e-4 * np.power(temp_k - 273.15, 2))
+    return sw_rad * (1 - sw_albedo) + \
+        STEFAN_BOLTZMANN * (emis_atmos - emis_surface) * np.power(temp_k, 4)
+
+
 def potential_et(p, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
                  sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
                  vpd_night, pressure, fpar, lai):

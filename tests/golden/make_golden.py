@@ -53,8 +53,102 @@ def pack_sep(result):
                 canopy_night=c_n, soil_night=s_n, trans_night=t_n)
 
 
+def make_f9(ref):
+    """F9 (round 2): vectors the first set did not hold -- written by
+    ``make_golden.py --f9`` alone so that the files of F1-F8 stay byte for byte
+    what they were.
+
+    * ``MOD16.potential_transpiration`` (:546-602, default and another alpha,
+      with and without the optional rhumidity / f_wet) and the deprecated
+      ``radiation_net`` (:1293-1337);
+    * ``evaporation_wet_canopy`` / ``transpiration`` / ``_evapotranspiration``
+      with ``tiny`` other than 1e-7 (:869, :1157, :199), on inputs with lai = 0
+      and wet fractions that are exactly 0 or below the new ``tiny``;
+    * the (N,)-against-(T, N) broadcast of the forward-run notebook (cell 17):
+      per-site ``pressure`` / ``temp_annual`` rows, a scalar ``sw_rad_night``
+      and a (T, 1) column against (T, N) drivers, through
+      ``MOD16.evapotranspiration`` with per-site (N,) parameter arrays.
+    """
+    MOD16 = ref.MOD16
+    names = list(MOD16.required_parameters)
+    data_dir = os.path.join(REFERENCE, 'mod16', 'data')
+    c51 = 'MOD16_BPLUT_C5.1_05deg_MCD43B_Albedo_MERRA_GMAO.csv'
+    bplut = ref.utils.restore_bplut(os.path.join(data_dir, c51))
+    bplut['beta'] = np.where(np.isnan(bplut['tmin_close']), np.nan, 250.0)
+    p2 = {k: bplut[k][7] for k in names}
+    m2 = MOD16(p2)
+    _, drv = synth.drivers((256,), seed=9, special=False)
+    (lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_a, tmin_, vpd_d, vpd_n, pa,
+     fpar_, lai_) = drv
+    lai_ = lai_.copy()
+    lai_[:8] = 0.0
+    lai_[8:16] = 5e-4            # below tiny = 1e-3, above the default
+    vpd_d = vpd_d.copy()
+    vpd_d[16:24] = 0.0           # rh = 1 -> f_wet = 1 -> (1 - f_wet) = 0
+    f9 = dict(params=np.array([p2[k] for k in names], float),
+              drivers=np.stack([lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_a, tmin_,
+                                vpd_d, vpd_n, pa, fpar_, lai_]))
+    rh = MOD16.rhumidity(t_d, vpd_d)
+    fw = np.where(rh < 0.7, 0.0, rh ** 4)
+    f9['rhumidity'], f9['f_wet'] = rh, fw
+    f9['potential_transpiration'] = MOD16.potential_transpiration(
+        lw_d, sw_d, alb, pa, t_d, vpd_d, fpar_)
+    f9['potential_transpiration_alpha1'] = MOD16.potential_transpiration(
+        lw_d, sw_d, alb, pa, t_d, vpd_d, fpar_, alpha=1.0)
+    f9['potential_transpiration_given'] = MOD16.potential_transpiration(
+        lw_d, sw_d, alb, pa, t_d, vpd_d, fpar_, rhumidity=rh, f_wet=fw)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        f9['radiation_net'] = ref.radiation_net(sw_d, alb, t_d)
+        rad_c = fpar_ * (sw_d * (1 - alb) + lw_d)
+        f9['rad_canopy'] = rad_c
+        for tag, tiny in (('1e-3', 1e-3), ('1e-12', 1e-12)):
+            f9['wet_canopy_tiny_' + tag] = m2.evaporation_wet_canopy(
+                pa, t_d, vpd_d, lai_, fpar_, rad_c, tiny=tiny)
+            f9['transpiration_day_tiny_' + tag] = m2.transpiration(
+                pa, t_d, vpd_d, lai_, fpar_, rad_c, tmin_, daytime=True, tiny=tiny)
+            f9['transpiration_night_tiny_' + tag] = m2.transpiration(
+                pa, t_n, vpd_n, lai_, fpar_, fpar_ * lw_n, tmin_, daytime=False, tiny=tiny)
+        # the calibration path with another tiny
+        T_, N_ = 6, 24
+        cls7, drv7 = synth.drivers((T_, N_), seed=19, special=False)
+        site_cls = cls7[0]
+        pars7 = [bplut[k][site_cls].reshape(1, N_) for k in names]
+        drv7[13][2, :6] = 0.0
+        drv7[13][3, :6] = 2e-3
+        f9['static_params'] = np.concatenate(pars7, 0)
+        f9['static_drivers'] = np.stack(drv7)
+        d, n_ = MOD16._evapotranspiration(pars7, *drv7, tiny=1e-2)
+        f9['static_day_tiny_1e-2'], f9['static_night_tiny_1e-2'] = d, n_
+        f9['static_et_ignores_tiny'] = MOD16._et(pars7, *drv7, tiny=1e-2)
+        # notebook cell 17: (N,) rows, a scalar and a (T, 1) column against (T, N)
+        T_, N_ = 9, 31
+        cls17, drv17 = synth.drivers((T_, N_), seed=17, special=True)
+        site_cls = cls17[0]
+        site_par = {k: bplut[k][site_cls] for k in names}            # (N,)
+        mixed = list(drv17)
+        mixed[3] = 0                                                  # sw_rad_night scalar
+        mixed[7] = drv17[7][0].copy()                                 # temp_annual (N,)
+        mixed[11] = drv17[11][0].copy()                               # pressure (N,)
+        mixed[4] = drv17[4][:, :1].copy()                             # albedo (T, 1)
+        day, night = MOD16(site_par).evapotranspiration(*mixed)
+        sep = pack_sep(MOD16(site_par).evapotranspiration(*mixed, separate=True))
+    f9['bcast_site_cls'] = site_cls
+    f9['bcast_site_params'] = np.stack([site_par[k] for k in names])
+    f9['bcast_dense'] = np.stack([drv17[k] for k in (0, 1, 2, 5, 6, 8, 9, 10, 12, 13)])
+    f9['bcast_temp_annual'], f9['bcast_pressure'] = mixed[7], mixed[11]
+    f9['bcast_albedo'] = mixed[4]
+    f9['bcast_day'], f9['bcast_night'] = day, night
+    for k, v in sep.items():
+        f9['bcast_' + k] = v
+    np.savez_compressed(os.path.join(HERE, 'f9_round2.npz'), **f9)
+    print('f9_round2.npz', os.path.getsize(os.path.join(HERE, 'f9_round2.npz')), 'bytes')
+
+
 def main():
     ref = import_reference()
+    if '--f9' in sys.argv:
+        return make_f9(ref)
     MOD16 = ref.MOD16
     names = list(MOD16.required_parameters)
     assert tuple(names) == oracle.PARAM_NAMES

@@ -45,7 +45,8 @@ def test_library_exports_every_declared_symbol(lib):
 def test_ctypes_prototypes_match_the_header(lib):
     assert sorted(lib.PROTOTYPES) == declared_functions()
     loaded = lib.load()
-    assert loaded.mod16_version() == 1
+    assert loaded.mod16_version() == lib.ABI_VERSION
+    assert re.search(r"#define MOD16_ABI_VERSION %d\b" % lib.ABI_VERSION, open(HEADER).read())
     assert loaded.mod16_strerror(0) == b'ok'
     assert b'class' in loaded.mod16_strerror(lib.ERR_CLASS_RANGE)
     assert loaded.mod16_strerror(-99) == b'unknown status'

@@ -222,11 +222,49 @@ def test_static_helpers(m16):
                   RTOL, 'pet')
 
 
-def test_unsupported_corners(m16):
-    m = m16.MOD16(S.params)
-    with pytest.raises(NotImplementedError):
-        m.transpiration(S.pressure, S.temp_k, S.vpd, S.lai, S.fpar, S.rad_canopy, S.tmin,
-                        tiny=1e-6)
+def test_f9_potential_transpiration_and_radiation_net(m16, golden):
+    """Against the reference's own outputs (tests/golden/f9_round2.npz)."""
+    f = golden('f9_round2')
+    (lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_a, tmin, vpd_d, vpd_n, pa, fpar, lai) = \
+        list(f['drivers'])
+    M = m16.MOD16
+    assert_parity(M.potential_transpiration(lw_d, sw_d, alb, pa, t_d, vpd_d, fpar),
+                  f['potential_transpiration'], RTOL, 'pot. transpiration')
+    assert_parity(M.potential_transpiration(lw_d, sw_d, alb, pa, t_d, vpd_d, fpar, alpha=1.0),
+                  f['potential_transpiration_alpha1'], RTOL, 'alpha = 1')
+    assert_parity(M.potential_transpiration(lw_d, sw_d, alb, pa, t_d, vpd_d, fpar,
+                                            rhumidity=f['rhumidity'], f_wet=f['f_wet']),
+                  f['potential_transpiration_given'], RTOL, 'rh, f_wet given')
+    assert_parity(m16.radiation_net(sw_d, alb, t_d), f['radiation_net'], RTOL, 'radiation_net')
+
+
+@pytest.mark.parametrize('tag,tiny', [('1e-3', 1e-3), ('1e-12', 1e-12)])
+def test_f9_tiny_is_an_argument(m16, golden, tag, tiny):
+    """`tiny` as the reference takes it (mod16/__init__.py:869, :1157): a kernel
+    argument, checked on inputs where it changes the result."""
+    f = golden('f9_round2')
+    model = m16.MOD16(dict(zip(m16.MOD16.required_parameters, f['params'])))
+    (lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_a, tmin, vpd_d, vpd_n, pa, fpar, lai) = \
+        list(f['drivers'])
+    rad_c = f['rad_canopy']
+    assert_parity(model.evaporation_wet_canopy(pa, t_d, vpd_d, lai, fpar, rad_c, tiny=tiny),
+                  f['wet_canopy_tiny_' + tag], RTOL, 'wet canopy')
+    assert_parity(model.transpiration(pa, t_d, vpd_d, lai, fpar, rad_c, tmin, tiny=tiny),
+                  f['transpiration_day_tiny_' + tag], RTOL, 'transpiration day')
+    assert_parity(model.transpiration(pa, t_n, vpd_n, lai, fpar, fpar * lw_n, tmin,
+                                      daytime=False, tiny=tiny),
+                  f['transpiration_night_tiny_' + tag], RTOL, 'transpiration night')
+
+
+def test_f9_static_path_tiny(m16, golden):
+    f = golden('f9_round2')
+    params = [f['static_params'][k:k + 1] for k in range(11)]
+    drv = list(f['static_drivers'])
+    day, night = m16.MOD16._evapotranspiration(params, *drv, tiny=1e-2)
+    assert_parity(day, f['static_day_tiny_1e-2'], 1e-11, 'day')
+    assert_parity(night, f['static_night_tiny_1e-2'], 1e-11, 'night')
+    # MOD16._et accepts `tiny` and, as the reference (:190-192), does not pass it on
+    assert_parity(m16.MOD16._et(params, *drv, tiny=1e-2), f['static_et_ignores_tiny'], 1e-11, '_et')
 
 
 def test_et_vectorized(m16, golden):                      # tests.py:64-90, all three interfaces

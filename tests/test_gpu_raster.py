@@ -232,6 +232,47 @@ def test_time_series_streaming_ring(env):
     assert not torch.equal(diag[0], diag[1])
 
 
+def test_time_series_steps_match_the_oracle(env):
+    """configs[3] against the ORACLE, not against another HIP launch: windows of
+    >= 300 k pixels of inputs and outputs of the first, a middle and the last
+    step of a 46-step series are copied back while the ring streams on, and the
+    numpy oracle runs on exactly those input bits (float64, 1e-8; NaN and
+    exact-zero masks identical); the step's diagnostics are checked against
+    numpy over the whole raster of that step."""
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table)
+    rows, cols, steps = 600, 1440, 46
+    n = rows * cols
+    w0, w1 = 123 * cols + 64, 123 * cols + 64 + 320000         # one >= 300 k-pixel window
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    bufs = eng.alloc_series(n)
+    grabbed = {}
+
+    def grab(s, day, night):
+        if s in (0, 23, steps - 1):
+            # enqueued on the compute stream right behind step s: the copies see the
+            # slot of step s before the ingest stream may refill it
+            grabbed[s] = ([d[w0:w1].clone() for d in bufs['ring'][s % 2]],
+                          bufs['cls'][w0:w1].clone(), day[w0:w1].clone(), night[w0:w1].clone(),
+                          day.clone(), night.clone())
+
+    diag, _, _ = eng.run_series(n, steps, seed=16, on_step=grab, buffers=bufs)
+    eng.check()
+    assert sorted(grabbed) == [0, 23, steps - 1]
+    for s, (drv, cls, day, night, fday, fnight) in grabbed.items():
+        want_day, want_night = oracle.evapotranspiration_raster(bplut, cls.cpu().numpy(), *to_np(drv))
+        assert_parity(day.cpu().numpy(), want_day, 1e-8, 'step %d day' % s)
+        assert_parity(night.cpu().numpy(), want_night, 1e-8, 'step %d night' % s)
+        hd, hn = fday.cpu().numpy(), fnight.cpu().numpy()
+        g = diag[s].cpu().numpy()
+        np.testing.assert_allclose(g[:2], [np.nansum(hd), np.nansum(hn)], rtol=1e-12)
+        assert g[4] == np.isnan(hd).sum() and g[5] == np.isnan(hn).sum()
+        assert g[2] == n - g[4] and g[3] == n - g[5]
+        assert g[6] == np.nanmax(hd) and g[7] == np.nanmax(hn)
+    # the windows differ from step to step (the ring really advanced)
+    assert not torch.equal(torch.nan_to_num(grabbed[0][2]), torch.nan_to_num(grabbed[23][2]))
+
+
 @pytest.mark.parametrize('graph', [True, False])
 def test_bound_launch_equals_run(env, graph):
     torch, RasterEngine, table = env
@@ -257,6 +298,130 @@ def test_bound_launch_equals_run(env, graph):
     assert torch.equal(d1, d2) and not torch.equal(torch.nan_to_num(a), torch.nan_to_num(a2))
     assert torch.equal(torch.nan_to_num(a2), torch.nan_to_num(day))
     assert torch.equal(torch.nan_to_num(b2), torch.nan_to_num(night))
+
+
+def test_bound_graph_survives_workspace_growth(env):
+    """A captured graph owns its diagnostics workspace: launches of LARGER
+    rasters on the same engine (DEVICE and HOST mode) make the context's own
+    workspace grow -- it is freed and re-allocated -- and the graph bound before
+    that must still replay correctly afterwards."""
+    torch, RasterEngine, table = env
+    import mod16_amd
+    eng = RasterEngine(table)
+    n = 1200 * 1200
+    cls, drv = eng.synth(n, seed=21)
+    day, night = eng.empty(n, 2)
+    d_graph = torch.zeros(8, dtype=torch.float64, device='cuda')
+    launch = eng.bind(cls, drv, day, night, d_graph, graph=True)
+    launch()
+    eng.check()
+    first = d_graph.clone()
+    # a raster 40 x larger through the same context: DEVICE mode with diagnostics ...
+    big = 40 * n
+    bcls, bdrv = eng.synth(big, seed=22)
+    d_big = torch.zeros(8, dtype=torch.float64, device='cuda')
+    eng.run(bcls, bdrv, diag=d_big)
+    eng.check()
+    # ... and HOST mode (stages 2 Mi-pixel tiles, reserves its own workspace size)
+    hcls = bcls[:5 * n].cpu().numpy()
+    hdrv = [d[:5 * n].cpu().numpy() for d in bdrv]
+    ctx = eng.ctx
+    out = [np.empty(5 * n), np.empty(5 * n)]
+    ctx.et(np.float64, hcls.ctypes.data, [d.ctypes.data for d in hdrv], [1] * 14, None, None,
+           5 * n, out[0].ctypes.data, out[1].ctypes.data, None)
+    del bcls, bdrv
+    torch.cuda.empty_cache()
+    scratch = torch.full((64 << 20,), 7.0, dtype=torch.float64, device='cuda')   # reuse freed memory
+    d_graph.zero_()
+    for _ in range(3):
+        launch()
+    eng.check()
+    assert torch.equal(d_graph, first)
+    assert bool((scratch == 7.0).all())
+    d_run = torch.zeros(8, dtype=torch.float64, device='cuda')
+    a, b = eng.run(cls, drv, diag=d_run)
+    eng.check()
+    assert torch.equal(d_run, d_graph)
+    assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(day))
+    assert torch.equal(torch.nan_to_num(b), torch.nan_to_num(night))
+
+
+def test_engines_with_different_tables_do_not_disturb_each_other(env):
+    """Each RasterEngine has its own context and BPLUT copy: interleaved launches
+    (and bound graphs) of two engines with different tables, and a numpy-path
+    call with a third table in between, each compute with their own table."""
+    torch, RasterEngine, table = env
+    import mod16_amd
+    table2 = table.copy()
+    table2[:, 7] *= 0.5          # csl
+    table2[:, 10] = 400.0        # beta
+    e1, e2 = RasterEngine(table), RasterEngine(table2)
+    n = 300000
+    cls, drv = e1.synth(n, seed=31)
+    want1 = [t.clone() for t in RasterEngine(table).run(cls, drv)]
+    want2 = [t.clone() for t in RasterEngine(table2).run(cls, drv)]
+    torch.cuda.synchronize()
+    assert not torch.equal(torch.nan_to_num(want1[0]), torch.nan_to_num(want2[0]))
+    d1, d2 = (torch.zeros(8, dtype=torch.float64, device='cuda') for _ in range(2))
+    o1, o2 = e1.empty(n, 2), e2.empty(n, 2)
+    g1 = e1.bind(cls, drv, o1[0], o1[1], d1)
+    g2 = e2.bind(cls, drv, o2[0], o2[1], d2)
+    table3 = table.copy()
+    table3[:, 4] *= 2.0
+    h = [d[:5000].cpu().numpy() for d in drv]
+    for _ in range(2):
+        g1()
+        a2 = e2.run(cls, drv)
+        mod16_amd.evapotranspiration_raster(table3, cls[:5000].cpu().numpy(), *h)
+        g2()
+        a1 = e1.run(cls, drv)
+    torch.cuda.synchronize()
+    for got, want in ((o1, want1), (a1, want1), (o2, want2), (a2, want2)):
+        for g, w in zip(got, want):
+            assert torch.equal(torch.nan_to_num(g), torch.nan_to_num(w))
+
+
+def test_numpy_path_from_two_threads(env):
+    """The reference's functions are pure and may be called from several threads
+    (SURVEY.md section 8b). ctypes drops the GIL: two threads run
+    MOD16.evapotranspiration / evapotranspiration_raster concurrently on different
+    inputs and tables; both must equal the serial results."""
+    import threading
+    torch, RasterEngine, table = env
+    import mod16_amd
+    from oracle import synth
+    table2 = table.copy()
+    table2[:, 10] = 500.0
+    jobs = []
+    for k, tab in enumerate((table, table2)):
+        cls, drv = synth.drivers((700, 3000), seed=40 + k)      # 2.1 M pixels: more than one staged tile
+        jobs.append((tab, cls, drv))
+    serial = [mod16_amd.evapotranspiration_raster(tab, cls, *drv) for tab, cls, drv in jobs]
+    params = dict(zip(mod16_amd.MOD16.required_parameters, table[7]))
+    serial_m = mod16_amd.MOD16(params).evapotranspiration(*jobs[0][2])
+    results, errors = {}, []
+
+    def work(i):
+        try:
+            tab, cls, drv = jobs[i % 2]
+            for rep in range(3):
+                if i == 2:
+                    results[(i, rep)] = mod16_amd.MOD16(params).evapotranspiration(*jobs[0][2])
+                else:
+                    results[(i, rep)] = mod16_amd.evapotranspiration_raster(tab, cls, *drv)
+        except Exception as exc:       # surfaced below
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for (i, rep), got in results.items():
+        want = serial_m if i == 2 else serial[i]
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w, equal_nan=True), (i, rep)
 
 
 def test_unaligned_device_pointers_take_the_scalar_path(env):
@@ -400,3 +565,57 @@ def test_diagnostics_of_an_all_nan_raster(env, dtype):
     want = np.array([0.0, 0.0, 0.0, 0.0, n, n, -np.inf, -np.inf])
     assert np.array_equal(fused.cpu().numpy(), want)
     assert np.array_equal(alone.cpu().numpy(), want)
+
+
+def test_global_grid_float64(env):
+    """BASELINE.json configs[2] at FULL size on one GPU: the 43200 x 21600
+    float64 grid (120 GB resident; skipped when less than 150 GB of HBM is
+    free). Checks that do not need a CPU pass over 933 M pixels: diagnostics
+    consistent with the raster (n_valid + n_nan = n, NaN share of the
+    generator), the production (FAST) kernel against the reference-order
+    (EXACT) kernel on every pixel (masks identical, nothing above 1e-5, the
+    north-star tolerance), and the numpy oracle on four 1200 x 1200 windows
+    copied back (1e-8, masks identical)."""
+    torch, RasterEngine, table = env
+    from mod16_amd import _lib
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150e9:
+        pytest.skip('needs 150 GB of free HBM, %.0f GB available' % (free / 1e9))
+    rows, cols = 21600, 43200
+    n = rows * cols
+    eng = RasterEngine(table)
+    cls, drv, day, night = eng.alloc_raster(n, 512 << 20)
+    eng.synth(n, seed=16, out=(cls, drv))
+    diag = torch.zeros(8, dtype=torch.float64, device='cuda')
+    eng.run(cls, drv, day, night, diag=diag)
+    eng.check()
+    g = diag.cpu().numpy()
+    assert g[2] + g[4] == n and g[3] + g[5] == n
+    assert 0.02 < g[4] / n < 0.06                     # invalid classes + NaN fills of the generator
+    assert g[0] > 0 and g[1] > 0 and np.isfinite(g[6]) and np.isfinite(g[7])
+    # every pixel: FAST against EXACT on the device, in slices (bounded temporaries)
+    exact = RasterEngine(table, math=_lib.MATH_EXACT)
+    eday, enight = exact.run(cls, drv)
+    exact.check()
+    worst, above = 0.0, 0
+    step = 1 << 27
+    for got, ref in ((day, eday), (night, enight)):
+        for lo in range(0, n, step):
+            a, b = got[lo:lo + step], ref[lo:lo + step]
+            assert torch.equal(torch.isnan(a), torch.isnan(b))
+            assert torch.equal(a == 0, b == 0)
+            err = torch.nan_to_num_((a - b).abs_().div_(b.abs()), nan=0.0, posinf=0.0)
+            worst = max(worst, float(err.max()))
+            above += int((err > 1e-5).sum())
+            del err
+    assert above == 0 and worst < 1e-7, (above, worst)
+    del eday, enight
+    # the oracle on four windows (start, two inside, end)
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    m = 1200 * 1200
+    for s0 in (0, (n // 3) // 4 * 4, (2 * n // 3) // 4 * 4, n - m):
+        h_cls = cls[s0:s0 + m].cpu().numpy()
+        h_drv = [d[s0:s0 + m].cpu().numpy() for d in drv]
+        want = oracle.evapotranspiration_raster(bplut, h_cls, *h_drv)
+        assert_parity(day[s0:s0 + m].cpu().numpy(), want[0], 1e-8, 'day @%d' % s0)
+        assert_parity(night[s0:s0 + m].cpu().numpy(), want[1], 1e-8, 'night @%d' % s0)

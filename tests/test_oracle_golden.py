@@ -195,3 +195,71 @@ def test_f8_raw_driver_preprocessing(golden):
     same(night, f['night'])
     same(total, f['total8'])
     assert np.isnan(f['day'][0, 1]) and np.isnan(f['night'][1, 1])     # fill codes
+
+
+def test_f9_potential_transpiration_and_radiation_net(golden):
+    """Reference outputs of MOD16.potential_transpiration (:546-602) and
+    radiation_net (:1293-1337), instead of re-typed closed forms."""
+    f = golden('f9_round2')
+    (lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_a, tmin, vpd_d, vpd_n, pa, fpar, lai) = \
+        list(f['drivers'])
+    same(oracle.potential_transpiration(lw_d, sw_d, alb, pa, t_d, vpd_d, fpar),
+         f['potential_transpiration'])
+    same(oracle.potential_transpiration(lw_d, sw_d, alb, pa, t_d, vpd_d, fpar, alpha=1.0),
+         f['potential_transpiration_alpha1'])
+    same(oracle.potential_transpiration(lw_d, sw_d, alb, pa, t_d, vpd_d, fpar,
+                                        rh=f['rhumidity'], f_wet=f['f_wet']),
+         f['potential_transpiration_given'])
+    same(oracle.radiation_net(sw_d, alb, t_d), f['radiation_net'])
+
+
+@pytest.mark.parametrize('tag,tiny', [('1e-3', 1e-3), ('1e-12', 1e-12)])
+def test_f9_tiny_argument(golden, tag, tiny):
+    """`tiny` other than the default (reference :869, :1157)."""
+    f = golden('f9_round2')
+    p = params_of(f['params'])
+    (lw_d, lw_n, sw_d, sw_n, alb, t_d, t_n, t_a, tmin, vpd_d, vpd_n, pa, fpar, lai) = \
+        list(f['drivers'])
+    rad_c = f['rad_canopy']
+    same(oracle.evaporation_wet_canopy(p, pa, t_d, vpd_d, lai, fpar, rad_c, tiny=tiny),
+         f['wet_canopy_tiny_' + tag])
+    same(oracle.transpiration(p, pa, t_d, vpd_d, lai, fpar, rad_c, tmin, tiny=tiny),
+         f['transpiration_day_tiny_' + tag])
+    same(oracle.transpiration(p, pa, t_n, vpd_n, lai, fpar, fpar * lw_n, tmin,
+                              daytime=False, tiny=tiny), f['transpiration_night_tiny_' + tag])
+    # the argument matters on these inputs
+    assert not np.array_equal(f['wet_canopy_tiny_1e-3'], f['wet_canopy_tiny_1e-12'], equal_nan=True)
+
+
+def test_f9_static_path_tiny(golden):
+    f = golden('f9_round2')
+    params = [f['static_params'][k:k + 1] for k in range(11)]
+    drv = list(f['static_drivers'])
+    day, night = oracle.et_static_daynight(params, *drv, tiny=1e-2)
+    same(day, f['static_day_tiny_1e-2'])
+    same(night, f['static_night_tiny_1e-2'])
+    # MOD16._et drops its `tiny` (reference :190-192)
+    same(oracle.et_static(params, *drv), f['static_et_ignores_tiny'])
+    assert not np.array_equal(day + night, f['static_et_ignores_tiny'], equal_nan=True)
+
+
+def bcast_inputs(f):
+    """The mixed-shape argument list of the F9 broadcast case: (T, N) dense
+    drivers, (N,) temp_annual / pressure, a (T, 1) albedo, scalar sw_rad_night."""
+    dense = list(f['bcast_dense'])
+    lw_d, lw_n, sw_d, t_d, t_n, tmin, vpd_d, vpd_n, fpar, lai = dense
+    return [lw_d, lw_n, sw_d, 0, f['bcast_albedo'], t_d, t_n, f['bcast_temp_annual'], tmin,
+            vpd_d, vpd_n, f['bcast_pressure'], fpar, lai]
+
+
+def test_f9_broadcast_rows_and_columns(golden):
+    """(N,) against (T, N) (reference mod16/__init__.py:180-181, notebook cell 17)."""
+    f = golden('f9_round2')
+    p = {k: f['bcast_site_params'][j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    drv = bcast_inputs(f)
+    day, night = oracle.evapotranspiration(p, *drv)
+    same(day, f['bcast_day'])
+    same(night, f['bcast_night'])
+    res = oracle.evapotranspiration(p, *drv, separate=True)
+    for name, got in zip(SEP, list(res[0]) + list(res[1])):
+        same(got, f['bcast_' + name])
