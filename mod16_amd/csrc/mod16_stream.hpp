@@ -273,6 +273,9 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
 #pragma nounroll
     for (; cbase + run < npiece; ) {
         Ptrs ptrs;
+#ifdef MOD16_PRIO   // experiment: the memory phase of a wave outranks its partner's arithmetic
+        __builtin_amdgcn_s_setprio(MOD16_PRIO);
+#endif
         load_ptrs(ptrs);
         // everything but the NOUT stores of the previous iteration (and its
         // diagnostics flush, if any) must be complete: this iteration's DMA and,
@@ -301,6 +304,9 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
         const int64_t vn = vec_of(cb_n, run_n);
         if (vn < nvec) issue(offs_of(cb_n, run_n), ptrs);
         asm volatile("" ::: "memory");
+#ifdef MOD16_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 
         if (v < nvec) {   // only the last piece is ragged
             VT res[NOUT];

@@ -58,3 +58,43 @@ def test_two_rank_gloo_bands_and_allreduce(tmp_path):
     np.testing.assert_allclose(res['reduced'][:2], res['global'][:2], rtol=1e-12)
     assert res['reduced'][2:] == res['global'][2:]
     assert res['bands_identical_to_global']
+
+
+def test_bench_spawn_command():
+    """`python bench.py --gpus N` starts its own ranks: the command of the child."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.spawn_command(['--gpus', '8', '--steps', '5', '--warmup', '1'], 8, 29511)
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nnodes=1' in cmd
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '8'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[cmd.index('--master-port') + 1] == '29511'
+    k = cmd.index(os.path.join(ROOT, 'bench.py'))
+    assert cmd[k + 1:] == ['--gpus', '8', '--steps', '5', '--warmup', '1']
+
+
+def test_bench_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` typed as is (no torch.distributed.run around it):
+    the parent launches two ranks, the ranks count each other with an all-reduce and
+    rank 0's line comes back through the parent, whose exit code is the child's.
+    MOD16_BENCH_PLUMBING=1 replaces the GPU work of a rank by nothing (no GPU in
+    this container); launcher, rendezvous and relay are the real ones."""
+    env = dict(os.environ, MOD16_BENCH_PLUMBING='1', OMP_NUM_THREADS='1')
+    for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(key, None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+                           '--steps', '3', '--warmup', '1'],
+                          env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, proc.stdout
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['ranks_seen'] == 2 and res['steps'] == 3
+    # a failing rank makes the parent fail too
+    env['MOD16_BENCH_PLUMBING'] = '0'
+    env['CUDA_VISIBLE_DEVICES'] = env['HIP_VISIBLE_DEVICES'] = ''
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+                           '--no-cpu-baseline'], env=env, cwd=ROOT, capture_output=True,
+                          text=True, timeout=300)
+    assert proc.returncode != 0
