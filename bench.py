@@ -238,6 +238,8 @@ def main():
                     help="raster layout of the timed steps: the engine's tiled layout or 16 plain arrays")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--no-plain', action='store_true',
+                    help='skip timing the same kernel on 16 plain arrays (profiled runs: one layout per kernel symbol)')
     ap.add_argument('--no-configs', action='store_true',
                     help='skip the other BASELINE.json configurations (1200x1200 tile, series, float32)')
     ap.add_argument('--cpu-workers', type=int, default=16)
@@ -441,7 +443,7 @@ def main():
     # the same kernel on 16 plain arrays (the layout of the reference's arguments)
     plain = None
     copy_gbps = None
-    if args.layout == 'tiled':
+    if args.layout == 'tiled' and not args.no_plain:
         steps_bound = ras = None
         torch.cuda.empty_cache()
         try:

@@ -14,9 +14,10 @@ if [ -z "$SKIP_TESTS" ]; then
 fi
 timeout -k 10 500 python bench.py "$@" > $O/bench_line.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
 cat $O/bench_line.json
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py "$@" --no-cpu-baseline --steps 10 > $O/bench_line_under_rocprof.json 2> $O/rocprof_stats.err
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py "$@" --no-cpu-baseline --no-parity --steps 3 --warmup 1 > $O/pmc_fetch.out 2> $O/pmc_fetch.err
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py "$@" --no-cpu-baseline --no-parity --steps 3 --warmup 1 > $O/pmc_write.out 2> $O/pmc_write.err
+# profiled runs: one raster layout per kernel symbol (--no-plain), nothing but the headline configuration (--no-configs)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py "$@" --no-cpu-baseline --no-plain --no-configs --steps 40 > $O/bench_line_under_rocprof.json 2> $O/rocprof_stats.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py "$@" --no-cpu-baseline --no-parity --no-plain --no-configs --steps 3 --warmup 1 > $O/pmc_fetch.out 2> $O/pmc_fetch.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py "$@" --no-cpu-baseline --no-parity --no-plain --no-configs --steps 3 --warmup 1 > $O/pmc_write.out 2> $O/pmc_write.err
 find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 O=$O python - <<'PY'
 import csv, glob, json, os
@@ -32,6 +33,24 @@ for name in ('FETCH_SIZE', 'WRITE_SIZE'):
     res[name] = (sum(vals) / len(vals) if vals else None, len(vals))
 print(json.dumps(res))
 json.dump(res, open(os.path.join(O, 'pmc_raw.json'), 'w'))
+# the record bench.py reads back as roofline.traffic (gfx950: FETCH_SIZE x 2, MI355X_MICROARCH.md HBM)
+try:
+    line = json.load(open(os.path.join(O, 'bench_line_under_rocprof.json')))
+    n = line['roofline']['pixels_per_launch']
+    rd = res['FETCH_SIZE'][0] * 1024 * 2
+    wr = res['WRITE_SIZE'][0] * 1024
+    rec = {'kernel': line['roofline']['kernel'], 'layout': line['config']['raster_layout']['layout'],
+           'dtype': {'f64': 'float64', 'f32': 'float32'}[line['dtype']],
+           'launches_averaged': [res['FETCH_SIZE'][1], res['WRITE_SIZE'][1]],
+           'FETCH_SIZE_KB_per_launch': res['FETCH_SIZE'][0], 'WRITE_SIZE_KB_per_launch': res['WRITE_SIZE'][0],
+           'correction': 'gfx950: FETCH_SIZE counts 128-B requests as 64 B for 16 B/lane streaming reads -> x2; WRITE_SIZE exact',
+           'read_bytes_per_launch': rd, 'write_bytes_per_launch': wr, 'traffic_bytes_per_launch': rd + wr,
+           'pixels_per_launch': n, 'traffic_bytes_per_pixel': (rd + wr) / n,
+           'algorithmic_bytes_per_pixel': line['roofline']['bytes_per_pixel']}
+    json.dump(rec, open(os.path.join(O, 'pmc_hbm_traffic.json'), 'w'), indent=1)
+    print(json.dumps(rec))
+except Exception as exc:
+    print('no traffic record:', exc)
 PY
 # keep the merged output small
 find $O -name "*.csv" -size +2M -delete
