@@ -455,6 +455,17 @@ MOD16_API int mod16_synth_tiled_f32(mod16_ctx* ctx, const mod16_layout* layout,
 MOD16_API int mod16_time_graph(mod16_graph* graph, int launches, void* stream, float* ms);
 
 /*
+ * Page-locked host memory for the arrays a HOST-mode call writes its results to.
+ * The reference returns freshly allocated arrays (mod16/__init__.py:789-793); a
+ * device-to-host copy into fresh pageable memory is bound by the kernel's
+ * page-fault rate (13 GB/s measured), into page-locked memory by PCIe (57 GB/s).
+ * The Python layer keeps a bounded pool of such blocks behind the numpy arrays
+ * it returns. Not tied to a ctx; thread-safe.
+ */
+MOD16_API int mod16_host_alloc(int64_t bytes, void** out);
+MOD16_API int mod16_host_free(void* p);
+
+/*
  * Measurement aid for bench.py ("roofline vs measured
  * copy bandwidth"): allocates two device buffers of `bytes`, times a one-shot
  * 16-byte-per-lane copy kernel `reps` times with HIP events and returns the

@@ -109,7 +109,7 @@ def _forward(cls, drivers, params, separate, flags, device, pet=False, out=None)
     else:
         keep_p, pptr, pstride = _marshal(params, shape, dtype)
     if pet:
-        outs = [np.empty(shape, dtype) for _ in range(4)]
+        outs = [_lib.pinned.empty(shape, dtype) for _ in range(4)]
         if n:
             fn = ctx.lib.mod16_et_pet_f32 if dtype == np.float32 else ctx.lib.mod16_et_pet_f64
             ctx.check(fn(
@@ -132,7 +132,7 @@ def _forward(cls, drivers, params, separate, flags, device, pet=False, out=None)
                 raise ValueError('out arrays must be writeable C-contiguous %s arrays of shape %s'
                                  % (dtype, shape))
     else:
-        outs = [np.empty(shape, dtype) for _ in range(nout)]
+        outs = [_lib.pinned.empty(shape, dtype) for _ in range(nout)]
     if separate:
         day = night = None
         sep = [o.ctypes.data for o in outs]
@@ -664,7 +664,7 @@ def evapotranspiration_raw(
                 raise IndexError('uint8 raster value outside [0, 255]')
             a = a.astype(np.uint8)
         bytes_.append(np.ascontiguousarray(np.broadcast_to(a, shape)))
-    outs = [np.empty(shape, dtype) for _ in range(3 if hours else 2)]
+    outs = [_lib.pinned.empty(shape, dtype) for _ in range(3 if hours else 2)]
     if n:
         fn = ctx.lib.mod16_et_raw_f32 if dtype == np.float32 else ctx.lib.mod16_et_raw_f64
         ctx.check(fn(

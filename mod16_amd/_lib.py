@@ -7,6 +7,7 @@ when a computation is requested, the call fails loudly.
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -150,6 +151,8 @@ PROTOTYPES = {
         C.c_void_p, _LAYP, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
         _PP, C.c_void_p]),
     'mod16_time_graph': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+    'mod16_host_alloc': (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
+    'mod16_host_free': (C.c_int, [C.c_void_p]),
     'mod16_measure_copy': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
     'mod16_time_et': (C.c_int, [
         C.c_void_p, C.c_int, C.c_void_p, _PP, _I64P, _PP, _I64P, C.c_int64,
@@ -306,6 +309,62 @@ class Context:
         self.check(self.lib.mod16_check_status(self.handle, stream))
 
 
+class _PinnedPool(object):
+    '''Page-locked host blocks behind the result arrays of the numpy entry points.
+
+    The reference returns fresh arrays; writing 1.5 GB of results into fresh
+    pageable memory costs a page fault per 4 KiB (13 GB/s measured) where PCIe
+    moves 57 GB/s, so result arrays of ``MIN_BYTES`` or more are numpy views of
+    ``hipHostMalloc`` blocks. A block goes back to the pool when its array is
+    garbage-collected and is handed out again for the next result of that size
+    (a time loop allocates once); the pool keeps at most ``MAX_CACHED`` bytes of
+    idle blocks, the rest is freed. Everything else about the arrays is ordinary
+    (writeable, C-contiguous, own their memory through ``.base``).'''
+    MIN_BYTES = 1 << 20
+    MAX_CACHED = 8 << 30
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.free = {}          # nbytes -> [address, ...]
+        self.cached = 0
+
+    def take(self, nbytes):
+        with self.lock:
+            blocks = self.free.get(nbytes)
+            if blocks:
+                self.cached -= nbytes
+                return blocks.pop()
+        p = C.c_void_p()
+        if load().mod16_host_alloc(nbytes, C.byref(p)) != OK or not p.value:
+            return None
+        return p.value
+
+    def give(self, addr, nbytes):
+        with self.lock:
+            if self.cached + nbytes <= self.MAX_CACHED:
+                self.free.setdefault(nbytes, []).append(addr)
+                self.cached += nbytes
+                return
+        try:
+            load().mod16_host_free(addr)
+        except Exception:       # interpreter shutdown
+            pass
+
+    def empty(self, shape, dtype):
+        '''``numpy.empty(shape, dtype)``, page-locked when large enough.'''
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if nbytes < self.MIN_BYTES or os.environ.get('MOD16_PINNED_RESULTS') == '0':
+            return np.empty(shape, dtype)
+        addr = self.take(nbytes)
+        if addr is None:
+            return np.empty(shape, dtype)
+        buf = (C.c_char * nbytes).from_address(addr)
+        weakref.finalize(buf, self.give, addr, nbytes)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+pinned = _PinnedPool()
 _local = threading.local()
 
 

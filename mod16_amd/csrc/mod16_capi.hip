@@ -25,7 +25,7 @@ using namespace mod16;
 namespace {
 constexpr int64_t kTilePixels = int64_t(1) << 21;   // HOST mode: pixels per staged tile
 constexpr int kDiagBlocks = 1024;
-constexpr int kSlots = 4;                           // staging slots = host threads of the HOST mode
+constexpr int kSlots = 12;                          // staging slots = host threads of the HOST mode
 constexpr size_t kStagger = 33 * 1024;              // see RasterEngine.STAGGER_BYTES
 }  // namespace
 
@@ -44,7 +44,7 @@ struct mod16_ctx {
     int cus = 256;
     int grid_mult = 64;              // blocks per CU in the grid-stride launches of the plain kernels
     bool use_dma = true;             // production pipeline (mod16_stream.hpp); MOD16_NO_DMA=1: plain kernels only
-    int host_threads = kSlots;       // MOD16_HOST_THREADS: staging threads of the HOST mode (1..kSlots)
+    int host_threads = 8;            // MOD16_HOST_THREADS: staging threads of the HOST mode (1..kSlots)
     int run_shift = -1;              // MOD16_RUN_SHIFT: force 2^k pieces per run (experiments)
     int use_pitch = 1;               // scalar base + pitch addressing for slab layouts (MOD16_PITCH=0: off)
     unsigned long long* dyn_counters = nullptr;   // ring of ticket counters, 128 B apart
@@ -913,6 +913,25 @@ extern "C" int mod16_time_et(mod16_ctx* ctx, int is_f32, const uint8_t* cls,
     (void)hipEventDestroy(e1);
     *ms = t / (float)launches;
     return rc;
+}
+
+// Page-locked host memory for result arrays (mod16_amd/_lib.py keeps a small pool): a
+// device-to-host copy into fresh pageable memory runs at the kernel's page-fault rate
+// (13 GB/s measured, tools/probe_pcie.hip), into pinned memory at the PCIe rate (57 GB/s).
+extern "C" int mod16_host_alloc(int64_t bytes, void** out) {
+    if (!out || bytes <= 0) return MOD16_ERR_ARG;
+    *out = nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return MOD16_ERR_NOMEM;
+    }
+    *out = p;
+    return MOD16_OK;
+}
+extern "C" int mod16_host_free(void* p) {
+    if (!p) return MOD16_OK;
+    return hipHostFree(p) == hipSuccess ? MOD16_OK : MOD16_ERR_HIP;
 }
 
 extern "C" int mod16_measure_copy(mod16_ctx* ctx, int64_t bytes, int reps, float* gbps) {

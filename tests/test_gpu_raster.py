@@ -424,6 +424,34 @@ def test_numpy_path_from_two_threads(env):
             assert np.array_equal(g, w, equal_nan=True), (i, rep)
 
 
+def test_result_arrays_come_from_a_pinned_pool(env):
+    """Result arrays of the numpy entry points are page-locked blocks that return
+    to a pool when the array dies and are handed out again: ordinary arrays to
+    the caller (writeable, contiguous, correct), no fresh page faults per call."""
+    import gc
+    torch, RasterEngine, table = env
+    import mod16_amd
+    from mod16_amd import _lib
+    from oracle import synth
+    cls, drv = synth.drivers((900, 1000), seed=50)
+    day, night = mod16_amd.evapotranspiration_raster(table, cls, *drv)
+    assert day.flags.writeable and day.flags.c_contiguous and day.base is not None
+    addr = day.ctypes.data
+    keep = day.copy()
+    del day, night
+    gc.collect()
+    assert _lib.pinned.cached >= 2 * 900 * 1000 * 8
+    day2, night2 = mod16_amd.evapotranspiration_raster(table, cls, *drv)
+    assert addr in (day2.ctypes.data, night2.ctypes.data)          # the block came back
+    assert np.array_equal(day2, keep, equal_nan=True)
+    day2 += 1.0                                                    # an ordinary array
+    # a caller that keeps results keeps its memory: nothing is recycled under it
+    a = mod16_amd.evapotranspiration_raster(table, cls, *drv)
+    b = mod16_amd.evapotranspiration_raster(table, cls, *drv)
+    assert len({a[0].ctypes.data, a[1].ctypes.data, b[0].ctypes.data, b[1].ctypes.data}) == 4
+    assert np.array_equal(a[0], b[0], equal_nan=True)
+
+
 def test_unaligned_device_pointers_take_the_scalar_path(env):
     """Tensors that start 8 bytes into an allocation are not 16-byte aligned:
     the library must fall back to the scalar-access kernel, same results."""

@@ -100,3 +100,18 @@ def test_marshal_strides_and_broadcast():
     assert np.array_equal(keep[1][2], np.arange(5.0))
     assert all(k.dtype == np.float64 for k in keep)
     assert ptrs[2] == keep[2].ctypes.data
+
+
+def test_result_arrays_fall_back_to_numpy_without_a_gpu():
+    """The pool of page-locked result blocks (mod16_amd/_lib.py) hands out plain
+    numpy arrays when no page-locked memory can be had (no GPU here) or the array
+    is small."""
+    import numpy as np
+    from mod16_amd import _lib
+    a = _lib.pinned.empty((1200, 1200), np.float64)
+    assert a.shape == (1200, 1200) and a.dtype == np.float64
+    assert a.flags.writeable and a.flags.c_contiguous
+    a[:] = 2.0
+    assert a.sum() == 2.0 * 1200 * 1200
+    small = _lib.pinned.empty((10,), np.float32)
+    assert small.base is None and small.dtype == np.float32

@@ -67,6 +67,10 @@ BODY2(add32_ind, "v_add_u32 %0, %5, %5\n v_add_u32 %1, %5, %5\n v_add_u32 %2, %5
 BODY2(fma32_ind, "v_fma_f32 %0, %5, %5, %5\n v_fma_f32 %1, %5, %5, %5\n v_fma_f32 %2, %5, %5, %5\n v_fma_f32 %3, %5, %5, %5", "memory")
 BODY2(sel64, "v_cmp_gt_f64 vcc, %6, %7\n v_cndmask_b32 %0, %5, %5, vcc\n v_cmp_gt_f64 vcc, %7, %6\n v_cndmask_b32 %1, %5, %5, vcc", "vcc")
 BODY2(sel64_sgpr, "v_cmp_gt_f64 s[20:21], %6, %7\n v_cndmask_b32 %0, %5, %5, s[20:21]\n v_cmp_gt_f64 s[22:23], %7, %6\n v_cndmask_b32 %1, %5, %5, s[22:23]", "s20", "s21", "s22", "s23")
+BODY2(selpair_vcc, "v_cmp_gt_f64 vcc, %6, %7\n v_cndmask_b32 %0, %5, %5, vcc\n v_cndmask_b32 %1, %5, %5, vcc\n v_fma_f64 %4, %4, %6, %7", "vcc")
+BODY2(selpair_sgpr, "v_cmp_gt_f64 s[20:21], %6, %7\n v_cndmask_b32 %0, %5, %5, s[20:21]\n v_cndmask_b32 %1, %5, %5, s[20:21]\n v_fma_f64 %4, %4, %6, %7", "s20", "s21")
+BODY2(selpair_vcc3, "v_cmp_gt_f64 vcc, %6, %7\n v_cndmask_b32_e64 %0, %5, %5, vcc\n v_cndmask_b32_e64 %1, %5, %5, vcc\n v_fma_f64 %4, %4, %6, %7", "vcc")
+BODY2(fma64x3_cnd, "v_fma_f64 %4, %4, %6, %7\n v_fma_f64 %4, %4, %6, %7\n v_fma_f64 %4, %4, %6, %7\n v_cndmask_b32 %1, %5, %5, vcc", "memory")
 BODY2(dsread, "ds_read_b64 %4, %0\n ds_read_b64 %4, %0\n ds_read_b64 %4, %0\n ds_read_b64 %4, %0\n s_waitcnt lgkmcnt(0)", "memory")
 BODY2(readlane_ind, "v_readlane_b32 s20, %0, 3\n v_readlane_b32 s21, %1, 5\n v_readlane_b32 s22, %2, 7\n v_readlane_b32 s23, %3, 9", "s20", "s21", "s22", "s23")
 
@@ -91,6 +95,6 @@ int main(int argc, char** argv) {
     RUN(fma64) RUN(add64) RUN(mul64) RUN(min64) RUN(cmp64_vcc) RUN(cmp64_sgpr) RUN(cmp32_vcc) RUN(cmpclass64)
     RUN(cndmask) RUN(mov32) RUN(mov64) RUN(readlane) RUN(writelane) RUN(rcp64) RUN(ldexp64) RUN(rndne64)
     RUN(cvti32f64) RUN(cvtf64i32) RUN(frexpm64) RUN(frexpe64) RUN(fma32) RUN(pkfma32) RUN(and32) RUN(lshl_add64) RUN(smov)
-    RUN(cnd_indep) RUN(cnd_dep) RUN(cnd_e64) RUN(fma64_dep) RUN(mov32_dep) RUN(mov32_ind) RUN(add32_dep) RUN(add32_ind) RUN(fma32_ind) RUN(sel64) RUN(sel64_sgpr) RUN(dsread) RUN(readlane_ind)
+    RUN(cnd_indep) RUN(cnd_dep) RUN(cnd_e64) RUN(fma64_dep) RUN(mov32_dep) RUN(mov32_ind) RUN(add32_dep) RUN(add32_ind) RUN(fma32_ind) RUN(sel64) RUN(sel64_sgpr) RUN(selpair_vcc) RUN(selpair_sgpr) RUN(selpair_vcc3) RUN(fma64x3_cnd) RUN(dsread) RUN(readlane_ind)
     return 0;
 }
