@@ -132,6 +132,35 @@ MOD16_API int mod16_et_f64(mod16_ctx* ctx, const uint8_t* cls,
                  double* const* out_sep, unsigned flags, int where,
                  void* stream);
 
+/*
+ * The same with the reference's 2-level broadcasting: its callers pass (N,)
+ * arrays -- one value per site: pressure, temp_annual, the per-site parameters
+ * `params_dict[key][pft_map]` -- against (T, N) drivers (mod16/__init__.py:180-181,
+ * forward-run notebook cell 17), and numpy broadcasts them. Here every input
+ * carries a broadcast kind instead of a 0 / 1 stride and nothing is made dense:
+ * with the (T, N) raster flattened to n = T * inner pixels (inner = N),
+ *
+ *     MOD16_BC_SCALAR  one value                     element 0
+ *     MOD16_BC_DENSE   [n]                           element i
+ *     MOD16_BC_ROW     [inner]   an (N,) array       element i % inner
+ *     MOD16_BC_COL     [n/inner] a (T, 1) array      element i / inner
+ *
+ * `cls_kind` is the kind of the class raster (a per-site PFT vector is a ROW).
+ * A call with a ROW or COL input runs the one-pixel-per-thread kernel (in HOST
+ * mode the small arrays are uploaded whole, once); without one it is mod16_et_*.
+ */
+enum mod16_broadcast { MOD16_BC_SCALAR = 0, MOD16_BC_DENSE = 1, MOD16_BC_ROW = 2, MOD16_BC_COL = 3 };
+MOD16_API int mod16_et2_f64(mod16_ctx* ctx, const uint8_t* cls, int cls_kind,
+                  const double* const* drivers, const int64_t* dkind,
+                  const double* const* params, const int64_t* pkind,
+                  int64_t inner, int64_t n, double* out_day, double* out_night,
+                  double* const* out_sep, unsigned flags, int where, void* stream);
+MOD16_API int mod16_et2_f32(mod16_ctx* ctx, const uint8_t* cls, int cls_kind,
+                  const float* const* drivers, const int64_t* dkind,
+                  const float* const* params, const int64_t* pkind,
+                  int64_t inner, int64_t n, float* out_day, float* out_night,
+                  float* const* out_sep, unsigned flags, int where, void* stream);
+
 /* float32 data: MOD16_MATH_FAST widens to float64 on load, computes in float64 and
  * rounds once on store; MOD16_MATH_EXACT keeps float32 arithmetic in the reference's
  * operation order (what numpy does for the reference on float32 inputs);

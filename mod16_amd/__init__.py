@@ -63,16 +63,40 @@ def _result_dtype(values):
     return np.dtype(np.float64)
 
 
-def _marshal(values, shape, dtype):
+def _broadcast_kind(a_shape, size, shape):
+    '''How an input of shape ``a_shape`` broadcasts against the full ``shape``,
+    as one of the kinds the C ABI takes without making it dense (``mod16_et2_*``):
+    scalar, dense, an (N,) row against (..., N), or a (..., 1) column. ``None``:
+    another pattern (made dense by the caller).'''
+    if size == 1:
+        return _lib.BC_SCALAR
+    padded = (1,) * (len(shape) - len(a_shape)) + tuple(a_shape)
+    if padded == tuple(shape):
+        return _lib.BC_DENSE
+    if len(shape) >= 2:
+        if padded[-1] == shape[-1] and all(x == 1 for x in padded[:-1]):
+            return _lib.BC_ROW
+        if padded[-1] == 1 and padded[:-1] == tuple(shape[:-1]):
+            return _lib.BC_COL
+    return None
+
+
+def _marshal(values, shape, dtype, kinds=False):
     '''-> (keepalive arrays, addresses, element strides) for the C ABI: a
     size-1 input is passed as a broadcast scalar (stride 0), anything else is
-    made dense over ``shape`` (stride 1).'''
+    made dense over ``shape`` (stride 1). With ``kinds`` the third list holds
+    broadcast kinds (``_lib.BC_*``) and (N,) rows / (..., 1) columns stay as
+    small as they are.'''
     keep, ptrs, strides = [], [], []
     for v in values:
         a = np.asarray(v, dtype=dtype)
+        kind = _broadcast_kind(a.shape, a.size, shape) if kinds else None
         if a.size == 1:
             a = np.ascontiguousarray(a.reshape(1))
             strides.append(0)
+        elif kind in (_lib.BC_ROW, _lib.BC_COL):
+            a = np.ascontiguousarray(a.reshape(-1))
+            strides.append(kind)
         else:
             if a.shape != shape:
                 a = np.broadcast_to(a, shape)
@@ -101,13 +125,23 @@ def _forward(cls, drivers, params, separate, flags, device, pet=False, out=None)
         shapes.append(cls.shape)
     shape = np.broadcast_shapes(*shapes)
     n = int(np.prod(shape, dtype=np.int64))
-    keep_d, dptr, dstride = _marshal(drivers, shape, dtype)
+    # (N,) rows and (..., 1) columns against (..., N) drivers are not made dense
+    # (reference mod16/__init__.py:180-181): the C ABI takes them as they are
+    two_level = not pet and len(shape) >= 2 and n > 0
+    keep_d, dptr, dstride = _marshal(drivers, shape, dtype, kinds=two_level)
     pptr = pstride = cptr = None
+    ckind = _lib.BC_DENSE
     if cls is not None:
-        cls = np.ascontiguousarray(np.broadcast_to(cls, shape))
+        k = _broadcast_kind(cls.shape, cls.size, shape) if two_level else None
+        if k in (_lib.BC_ROW, _lib.BC_COL):
+            cls, ckind = np.ascontiguousarray(cls.reshape(-1)), k
+        else:
+            cls = np.ascontiguousarray(np.broadcast_to(cls, shape))
         cptr = cls.ctypes.data
     else:
-        keep_p, pptr, pstride = _marshal(params, shape, dtype)
+        keep_p, pptr, pstride = _marshal(params, shape, dtype, kinds=two_level)
+    two_level = two_level and (ckind != _lib.BC_DENSE or max(dstride) > 1 or
+                               (pstride is not None and max(pstride) > 1))
     if pet:
         outs = [_lib.pinned.empty(shape, dtype) for _ in range(4)]
         if n:
@@ -139,7 +173,10 @@ def _forward(cls, drivers, params, separate, flags, device, pet=False, out=None)
     else:
         day, night = outs[0].ctypes.data, outs[1].ctypes.data
         sep = None
-    if n:
+    if n and two_level:
+        ctx.et2(dtype, cptr, ckind, dptr, dstride, pptr, pstride, shape[-1], n, day, night,
+                sep, flags=flags, where=_lib.HOST)
+    elif n:
         ctx.et(dtype, cptr, dptr, dstride, pptr, pstride, n, day, night, sep,
                flags=flags, where=_lib.HOST)
     if not shape:      # all-scalar input: numpy scalars, as the reference

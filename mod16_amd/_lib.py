@@ -16,6 +16,7 @@ N_PARAMS = 11
 N_CLASSES = 13
 N_COMPONENTS = 6
 HOST, DEVICE = 0, 1
+BC_SCALAR, BC_DENSE, BC_ROW, BC_COL = 0, 1, 2, 3      # enum mod16_broadcast
 MATH_FAST, MATH_EXACT, MATH_MIXED = 0, 1, 2
 
 METHOD_MAX_IN = 13
@@ -71,6 +72,12 @@ PROTOTYPES = {
     'mod16_et_f32': (C.c_int, [
         C.c_void_p, C.c_void_p, _PP, _I64P, _PP, _I64P, C.c_int64, C.c_void_p,
         C.c_void_p, _PP, C.c_uint, C.c_int, C.c_void_p]),
+    'mod16_et2_f64': (C.c_int, [
+        C.c_void_p, C.c_void_p, C.c_int, _PP, _I64P, _PP, _I64P, C.c_int64, C.c_int64,
+        C.c_void_p, C.c_void_p, _PP, C.c_uint, C.c_int, C.c_void_p]),
+    'mod16_et2_f32': (C.c_int, [
+        C.c_void_p, C.c_void_p, C.c_int, _PP, _I64P, _PP, _I64P, C.c_int64, C.c_int64,
+        C.c_void_p, C.c_void_p, _PP, C.c_uint, C.c_int, C.c_void_p]),
     'mod16_et_pet_f64': (C.c_int, [
         C.c_void_p, C.c_void_p, _PP, _I64P, _PP, _I64P, C.c_int64, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_void_p]),
@@ -291,6 +298,20 @@ class Context:
             ptr_array(params) if params is not None else None,
             i64_array(pstride) if pstride is not None else None,
             int(n), out_day, out_night,
+            ptr_array(out_sep) if out_sep is not None else None,
+            int(flags), int(where), stream))
+
+    def et2(self, dtype, cls, cls_kind, drivers, dkind, params, pkind, inner, n,
+            out_day, out_night, out_sep, flags=MATH_FAST, where=HOST, stream=None):
+        '''mod16_et2_f64 / mod16_et2_f32: as ``et`` with a broadcast kind
+        (``BC_*``) per input instead of a 0 / 1 stride.'''
+        fn = self.lib.mod16_et2_f32 if np.dtype(dtype) == np.float32 \
+            else self.lib.mod16_et2_f64
+        self.check(fn(
+            self.handle, cls, int(cls_kind), ptr_array(drivers), i64_array(dkind),
+            ptr_array(params) if params is not None else None,
+            i64_array(pkind) if pkind is not None else None,
+            int(inner), int(n), out_day, out_night,
             ptr_array(out_sep) if out_sep is not None else None,
             int(flags), int(where), stream))
 

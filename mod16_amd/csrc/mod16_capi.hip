@@ -70,6 +70,8 @@ struct mod16_ctx {
     std::mutex launch_mu;            // HOST mode: kernel launches of the staging threads
     void* scalars = nullptr;         // device copies of broadcast scalars
     unsigned long long* force_counter = nullptr;   // ticket counter to use instead of the ring (graph capture)
+    void* bc_buf = nullptr;          // HOST mode: device copies of (N,) / (T, 1) inputs (mod16_et2_*)
+    size_t bc_bytes = 0;
     void* batch_buf = nullptr;       // HOST-mode workspace of mod16_et_static_batch_*
     size_t batch_bytes = 0;
     std::string err;
@@ -132,6 +134,7 @@ extern "C" int mod16_destroy(mod16_ctx* ctx) {
     }
     if (ctx->scalars) (void)hipFree(ctx->scalars);
     if (ctx->batch_buf) (void)hipFree(ctx->batch_buf);
+    if (ctx->bc_buf) (void)hipFree(ctx->bc_buf);
     if (ctx->lut64) (void)hipFree(ctx->lut64);
     if (ctx->lut32) (void)hipFree(ctx->lut32);
     if (ctx->tab64) (void)hipFree(ctx->tab64);
@@ -424,6 +427,10 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     return ws_release(ctx, st);
 }
 
+template <typename T> static bool has_rows_or_cols(const EtArgs<T>& a) {
+    return (a.row_drv | a.col_drv | a.row_par | a.col_par) != 0u || (a.cls && a.cls_mode != MOD16_BC_DENSE);
+}
+
 // ddiag != NULL: also produce the diagnostics vector (device, 8 doubles).
 template <typename T>
 static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st,
@@ -450,7 +457,9 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
         if (k >= 2 && a.out[k]) sep = true;
     }
     const bool dense = a.dense_drv == 0x3fffu;
-    const int64_t nbody = aligned ? (a.n / V) * V : 0;
+    // (N,) rows or (T, 1) columns among the inputs: the one-pixel-per-thread kernel
+    // indexes them; the vector kernels see plain dense arrays and scalars only
+    const int64_t nbody = (aligned && !has_rows_or_cols(a)) ? (a.n / V) * V : 0;
     bool fused_diag = false;
     // dense class rasters with one of the supported output sets take the
     // production pipeline (mod16_stream.hpp), everything else the plain kernel
@@ -525,10 +534,11 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
         EtArgs<T> t = a;
         const int64_t off = nbody;
         for (int k = 0; k < 14; ++k) if ((t.dense_drv >> k) & 1u) t.drv[k] += off;
-        if (lut) t.cls += off;
+        if (lut) { if (t.cls_mode == MOD16_BC_DENSE) t.cls += off; }
         else for (int k = 0; k < 11; ++k) if ((t.dense_par >> k) & 1u) t.par[k] += off;
         for (int k = 0; k < 10; ++k) if (t.out[k]) t.out[k] += off;
         t.n = a.n - off;
+        t.base = a.base + off;
         launch_variant<T, 1>(t, lut, fast, sep, dense, grid_for(ctx, t.n), st);
     }
     HIPCHK(ctx, hipGetLastError());
@@ -539,30 +549,43 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
     return MOD16_OK;
 }
 
+// dstride / pstride hold a broadcast kind per array: MOD16_BC_SCALAR (0), MOD16_BC_DENSE (1)
+// and, with inner > 0 (mod16_et2_*), MOD16_BC_ROW (2) / MOD16_BC_COL (3).
 template <typename T>
 static int fill_args(mod16_ctx* ctx, EtArgs<T>& a, const uint8_t* cls, const T* const* drivers,
                      const int64_t* dstride, const T* const* params, const int64_t* pstride,
                      int64_t n, T* out_day, T* out_night, T* const* out_sep,
-                     T* pet_day = nullptr, T* pet_night = nullptr) {
+                     T* pet_day = nullptr, T* pet_night = nullptr, int64_t inner = 0,
+                     int cls_mode = MOD16_BC_DENSE) {
     if (!ctx) return MOD16_ERR_ARG;
     if (!drivers || !dstride || n < 0) return fail(ctx, MOD16_ERR_ARG, "mod16_et: NULL drivers/strides or n < 0");
     memset(&a, 0, sizeof a);
+    const int64_t max_kind = inner > 0 ? MOD16_BC_COL : MOD16_BC_DENSE;
+    if (inner > 0 && n % inner != 0) return fail(ctx, MOD16_ERR_ARG, "mod16_et2: n must be a multiple of inner");
+    a.inner = inner > 0 ? inner : 1;
+    a.base = 0;
     for (int k = 0; k < 14; ++k) {
         if (!drivers[k]) return fail(ctx, MOD16_ERR_ARG, "mod16_et: NULL driver array");
-        if (dstride[k] != 0 && dstride[k] != 1) return fail(ctx, MOD16_ERR_ARG, "mod16_et: driver stride must be 0 or 1");
+        if (dstride[k] < 0 || dstride[k] > max_kind) return fail(ctx, MOD16_ERR_ARG, "mod16_et: driver stride must be 0 or 1 (mod16_et2: a MOD16_BC_* kind)");
         a.drv[k] = drivers[k];
-        if (dstride[k]) a.dense_drv |= 1u << k;
+        if (dstride[k] == MOD16_BC_DENSE) a.dense_drv |= 1u << k;
+        if (dstride[k] == MOD16_BC_ROW) a.row_drv |= 1u << k;
+        if (dstride[k] == MOD16_BC_COL) a.col_drv |= 1u << k;
     }
     a.cls = cls;
+    a.cls_mode = (uint32_t)cls_mode;
     if (cls) {
         if (!ctx->have_lut) return fail(ctx, MOD16_ERR_NO_BPLUT, "mod16_et: class raster given but mod16_set_bplut_f64 was not called");
+        if (cls_mode < 0 || cls_mode > max_kind) return fail(ctx, MOD16_ERR_ARG, "mod16_et2: bad broadcast kind of the class raster");
     } else {
         if (!params || !pstride) return fail(ctx, MOD16_ERR_ARG, "mod16_et: neither a class raster nor parameter arrays given");
         for (int k = 0; k < 11; ++k) {
             if (!params[k]) return fail(ctx, MOD16_ERR_ARG, "mod16_et: NULL parameter array");
-            if (pstride[k] != 0 && pstride[k] != 1) return fail(ctx, MOD16_ERR_ARG, "mod16_et: parameter stride must be 0 or 1");
+            if (pstride[k] < 0 || pstride[k] > max_kind) return fail(ctx, MOD16_ERR_ARG, "mod16_et: parameter stride must be 0 or 1 (mod16_et2: a MOD16_BC_* kind)");
             a.par[k] = params[k];
-            if (pstride[k]) a.dense_par |= 1u << k;
+            if (pstride[k] == MOD16_BC_DENSE) a.dense_par |= 1u << k;
+            if (pstride[k] == MOD16_BC_ROW) a.row_par |= 1u << k;
+            if (pstride[k] == MOD16_BC_COL) a.col_par |= 1u << k;
         }
     }
     a.out[0] = out_day;
@@ -595,32 +618,49 @@ static int read_status(mod16_ctx* ctx, hipStream_t st) {
 // are what bounds this mode (the HIP runtime stages them through its own pinned
 // buffers on the calling thread), so the slots run them concurrently; kernel
 // launches are serialised (they share the context's workspace).
+// device copies of the inputs that are neither dense nor scalars: (N,) rows and
+// (T, 1) columns, uploaded whole once per call
+template <typename T> struct BcTable {
+    const T* drv[14] = {};
+    const T* par[11] = {};
+    const uint8_t* cls = nullptr;
+};
+
 template <typename T>
 static int stage_tile(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags, const T* dscal,
-                      size_t per_arr, int slot, int64_t off, int64_t m) {
+                      size_t per_arr, int slot, int64_t off, int64_t m, const BcTable<T>& bc) {
     hipStream_t st = ctx->streams[slot];
     char* base = static_cast<char*>(ctx->slab[slot]);
     EtArgs<T> d = h;
     d.n = m;
+    d.base = off;
     for (int k = 0; k < 14; ++k) {
         if ((h.dense_drv >> k) & 1u) {
             T* dp = reinterpret_cast<T*>(base + per_arr * k);
             HIPCHK(ctx, hipMemcpyAsync(dp, h.drv[k] + off, sizeof(T) * m, hipMemcpyHostToDevice, st));
             d.drv[k] = dp;
+        } else if (bc.drv[k]) {
+            d.drv[k] = bc.drv[k];
         } else {
             d.drv[k] = dscal + k;
         }
     }
     if (h.cls) {
-        uint8_t* dc = reinterpret_cast<uint8_t*>(base + per_arr * 35);
-        HIPCHK(ctx, hipMemcpyAsync(dc, h.cls + off, (size_t)m, hipMemcpyHostToDevice, st));
-        d.cls = dc;
+        if (h.cls_mode == MOD16_BC_DENSE) {
+            uint8_t* dc = reinterpret_cast<uint8_t*>(base + per_arr * 35);
+            HIPCHK(ctx, hipMemcpyAsync(dc, h.cls + off, (size_t)m, hipMemcpyHostToDevice, st));
+            d.cls = dc;
+        } else {
+            d.cls = bc.cls;
+        }
     } else {
         for (int k = 0; k < 11; ++k) {
             if ((h.dense_par >> k) & 1u) {
                 T* dp = reinterpret_cast<T*>(base + per_arr * (14 + k));
                 HIPCHK(ctx, hipMemcpyAsync(dp, h.par[k] + off, sizeof(T) * m, hipMemcpyHostToDevice, st));
                 d.par[k] = dp;
+            } else if (bc.par[k]) {
+                d.par[k] = bc.par[k];
             } else {
                 d.par[k] = dscal + 14 + k;
             }
@@ -667,6 +707,47 @@ static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
     for (int k = 0; k < 11; ++k) hs[14 + k] = (!h.cls && !((h.dense_par >> k) & 1u)) ? h.par[k][0] : T(0);
     HIPCHK(ctx, hipMemcpy(ctx->scalars, hs, sizeof(T) * 25, hipMemcpyHostToDevice));
     const T* dscal = static_cast<const T*>(ctx->scalars);
+    // (N,) rows and (T, 1) columns: whole, once, next to the tiles
+    BcTable<T> bc;
+    if (has_rows_or_cols(h)) {
+        const int64_t nrow = h.inner, ncol = n / h.inner;
+        auto len_of = [&](bool row) { return (size_t)(row ? nrow : ncol); };
+        size_t need_bc = 256;
+        for (int k = 0; k < 14; ++k)
+            if (((h.row_drv | h.col_drv) >> k) & 1u) need_bc += (len_of((h.row_drv >> k) & 1u) * sizeof(T) + 255) / 256 * 256;
+        for (int k = 0; k < 11 && !h.cls; ++k)
+            if (((h.row_par | h.col_par) >> k) & 1u) need_bc += (len_of((h.row_par >> k) & 1u) * sizeof(T) + 255) / 256 * 256;
+        if (h.cls && h.cls_mode != MOD16_BC_DENSE)
+            need_bc += (h.cls_mode == MOD16_BC_SCALAR ? 1 : len_of(h.cls_mode == MOD16_BC_ROW)) + 256;
+        if (ctx->bc_bytes < need_bc) {
+            if (ctx->bc_buf) HIPCHK(ctx, hipFree(ctx->bc_buf));
+            ctx->bc_buf = nullptr;
+            ctx->bc_bytes = 0;
+            HIPCHK(ctx, hipMalloc(&ctx->bc_buf, need_bc));
+            ctx->bc_bytes = need_bc;
+        }
+        char* cur = static_cast<char*>(ctx->bc_buf);
+        auto up = [&](const void* src, size_t bytes) -> const void* {
+            char* p = cur;
+            if (hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+            cur += (bytes + 255) / 256 * 256;
+            return p;
+        };
+        for (int k = 0; k < 14; ++k)
+            if (((h.row_drv | h.col_drv) >> k) & 1u) {
+                bc.drv[k] = static_cast<const T*>(up(h.drv[k], len_of((h.row_drv >> k) & 1u) * sizeof(T)));
+                if (!bc.drv[k]) return fail(ctx, MOD16_ERR_HIP, "mod16_et2: upload of a broadcast input failed");
+            }
+        for (int k = 0; k < 11 && !h.cls; ++k)
+            if (((h.row_par | h.col_par) >> k) & 1u) {
+                bc.par[k] = static_cast<const T*>(up(h.par[k], len_of((h.row_par >> k) & 1u) * sizeof(T)));
+                if (!bc.par[k]) return fail(ctx, MOD16_ERR_HIP, "mod16_et2: upload of a broadcast input failed");
+            }
+        if (h.cls && h.cls_mode != MOD16_BC_DENSE) {
+            bc.cls = static_cast<const uint8_t*>(up(h.cls, h.cls_mode == MOD16_BC_SCALAR ? 1 : len_of(h.cls_mode == MOD16_BC_ROW)));
+            if (!bc.cls) return fail(ctx, MOD16_ERR_HIP, "mod16_et2: upload of the class raster failed");
+        }
+    }
     // the kernels' shared workspace at its final size before any thread launches
     {
         const int64_t npiece = (tile / VecOf<T>::v + 63) / 64;
@@ -675,7 +756,7 @@ static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
     }
     if (nslots == 1) {
         for (int64_t off = 0; off < n; off += tile) {
-            int rc = stage_tile<T>(ctx, h, flags, dscal, per_arr, 0, off, std::min(tile, n - off));
+            int rc = stage_tile<T>(ctx, h, flags, dscal, per_arr, 0, off, std::min(tile, n - off), bc);
             if (rc != MOD16_OK) return rc;
         }
     } else {
@@ -685,7 +766,7 @@ static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
             workers.emplace_back([&, s]() {
                 if (hipSetDevice(ctx->device) != hipSuccess) { rcs[s] = MOD16_ERR_HIP; return; }
                 for (int64_t t = s; t < ntiles && rcs[s] == MOD16_OK; t += nslots)
-                    rcs[s] = stage_tile<T>(ctx, h, flags, dscal, per_arr, s, t * tile, std::min(tile, n - t * tile));
+                    rcs[s] = stage_tile<T>(ctx, h, flags, dscal, per_arr, s, t * tile, std::min(tile, n - t * tile), bc);
             });
         for (auto& w : workers) w.join();
         for (int s = 0; s < nslots; ++s)
@@ -699,10 +780,11 @@ template <typename T>
 static int et_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drivers,
                     const int64_t* dstride, const T* const* params, const int64_t* pstride,
                     int64_t n, T* out_day, T* out_night, T* const* out_sep, unsigned flags,
-                    int where, void* stream, T* pet_day = nullptr, T* pet_night = nullptr) {
+                    int where, void* stream, T* pet_day = nullptr, T* pet_night = nullptr,
+                    int64_t inner = 0, int cls_mode = MOD16_BC_DENSE) {
     EtArgs<T> a;
     int rc = fill_args<T>(ctx, a, cls, drivers, dstride, params, pstride, n, out_day, out_night,
-                          out_sep, pet_day, pet_night);
+                          out_sep, pet_day, pet_night, inner, cls_mode);
     if (rc != MOD16_OK) return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (where == MOD16_DEVICE) return launch_et<T>(ctx, a, flags, static_cast<hipStream_t>(stream));
@@ -727,6 +809,27 @@ extern "C" int mod16_et_f32(mod16_ctx* ctx, const uint8_t* cls, const float* con
     MOD16_LOCK(ctx);
     return et_entry<float>(ctx, cls, drivers, dstride, params, pstride, n, out_day, out_night,
                            out_sep, flags, where, stream);
+}
+
+extern "C" int mod16_et2_f64(mod16_ctx* ctx, const uint8_t* cls, int cls_kind,
+                             const double* const* drivers, const int64_t* dkind,
+                             const double* const* params, const int64_t* pkind, int64_t inner,
+                             int64_t n, double* out_day, double* out_night,
+                             double* const* out_sep, unsigned flags, int where, void* stream) {
+    MOD16_LOCK(ctx);
+    if (ctx && inner <= 0) return fail(ctx, MOD16_ERR_ARG, "mod16_et2: inner must be positive");
+    return et_entry<double>(ctx, cls, drivers, dkind, params, pkind, n, out_day, out_night,
+                            out_sep, flags, where, stream, nullptr, nullptr, inner, cls_kind);
+}
+extern "C" int mod16_et2_f32(mod16_ctx* ctx, const uint8_t* cls, int cls_kind,
+                             const float* const* drivers, const int64_t* dkind,
+                             const float* const* params, const int64_t* pkind, int64_t inner,
+                             int64_t n, float* out_day, float* out_night, float* const* out_sep,
+                             unsigned flags, int where, void* stream) {
+    MOD16_LOCK(ctx);
+    if (ctx && inner <= 0) return fail(ctx, MOD16_ERR_ARG, "mod16_et2: inner must be positive");
+    return et_entry<float>(ctx, cls, drivers, dkind, params, pkind, n, out_day, out_night,
+                           out_sep, flags, where, stream, nullptr, nullptr, inner, cls_kind);
 }
 
 template <typename T>

@@ -32,6 +32,14 @@ template <typename T> struct EtArgs {
     unsigned* status;
     uint32_t dense_drv;    // bit k set: driver k is a dense array, else a broadcast scalar
     uint32_t dense_par;
+    // 2-level broadcasting of the reference's (N,) against (T, N) inputs
+    // (mod16/__init__.py:180-181): pixel g = base + i of the flattened (T, N) raster
+    // reads element g % inner of a ROW input ((N,), one value per site) and g / inner
+    // of a COL input ((T, 1), one value per time step). Only the one-pixel-per-thread
+    // kernels look at these (a ROW / COL input sends the whole call there).
+    uint32_t row_drv, col_drv, row_par, col_par;
+    uint32_t cls_mode;     // MOD16_BC_* of the class raster
+    int64_t inner, base;
 };
 
 template <typename T, int V> struct Vec;
@@ -40,6 +48,14 @@ template <> struct Vec<double, 1> { typedef double type; };
 template <> struct Vec<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
 template <> struct Vec<float, 2> { typedef float type __attribute__((ext_vector_type(2))); };
 template <> struct Vec<float, 1> { typedef float type; };
+
+// index of pixel (i local, g global) in an input of the given broadcast kind
+struct BcIndex {
+    int64_t i, r, c;       // local dense index, g / inner, g % inner
+    __device__ __forceinline__ int64_t of(bool dense, bool row, bool col) const {
+        return dense ? i : (row ? c : (col ? r : 0));
+    }
+};
 
 template <typename T, int V, bool DENSE>
 __device__ __forceinline__ void load_vec(const T* __restrict__ p, bool dense, int64_t i,
@@ -99,11 +115,30 @@ __global__ void __launch_bounds__(kBlock) et_kernel(const EtArgs<T> a) {
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += step) {
         const int64_t i = v * V;
         T in[14][V];
+        unsigned cbits = 0;
+        T pin[11][V];
+        if constexpr (V == 1 && !DENSE) {
+            // every broadcast kind (scalar, dense, (N,) rows, (T, 1) columns)
+            BcIndex ix = {i, 0, 0};
+            if ((a.row_drv | a.col_drv | a.row_par | a.col_par) != 0u || a.cls_mode >= 2u) {
+                const int64_t g = a.base + i;
+                ix.r = g / a.inner;
+                ix.c = g - ix.r * a.inner;
+            }
+#pragma unroll
+            for (int k = 0; k < 14; ++k)
+                in[k][0] = a.drv[k][ix.of((a.dense_drv >> k) & 1u, (a.row_drv >> k) & 1u, (a.col_drv >> k) & 1u)];
+            if (LUT) {
+                cbits = a.cls[ix.of(a.cls_mode == 1u, a.cls_mode == 2u, a.cls_mode == 3u)];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 11; ++k)
+                    pin[k][0] = a.par[k][ix.of((a.dense_par >> k) & 1u, (a.row_par >> k) & 1u, (a.col_par >> k) & 1u)];
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < 14; ++k)
             load_vec<T, V, DENSE>(a.drv[k], (a.dense_drv >> k) & 1u, i, in[k]);
-        unsigned cbits = 0;
-        T pin[11][V];
         if (LUT) {
             if constexpr (V == 1) cbits = a.cls[i];
             else if constexpr (V == 2) cbits = *reinterpret_cast<const uint16_t*>(a.cls + i);
@@ -112,6 +147,7 @@ __global__ void __launch_bounds__(kBlock) et_kernel(const EtArgs<T> a) {
 #pragma unroll
             for (int k = 0; k < 11; ++k)
                 load_vec<T, V, false>(a.par[k], (a.dense_par >> k) & 1u, i, pin[k]);
+        }
         }
         T res[10][V];
 #pragma unroll

@@ -374,3 +374,80 @@ def test_scalar_drivers_over_many_tiles(m16, golden):
     want = m16.evapotranspiration_raster(f['table'], cls, *drv_d, pet=True)
     for a, b, what in zip(got, want, ('day', 'night', 'pet day', 'pet night')):
         assert_parity(a, b, 1e-12, what)
+
+
+def test_f9_rows_and_columns_against_the_reference(m16, golden):
+    """(N,) rows, a (T, 1) column and a scalar against (T, N) drivers with per-site
+    (N,) parameter arrays -- the reference's own outputs (tests/golden/f9_round2.npz),
+    through mod16_et2_* (nothing made dense on the host)."""
+    f = golden('f9_round2')
+    names = m16.MOD16.required_parameters
+    site_par = {k: f['bcast_site_params'][j] for j, k in enumerate(names)}
+    dense = list(f['bcast_dense'])
+    lw_d, lw_n, sw_d, t_d, t_n, tmin, vpd_d, vpd_n, fpar, lai = dense
+    drv = [lw_d, lw_n, sw_d, 0, f['bcast_albedo'], t_d, t_n, f['bcast_temp_annual'], tmin,
+           vpd_d, vpd_n, f['bcast_pressure'], fpar, lai]
+    seen = []
+    real = m16._lib.Context.et2
+
+    def spy(self, dtype, cls, ckind, drivers, dkind, params, pkind, inner, n, *a, **k):
+        seen.append((list(dkind), list(pkind) if pkind is not None else None, inner, n))
+        return real(self, dtype, cls, ckind, drivers, dkind, params, pkind, inner, n, *a, **k)
+
+    m16._lib.Context.et2 = spy
+    try:
+        for math, rtol in ((m16._lib.MATH_FAST, 1e-8), (m16._lib.MATH_EXACT, 1e-10)):
+            model = m16.MOD16(site_par)
+            model.math = math
+            day, night = model.evapotranspiration(*drv)
+            assert_parity(day, f['bcast_day'], rtol, 'day')
+            assert_parity(night, f['bcast_night'], rtol, 'night')
+            sep = model.evapotranspiration(*drv, separate=True)
+            for name, got in zip(('canopy_day', 'soil_day', 'trans_day', 'canopy_night', 'soil_night',
+                                  'trans_night'), list(sep[0]) + list(sep[1])):
+                assert_parity(got, f['bcast_' + name], 10 * rtol, name)
+    finally:
+        m16._lib.Context.et2 = real
+    T, N = f['bcast_day'].shape
+    B = m16._lib
+    assert seen and all(s[2] == N and s[3] == T * N for s in seen)
+    assert seen[0][0] == [1, 1, 1, B.BC_SCALAR, B.BC_COL, 1, 1, B.BC_ROW, 1, 1, 1, B.BC_ROW, 1, 1]
+    assert seen[0][1] == [B.BC_ROW] * 11
+    # the class-raster form: a per-site PFT vector against (T, N) drivers
+    table = np.full((13, 11), np.nan)
+    for j in range(N):
+        table[int(f['bcast_site_cls'][j])] = f['bcast_site_params'][:, j]
+    day, night = m16.evapotranspiration_raster(table, f['bcast_site_cls'], *drv)
+    assert_parity(day, f['bcast_day'], 1e-8, 'day (class vector)')
+    assert_parity(night, f['bcast_night'], 1e-8, 'night (class vector)')
+
+
+def test_rows_and_columns_over_several_staged_tiles(m16):
+    """The same kinds on a raster of more than one staged tile (2 Mi pixels), float64
+    and float32, against the oracle on the broadcast inputs."""
+    from oracle import synth
+    from mod16_amd.utils import restore_bplut, bplut_table
+    from mod16_amd.models import COLLECTION61_BPLUT
+    table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    T, N = 37, 70001
+    cls, drv = synth.drivers((T, N), seed=61)
+    site_cls = cls[0].copy()
+    mixed = list(drv)
+    mixed[7] = drv[7][0].copy()            # temp_annual (N,)
+    mixed[11] = drv[11][0].copy()          # pressure (N,)
+    mixed[4] = drv[4][:, :1].copy()        # albedo (T, 1)
+    mixed[3] = 0.0
+    full = [np.broadcast_to(np.asarray(v, np.float64), (T, N)) for v in mixed]
+    want = oracle.evapotranspiration_raster(bplut, np.broadcast_to(site_cls, (T, N)), *full)
+    got = m16.evapotranspiration_raster(table, site_cls, *mixed)
+    assert_parity(got[0], want[0], 1e-8, 'day')
+    assert_parity(got[1], want[1], 1e-8, 'night')
+    m32 = [np.asarray(v, np.float32) if isinstance(v, np.ndarray) else v for v in mixed]
+    got32 = m16.evapotranspiration_raster(table, site_cls, *m32)
+    want32 = oracle.evapotranspiration_raster(
+        bplut, np.broadcast_to(site_cls, (T, N)),
+        *[np.broadcast_to(np.asarray(v, np.float64), (T, N)) for v in m32])
+    assert got32[0].dtype == np.float32
+    assert_parity(got32[0], want32[0].astype(np.float32), 1e-6, 'day f32')
+    assert_parity(got32[1], want32[1].astype(np.float32), 1e-6, 'night f32')

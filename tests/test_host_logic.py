@@ -115,3 +115,34 @@ def test_result_arrays_fall_back_to_numpy_without_a_gpu():
     assert a.sum() == 2.0 * 1200 * 1200
     small = _lib.pinned.empty((10,), np.float32)
     assert small.base is None and small.dtype == np.float32
+
+
+def test_broadcast_kinds_are_not_made_dense():
+    """(N,) rows and (T, 1) columns against (T, N) drivers (reference
+    mod16/__init__.py:180-181, notebook cell 17) go to the C ABI as they are:
+    the marshalling hands over N (or T) elements and a broadcast kind, no (T, N)
+    temporary."""
+    import numpy as np
+    import mod16_amd
+    from mod16_amd import _lib
+    T, N = 7, 50
+    kind = mod16_amd._broadcast_kind
+    assert kind((), 1, (T, N)) == _lib.BC_SCALAR
+    assert kind((1, 1), 1, (T, N)) == _lib.BC_SCALAR
+    assert kind((T, N), T * N, (T, N)) == _lib.BC_DENSE
+    assert kind((N,), N, (T, N)) == _lib.BC_ROW
+    assert kind((1, N), N, (T, N)) == _lib.BC_ROW
+    assert kind((T, 1), T, (T, N)) == _lib.BC_COL
+    assert kind((N,), N, (3, T, N)) == _lib.BC_ROW
+    assert kind((3, T, 1), 3 * T, (3, T, N)) == _lib.BC_COL
+    assert kind((T, 1), T, (3, T, N)) is None            # another pattern: made dense
+    assert kind((N,), N, (N,)) == _lib.BC_DENSE
+    values = [np.ones((T, N)), np.arange(N, dtype=float), np.arange(T, dtype=float)[:, None], 3.0,
+              np.ones((1, N), np.float32)]
+    keep, ptrs, kinds = mod16_amd._marshal(values, (T, N), np.float64, kinds=True)
+    assert kinds == [_lib.BC_DENSE, _lib.BC_ROW, _lib.BC_COL, _lib.BC_SCALAR, _lib.BC_ROW]
+    assert [a.size for a in keep] == [T * N, N, T, 1, N]
+    assert all(a.flags.c_contiguous and a.dtype == np.float64 for a in keep)
+    # without the switch everything but scalars is dense, as before
+    keep, ptrs, strides = mod16_amd._marshal(values, (T, N), np.float64)
+    assert strides == [1, 1, 1, 0, 1] and [a.size for a in keep] == [T * N, T * N, T * N, 1, T * N]
