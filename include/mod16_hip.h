@@ -479,6 +479,15 @@ MOD16_API int mod16_synth_tiled_f32(mod16_ctx* ctx, const mod16_layout* layout,
                        uint64_t seed, int64_t step, int64_t pixel_offset, int64_t n,
                        uint8_t* cls, float* const* drivers, void* stream);
 
+/* mod16_time_et for a tiled raster: `launches` back-to-back direct (not captured)
+ * launches of mod16_et_tiled_*, HIP events on `stream`, mean milliseconds per launch.
+ * For steps shorter than a graph replay's fixed cost (a 1200 x 1200 tile) this is
+ * the faster way to issue them, and how bench.py times configs[1]. */
+MOD16_API int mod16_time_et_tiled(mod16_ctx* ctx, int is_f32, const mod16_layout* layout,
+                       const uint8_t* cls, const void* const* drivers, int64_t n,
+                       void* out_day, void* out_night, unsigned flags, double* ddiag,
+                       int launches, void* stream, float* ms);
+
 /* Mean milliseconds per replay of a captured step: `launches` back-to-back
  * mod16_graph_launch calls bracketed by HIP events on `stream`. Synchronous. */
 MOD16_API int mod16_time_graph(mod16_graph* graph, int launches, void* stream, float* ms);

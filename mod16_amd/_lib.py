@@ -157,6 +157,9 @@ PROTOTYPES = {
     'mod16_synth_tiled_f32': (C.c_int, [
         C.c_void_p, _LAYP, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
         _PP, C.c_void_p]),
+    'mod16_time_et_tiled': (C.c_int, [
+        C.c_void_p, C.c_int, _LAYP, C.c_void_p, _PP, C.c_int64, C.c_void_p, C.c_void_p,
+        C.c_uint, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     'mod16_time_graph': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     'mod16_host_alloc': (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
     'mod16_host_free': (C.c_int, [C.c_void_p]),

@@ -46,6 +46,7 @@ struct mod16_ctx {
     bool use_dma = true;             // production pipeline (mod16_stream.hpp); MOD16_NO_DMA=1: plain kernels only
     int host_threads = 8;            // MOD16_HOST_THREADS: staging threads of the HOST mode (1..kSlots)
     int run_shift = -1;              // MOD16_RUN_SHIFT: force 2^k pieces per run (experiments)
+    int static_below = 8;            // MOD16_STATIC_BELOW: runs per wave below which runs are dealt out statically (0: never)
     int use_pitch = 1;               // scalar base + pitch addressing for slab layouts (MOD16_PITCH=0: off)
     unsigned long long* dyn_counters = nullptr;   // ring of ticket counters, 128 B apart
     int dyn_next = 0;
@@ -173,6 +174,7 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
         if (const char* g = getenv("MOD16_PITCH")) ctx->use_pitch = atoi(g);
         if (const char* g = getenv("MOD16_HOST_THREADS")) ctx->host_threads = std::max(1, std::min(kSlots, atoi(g)));
         if (const char* g = getenv("MOD16_RUN_SHIFT")) ctx->run_shift = std::max(1, std::min(4, atoi(g)));
+        if (const char* g = getenv("MOD16_STATIC_BELOW")) ctx->static_below = std::max(0, std::min(64, atoi(g)));
         HIPCHK(ctx, hipMalloc(&ctx->dyn_counters, 64 * 128));
         const size_t nlut = MOD16_LUT_ROWS * kLutCols;
         HIPCHK(ctx, hipMalloc(&ctx->lut64, nlut * sizeof(double)));
@@ -353,7 +355,7 @@ static int reduce_entry(mod16_ctx* ctx, const T* day, const T* night, int64_t n,
                         double* ddiag, void* stream);
 
 // Launch geometry of the production pipeline for n pixels, V per 16-byte vector.
-struct StreamGeom { int run_shift; int64_t npiece, nruns; int grid; };
+struct StreamGeom { int run_shift; int64_t npiece, nruns; int grid; int static_sched; };
 static StreamGeom stream_geom(const mod16_ctx* ctx, int64_t n, int V, int tile_shift = kNoTile) {
     StreamGeom g;
     g.npiece = (n / V + 63) / 64;
@@ -363,6 +365,16 @@ static StreamGeom stream_geom(const mod16_ctx* ctx, int64_t n, int V, int tile_s
     int run_shift = 0;
     while ((1 << run_shift) < kDynRun) ++run_shift;
     while (run_shift > 1 && (g.npiece >> run_shift) < chip_waves) --run_shift;   // >= 2 pieces: the claim of a run is consumed in its second iteration
+    // A small raster (fewer than kStaticBelow runs per wave) is latency-bound and ends
+    // with its slowest wave: runs of 2 pieces dealt out round-robin -- all waves start
+    // together, so this is balanced to within one run, and no claim's round trip sits
+    // on a path that is only a few iterations long (1200 x 1200: 6 pieces at most per
+    // wave instead of 8).
+    g.static_sched = 0;
+    if (ctx->static_below > 0 && (g.npiece >> run_shift) < (int64_t)ctx->static_below * chip_waves) {
+        g.static_sched = 1;
+        run_shift = 1;
+    }
     if (ctx->run_shift > 0) run_shift = ctx->run_shift;
     run_shift = std::min(run_shift, tile_shift);     // a run never straddles two tiles
     g.run_shift = run_shift;
@@ -394,6 +406,7 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     }
     const StreamGeom g = stream_geom(ctx, s.n, V, s.tile_shift);
     s.run_shift = g.run_shift;
+    s.static_sched = g.static_sched;
     const int64_t nruns = g.nruns;
     const int grid = g.grid;
     DiagWs* ws = nullptr;
@@ -1859,6 +1872,34 @@ extern "C" int mod16_graph_et_tiled_f32(mod16_ctx* ctx, const mod16_layout* layo
                                         mod16_graph** out) {
     MOD16_LOCK(ctx);
     return graph_tiled_entry<float>(ctx, layout, cls, drivers, n, out_day, out_night, flags, ddiag, out);
+}
+
+extern "C" int mod16_time_et_tiled(mod16_ctx* ctx, int is_f32, const mod16_layout* layout,
+                                   const uint8_t* cls, const void* const* drivers, int64_t n,
+                                   void* out_day, void* out_night, unsigned flags, double* ddiag,
+                                   int launches, void* stream, float* ms) {
+    MOD16_LOCK(ctx);
+    if (!ctx || !ms || launches <= 0) return fail(ctx, MOD16_ERR_ARG, "mod16_time_et_tiled: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    HIPCHK(ctx, hipEventCreate(&e0));
+    HIPCHK(ctx, hipEventCreate(&e1));
+    int rc = MOD16_OK;
+    HIPCHK(ctx, hipEventRecord(e0, st));
+    for (int i = 0; i < launches && rc == MOD16_OK; ++i)
+        rc = is_f32 ? tiled_entry<float>(ctx, layout, cls, reinterpret_cast<const float* const*>(drivers), n,
+                                         static_cast<float*>(out_day), static_cast<float*>(out_night), flags, ddiag, stream)
+                    : tiled_entry<double>(ctx, layout, cls, reinterpret_cast<const double* const*>(drivers), n,
+                                          static_cast<double*>(out_day), static_cast<double*>(out_night), flags, ddiag, stream);
+    HIPCHK(ctx, hipEventRecord(e1, st));
+    HIPCHK(ctx, hipEventSynchronize(e1));
+    float t = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&t, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms = t / (float)launches;
+    return rc;
 }
 
 // mean milliseconds per replay of a captured step, HIP events on `stream`

@@ -99,6 +99,9 @@ template <typename T> struct StreamArgs {
     // base[(i >> log2 tile) * row + (i & (tile - 1))]. tile_shift = log2 of the PIECES
     // per tile (a piece = 64 vectors of 16 B); plain arrays: tile_shift = kNoTile, rows unused.
     int tile_shift;
+    int static_sched;          // small rasters: runs dealt out round-robin (wave w: runs w, w + nwaves, ...)
+                               // instead of claimed from the ticket counter -- every wave starts at once
+                               // and the atomic's round trip would sit on a path a few iterations long
     int64_t wide_row;          // elements between successive tiles of a wide array
     int64_t out_row;           // ... of an output array
     int64_t byte_row;          // bytes between successive tiles of a byte array
@@ -282,7 +285,9 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
         // one iteration after a claim, the claim's atomic
         if (flushed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOUT + 1) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOUT) : "memory");
-        if (run == 1) {
+        if (a.static_sched) {
+            if (run == 0) next_base = cbase + (nwaves << rs);
+        } else if (run == 1) {
             asm volatile("" : "+v"(ticket));
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ticket);
             const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ticket >> 32));
@@ -293,7 +298,7 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
         unsigned bits[NB];
         SlotRead<NW, NB>::go(in, bits, (unsigned)(uintptr_t)(lptr_t)ws + lane * 16u,
                              (unsigned)(uintptr_t)(lptr_t)ws + NW * 1024u + lane * 4u);
-        if (run == 0 && lane == 0) {
+        if (run == 0 && lane == 0 && !a.static_sched) {
             const unsigned long long one = 1;
             asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0"
                          : "=v"(ticket) : "v"(a.dyn_counter), "v"(one) : "memory");

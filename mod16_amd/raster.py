@@ -514,6 +514,18 @@ class RasterEngine(object):
         self.ctx.check(fn(self.ctx.handle, *self._tiled_args(r), dptr, self._stream()))
         return r.day, r.night
 
+    def time_tiled(self, r, launches=10, diag=None):
+        '''Mean milliseconds per direct launch of ``run_tiled`` (HIP events on the
+        current stream, ``mod16_time_et_tiled``).'''
+        torch = _torch()
+        ms = C.c_float(0)
+        lay, cls, drv, n, day, night, math = self._tiled_args(r)
+        self.ctx.check(self.ctx.lib.mod16_time_et_tiled(
+            self.ctx.handle, int(self.np_dtype == np.float32), lay, cls, drv, n, day, night, math,
+            self._check_tensor(diag, torch.float64, 8, 'diag') if diag is not None else None,
+            int(launches), self._stream(), C.byref(ms)))
+        return ms.value
+
     def bind_tiled(self, r, diag):
         '''``run_tiled(r, diag)`` captured once into a HIP graph
         (``mod16_graph_et_tiled_*``); the returned ``BoundStep`` replays it with

@@ -109,3 +109,13 @@ def test_no_kernel_spills_vector_registers(tmp_path):
     assert len(kernels) > 50
     spilling = [name for name, count in kernels if int(count) > 0]
     assert not spilling, spilling
+    # ... and none may touch scratch memory or park registers in the accumulator file
+    # (how hipcc spilled that kernel: 183 v_accvgpr_write / 263 v_accvgpr_read, no
+    # scratch): the stream kernels count their own vector-memory operations
+    # (s_waitcnt vmcnt(NOUT)), which compiler-issued scratch traffic would break
+    bodies = re.split(r'\n(_Z[^\n:]*):[^\n]*\n', text)
+    assert len(bodies) > 100
+    for name, body in zip(bodies[1::2], bodies[2::2]):
+        body = body.split('.section')[0]
+        assert not re.search(r'^\s*scratch_(load|store)', body, flags=re.M), name
+        assert not re.search(r'^\s*v_accvgpr_(read|write)', body, flags=re.M), name
