@@ -29,6 +29,39 @@ template <typename T> struct FastMath;   // float64 only: FAST kernels always co
 template <> struct FastMath<double> {
     typedef double T;
 
+    // x * m + c with two CONSTANTS m and c: one v_fma_f64 with m in a scalar register
+    // pair and c in a vector register pair. For this shape hipcc 7.2 emits v_mov_b64
+    // (copy c) + v_fmac_f64 -- two vector instructions; 28 of them per pair of pixels.
+    static __device__ __forceinline__ T fma_kk(T x, T m, T c) {
+#ifdef MOD16_NO_FMA_KK
+        return __builtin_fma(x, m, c);
+#else
+        T d;
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"(m), "v"(c));
+        return d;
+#endif
+    }
+
+    // maxNum / minNum as ONE v_max_f64 / v_min_f64. __builtin_fmax makes hipcc quiet a
+    // possible signalling NaN first (v_max_f64 x, x, x in front of every use: 20 extra
+    // vector instructions per pair of pixels); every value that reaches these is the
+    // result of arithmetic, i.e. already quiet. `k`: a constant (scalar register pair).
+    static __device__ __forceinline__ T vmax(T a, T b) {
+        T d;
+        asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+        return d;
+    }
+    static __device__ __forceinline__ T vmax_k(T a, T k) {
+        T d;
+        asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k));
+        return d;
+    }
+    static __device__ __forceinline__ T vmin_k(T a, T k) {
+        T d;
+        asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k));
+        return d;
+    }
+
     // 1/x: v_rcp_f64 (about 2^-23 relative) + one Newton step -> ~2^-45.
     static __device__ __forceinline__ T rcp(T x) {
         T r = __builtin_amdgcn_rcp(x);
@@ -44,7 +77,7 @@ template <> struct FastMath<double> {
         T y = __builtin_amdgcn_sqrt(__builtin_amdgcn_rsq(x));
         T y2 = y * y;
         T t = x * (y2 * y2);
-        y = y * __builtin_fma(-0.25, t, 1.25);
+        y = y * fma_kk(t, -0.25, 1.25);
         y2 = y * y;
         T y4 = y2 * y2;
         return (y4 * y2) * y;
@@ -62,7 +95,7 @@ template <> struct FastMath<double> {
         T kf = __builtin_rint(x * 92.33248261689366);               // 64 / ln 2
         T r = __builtin_fma(kf, -0x1.62e42fee00000p-7, x);          // ln2/64, 32-bit head
         r = __builtin_fma(kf, -0x1.a39ef35793c76p-39, r);
-        T p = __builtin_fma(r, 1.0 / 120.0, 1.0 / 24.0);            // |r| <= ln2/128
+        T p = fma_kk(r, 1.0 / 120.0, 1.0 / 24.0);                   // |r| <= ln2/128
         p = __builtin_fma(p, r, 1.0 / 6.0);
         p = __builtin_fma(p, r, 0.5);
         p = __builtin_fma(p, r, 1.0);
@@ -92,7 +125,11 @@ template <> struct FastMath<double> {
     // r - r^2/2 + ... - r^6/6 ; the host evaluates the same sequence (std::fma)
     // to make table entry 0 cancel exactly at x = 1
     static __host__ __device__ __forceinline__ T log1p_poly(T r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        T p = fma_kk(r, -1.0 / 6.0, 1.0 / 5.0);
+#else
         T p = __builtin_fma(r, -1.0 / 6.0, 1.0 / 5.0);
+#endif
         p = __builtin_fma(p, r, -0.25);
         p = __builtin_fma(p, r, 1.0 / 3.0);
         p = __builtin_fma(p, r, -0.5);
@@ -103,8 +140,8 @@ template <> struct FastMath<double> {
     // C pow semantics kept for: 0^y = 0 (y > 0), 1^y = 1 for every y incl. inf
     // and NaN (log_tab(1) = 0 exactly and y is clamped finite), x^0 = 1.
     static __device__ __forceinline__ T pow01_tab(T x, T y, const T* tb) {
-        T yc = __builtin_fmin(y, 1e300);
-        T t = __builtin_fmax(yc * log_tab(x, tb), -746.0);
+        T yc = vmin_k(y, 1e300);
+        T t = vmax_k(yc * log_tab(x, tb), -746.0);
         return exp_tab(t, tb);
     }
 };

@@ -553,6 +553,9 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
                                             const PixelShared<T>& sh, const T* tb, T t, T vpd,
                                             T rad_net, T rad_soil, T& canopy, T& soil,
                                             T& trans, T* pet = nullptr) {
+    // No implicit contraction: every fma of this function is written out, so that all
+    // kernels instantiated from it round alike (hipcc contracts a * b + c by context).
+#pragma clang fp contract(off)
     typedef FastMath<T> M;
     const T tiny = K<T>::tiny;
     const T cp = K<T>::cp;
@@ -570,19 +573,22 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     rh = __builtin_fma(__builtin_fma(-rh, esat, avp), resat, rh);
     rh = (avp < T(0)) ? T(0) : ((rh > T(1)) ? T(1) : rh);
     T rh2 = rh * rh;
-    T fwet = (rh < T(0.7)) ? T(0) : rh2 * rh2;
+    const bool dry = rh < T(0.7);                                  // :764 (NaN compares false)
+    T fwet = dry ? T(0) : rh2 * rh2;
     T omw = T(1) - fwet;
     // -- slope of the SVP curve (:1395-1397), latent heat (:121)
     T ta = (T(239.0) + t) - K<T>::t0;
     T rta = M::rcp(ta);
     T s = (T(17.38 * 239.0) * esat) * (rta * rta);
-    T lhv = (T(2.501) - T(0.002361) * tc) * T(1e6);
+    T lhv = M::fma_kk(tc, T(-0.002361e6), T(2.501e6));         // (2.501 - 0.002361 tc) 1e6, :121
     T slhv = s * lhv;
     // -- 1 / r_corr = (P / 101300) (T / 293.15)^-1.75, :771
     T inv_rcorr = sh.p_rel * M::pow_m1p75(t * T(1.0 / 293.15));
     // -- air density (:408-412) and radiative conductance 1/r_r (:947) from
     //    one reciprocal: rho = N / T, 1/r_r = 4 sigma T^4 / (Cp N)
-    T nn = sh.p_mbar_k - (rh * T(100)) * (T(0.00252) * tc - T(0.020582));
+    // p_mbar_k - (rh 100)(0.00252 tc - 0.020582); the contraction is written out so that
+    // every kernel built from this function rounds alike
+    T nn = __builtin_fma(-rh, M::fma_kk(tc, T(0.252), T(-2.0582)), sh.p_mbar_k);
     T u = M::rcp(nn * t);
     T rho_cp = cp * ((nn * nn) * u);
     T t2 = t * t;
@@ -592,15 +598,16 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     // -- wet canopy, :866-961 in conductances:
     //    1/r_a = g_h + 1/r_r ; evap = numer g_e / ((s lhv) g_e + k_p / r_a)
     {
-        T fw = (fwet == T(0)) ? tiny : fwet;                       // :934
-        T g_h = sh.glsh_l * fw;
+        // fwet is 0 exactly when rh < 0.7 (else rh^4 >= 0.24, or NaN), so the three
+        // tests on it -- fwet == 0 (:934), fw <= tiny (:961) -- are that one mask
+        T fw = dry ? tiny : fwet;                                  // :934
         T g_e = sh.glwv_l * fw;
-        T g_a = g_h + g_rr;
+        T g_a = __builtin_fma(sh.glsh_l, fw, g_rr);                // g_h + 1/r_r
         T numer = fw * __builtin_fma(rcfv * x.fpar, g_a, s * (x.fpar * rad_net));
         T den = __builtin_fma(slhv, g_e, sh.k_p * g_a);
         T evap = (numer * g_e) * M::rcp(den);
-        evap = (numer < T(0)) ? T(0) : evap;                       // :959
-        canopy = ((fw <= tiny) || sh.lai_tiny) ? T(0) : evap;      // :961
+        // numer < 0 -> 0 (:959), then fw <= tiny or lai <= tiny -> 0 (:961): one select
+        canopy = ((numer < T(0)) || dry || sh.lai_tiny) ? T(0) : evap;
     }
     // -- bare soil, :449-544 and :795-864
     {
@@ -623,7 +630,7 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
             T pot_soil = (q < T(0)) ? T(0) : __builtin_fma(q, fwet, q * omw);
             // alpha s A_c (1 - fwet) / (s + gamma) / lhv, gamma lhv = k_p
             T pot_tr = (T(kPriestleyTaylorAlpha) * (s * (x.fpar * rad_net)) * omw) *
-                       M::rcp(slhv + sh.k_p);
+                       M::rcp(__builtin_fma(s, lhv, sh.k_p));
             *pet = (canopy + pot_soil) + pot_tr;
         }
     }
@@ -633,13 +640,13 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
         if (DAY) {
             T m_vpd = (vpd >= p.vpd_close) ? T(0)
                       : ((vpd < p.vpd_open) ? T(1)
-                         : T(1) - (vpd - p.vpd_open) * p.inv_dvpd);
+                         : __builtin_fma(-(vpd - p.vpd_open), p.inv_dvpd, T(1)));
             g_s = ((p.csl * sh.m_tmin) * m_vpd) * inv_rcorr;       // :1237
         }
-        T gsc = g_s + p.g_cut * inv_rcorr;                         // :1238
+        T gsc = __builtin_fma(p.g_cut, inv_rcorr, g_s);            // :1238
         T g_bl = sh.glsh_lai * omw;                                // :1242
         T p1 = g_bl * gsc;
-        T s1 = g_bl + gsc;
+        T s1 = __builtin_fma(sh.glsh_lai, omw, gsc);               // g_bl + gsc
         bool open = sh.lai_pos && (omw > T(0));                    // :1245
         // g_canopy <= tiny  <=>  P1 <= tiny S1 (S1 > 0); NaN compares false
         bool shut = !open || (p1 <= tiny * s1);                    // :1258
@@ -656,6 +663,7 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
 template <typename T, bool PET = false>
 __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const ClassPar<T>& p,
                                                      const T* tb) {
+#pragma clang fp contract(off)
     PixelOut<T> o;
 #ifdef MOD16_TRIVIAL_BODY   // measurement aid (-DMOD16_TRIVIAL_BODY): memory pattern only, no arithmetic
     o.canopy_d = x.lw_d + x.sw_d + x.alb + x.t_d + x.t_ann + x.vpd_d + x.pa;
@@ -672,12 +680,12 @@ __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const 
     T a_n = x.lw_n;
     bool cond = (x.t_ann < T(273.15 + 25.0)) && (x.t_ann >= (K<T>::t0 + p.tmin_close)) &&
                 ((x.t_d - x.t_n) >= T(5));
-    T g_d = cond ? (T(4.73) * (x.t_d - K<T>::t0)) - T(20.87) : T(0);
+    T g_d = cond ? __builtin_fma(T(4.73), x.t_d - K<T>::t0, T(-20.87)) : T(0);
     g_d = (__builtin_fabs(g_d) > (T(0.39) * __builtin_fabs(a_d))) ? T(0.39) * a_d : g_d;
-    T g_n = cond ? (T(4.73) * (x.t_n - K<T>::t0)) - T(20.87) : T(0);
+    T g_n = cond ? __builtin_fma(T(4.73), x.t_n - K<T>::t0, T(-20.87)) : T(0);
     g_n = (__builtin_fabs(g_n) > (T(0.39) * __builtin_fabs(a_n))) ? T(0.39) * a_n : g_n;
     g_d = ((a_d - g_d < T(0)) && (a_d > T(0))) ? a_d : g_d;
-    g_n = ((a_d > T(0)) && ((a_n - g_n) < (T(-0.5) * a_d))) ? a_n + (T(0.5) * a_d) : g_n;
+    g_n = ((a_d > T(0)) && ((a_n - g_n) < (T(-0.5) * a_d))) ? __builtin_fma(T(0.5), a_d, a_n) : g_n;
     T rs_d = sh.omf * (a_d - g_d);
     T rs_n = sh.omf * (a_n - g_n);
     // -- period-independent terms

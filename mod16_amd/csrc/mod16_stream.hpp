@@ -370,8 +370,8 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
                         nan_n += (unsigned)__builtin_popcountll(__ballot(gn));
                         dsum_d += dn ? 0.0 : d;
                         dsum_n += gn ? 0.0 : g;
-                        dmax_d = __builtin_fmax(dmax_d, d);
-                        dmax_n = __builtin_fmax(dmax_n, g);
+                        dmax_d = FastMath<double>::vmax(dmax_d, d);
+                        dmax_n = FastMath<double>::vmax(dmax_n, g);
                     }
                 }
             } else {
@@ -448,8 +448,8 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
                     nan_n += (unsigned)__builtin_popcountll(__ballot(gn));
                     dsum_d += dn ? 0.0 : d;
                     dsum_n += gn ? 0.0 : g;
-                    dmax_d = __builtin_fmax(dmax_d, d);
-                    dmax_n = __builtin_fmax(dmax_n, g);
+                    dmax_d = FastMath<double>::vmax(dmax_d, d);
+                    dmax_n = FastMath<double>::vmax(dmax_n, g);
                 }
             }
             }
@@ -464,8 +464,8 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
             for (int off = 32; off > 0; off >>= 1) {
                 dsum_d += __shfl_xor(dsum_d, off, 64);
                 dsum_n += __shfl_xor(dsum_n, off, 64);
-                dmax_d = __builtin_fmax(dmax_d, __shfl_xor(dmax_d, off, 64));
-                dmax_n = __builtin_fmax(dmax_n, __shfl_xor(dmax_n, off, 64));
+                dmax_d = FastMath<double>::vmax(dmax_d, __shfl_xor(dmax_d, off, 64));
+                dmax_n = FastMath<double>::vmax(dmax_n, __shfl_xor(dmax_n, off, 64));
             }
             const double cnt_d = (double)__builtin_amdgcn_readfirstlane(nan_d);
             const double cnt_n = (double)__builtin_amdgcn_readfirstlane(nan_n);

@@ -373,7 +373,7 @@ def test_scalar_drivers_over_many_tiles(m16, golden):
     got = m16.evapotranspiration_raster(f['table'], cls, *drv_s, pet=True)
     want = m16.evapotranspiration_raster(f['table'], cls, *drv_d, pet=True)
     for a, b, what in zip(got, want, ('day', 'night', 'pet day', 'pet night')):
-        assert_parity(a, b, 1e-12, what)
+        assert_parity(a, b, 1e-11, what)     # two instantiations of one pixel function: contraction may differ
 
 
 def test_f9_rows_and_columns_against_the_reference(m16, golden):
