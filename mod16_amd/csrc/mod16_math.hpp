@@ -104,6 +104,18 @@ template <> struct FastMath<double> {
         return __builtin_amdgcn_ldexp(tb[ki & 63] * p, ki >> 6);
     }
 
+    // the same to 4e-11 (cubic): for results that end up in float32 (mod16_mixed.hpp)
+    static __device__ __forceinline__ T exp_tab3(T x, const T* tb) {
+        T kf = __builtin_rint(x * 92.33248261689366);
+        T r = __builtin_fma(kf, -0x1.62e42fee00000p-7, x);
+        r = __builtin_fma(kf, -0x1.a39ef35793c76p-39, r);
+        T p = fma_kk(r, 1.0 / 6.0, 0.5);
+        p = __builtin_fma(p, r, 1.0);
+        p = __builtin_fma(p, r, 1.0);
+        int ki = (int)kf;
+        return __builtin_amdgcn_ldexp(tb[ki & 63] * p, ki >> 6);
+    }
+
     // ln(x) for x > 0 normal (x is a relative humidity in (0, 1] here);
     // log(1) is exactly 0 by construction of table entry 0; x = 0 -> -inf.
     // Absolute error ~1e-16 (what matters: the result feeds exp(y log x)).

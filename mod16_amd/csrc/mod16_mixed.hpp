@@ -76,7 +76,8 @@ __device__ __forceinline__ void humid64(double t, double vpd, const double* tb, 
                                         bool& open_w) {
     typedef FastMath<double> M;
     double tc = t - K<double>::t0;
-    double esat = __builtin_fma(1e3 * 0.6108, M::exp_tab((17.27 * tc) * M::rcp(tc + 237.3), tb), tc * 0.0);
+    // exp to 4e-11 (cubic on the table's |r| <= ln2/128): the float32 results below keep 6e-8
+    double esat = __builtin_fma(1e3 * 0.6108, M::exp_tab3((17.27 * tc) * M::rcp(tc + 237.3), tb), tc * 0.0);
     double avp = esat - vpd;
     double resat = M::rcp(esat);
     double rh = avp * resat;
@@ -104,12 +105,12 @@ __device__ __forceinline__ Parts2 period_mixed(const ClassPar2& p, const Shared2
     f2 ta = (splat(239.0f) + t) - splat(273.15f);
     f2 rta = rcp2(ta);
     f2 s = (splat((float)(17.38 * 239.0)) * h.esat) * (rta * rta);          // :1395-1397
-    f2 lhv = (splat(2.501f) - splat(0.002361f) * tc) * splat(1e6f);          // :121
+    f2 lhv = __builtin_elementwise_fma(tc, splat(-0.002361e6f), splat(2.501e6f));   // (2.501 - 0.002361 tc) 1e6, :121
     f2 slhv = s * lhv;
     // 1 / r_corr = (P / 101300) (T / 293.15)^-1.75, :771
     f2 inv_rcorr = sh.p_rel * exp2_2(splat(-1.75f) * log2_2(t * splat((float)(1.0 / 293.15))));
     // rho Cp and 4 sigma T^3 / (rho Cp) from one reciprocal, :408-412, :947
-    f2 nn = sh.p_mbar_k - (h.rh * splat(100.f)) * (splat(0.00252f) * tc - splat(0.020582f));
+    f2 nn = sh.p_mbar_k - h.rh * __builtin_elementwise_fma(tc, splat(0.252f), splat(-2.0582f));   // (rh 100)(0.00252 tc - 0.020582)
     f2 u = rcp2(nn * t);
     f2 rho_cp = splat(1013.0f) * ((nn * nn) * u);
     f2 t2 = t * t;
@@ -123,8 +124,8 @@ __device__ __forceinline__ Parts2 period_mixed(const ClassPar2& p, const Shared2
     f2 numer = fw * ((rcfv * sh.fpar) * g_a + s * radc_raw);
     f2 den = slhv * g_e + sh.k_p * g_a;
     f2 evap = (numer * g_e) * rcp2(den);
-    evap = (numer < zero) ? zero : evap;                                     // :959
-    f2 canopy = (h.dry | sh.lai_tiny) ? zero : evap;                         // :961 (fw <= tiny <=> dry)
+    // numer < 0 -> 0 (:959), fw <= tiny (<=> dry) or lai <= tiny -> 0 (:961): one select
+    f2 canopy = ((numer < zero) | h.dry | sh.lai_tiny) ? zero : evap;
 
     // bare soil, :449-544, :795-864
     f2 r0 = (vpd <= p.vpd_open) ? p.rbl_min
@@ -174,14 +175,21 @@ __device__ __forceinline__ Parts2 period_mixed(const ClassPar2& p, const Shared2
 // the float64 BPLUT table in LDS ([row][kLutCols] layout, row stride `ls`).
 // vpd64: the two periods' VPD in float64 where the caller has it (raw drivers:
 // it is a difference of two exponentials), else NULL = the float32 inputs widened.
-template <bool PET>
+// f0 / f1: the same columns of the table rounded to float32 (a second copy in LDS: the
+// packed arithmetic wants float32 parameters, 15 per pixel, and converting them pixel by
+// pixel was 60 vector instructions per four pixels), used with LUTF; else l0 / l1 are converted.
+template <bool PET, bool LUTF = false>
 __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], const double* l0,
                                                     const double* l1, int ls, const double* tb,
                                                     Parts2& day, Parts2& night,
-                                                    const double (*vpd64)[2] = nullptr) {
+                                                    const double (*vpd64)[2] = nullptr,
+                                                    const float* f0 = nullptr, const float* f1 = nullptr) {
     const f2 zero = splat(0.f);
     auto col = [&](int k) { return f2{in[k][0], in[k][1]}; };
-    auto par = [&](int row) { return f2{(float)l0[row * ls], (float)l1[row * ls]}; };
+    auto par = [&](int row) {
+        if constexpr (LUTF) return f2{f0[row * ls], f1[row * ls]};
+        else return f2{(float)l0[row * ls], (float)l1[row * ls]};
+    };
     // ---- radiation received by the soil, :963-1119, float32
     const f2 lw_d = col(0), lw_n = col(1), sw_d = col(2), sw_n = col(3), alb = col(4);
     const f2 t_d = col(5), t_n = col(6), t_ann = col(7), fpar = col(12);

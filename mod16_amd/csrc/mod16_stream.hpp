@@ -182,6 +182,12 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
     __shared__ __attribute__((aligned(16))) double tab[kTab];
     __shared__ __attribute__((aligned(16))) char stage[(kBlock / 64) * kSlot];
     for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) lut[i] = a.lut64[i];
+    const float* lutf = nullptr;       // mixed-precision forms: the table in float32 as well
+    if constexpr (stream_is_mixed(MODE)) {
+        __shared__ float lut32[MOD16_LUT_ROWS * kLutCols];
+        for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) lut32[i] = (float)a.lut64[i];
+        lutf = lut32;
+    }
     for (int i = threadIdx.x; i < kTab; i += kBlock) tab[i] = a.tab[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -337,9 +343,9 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
                         float din[14][2];
                         double vpd64[2][2];
                         raw_pair_mixed(pin, fp, lx, tab, din, vpd64);
-                        et_pair_mixed_parts<false>(din, lut + c0, lut + c1, kLutCols, tab, pd, pn, vpd64);
+                        et_pair_mixed_parts<false, true>(din, lut + c0, lut + c1, kLutCols, tab, pd, pn, vpd64, lutf + c0, lutf + c1);
                     } else {
-                        et_pair_mixed_parts<MODE == kStreamPetMixed>(pin, lut + c0, lut + c1, kLutCols, tab, pd, pn);
+                        et_pair_mixed_parts<MODE == kStreamPetMixed, true>(pin, lut + c0, lut + c1, kLutCols, tab, pd, pn, nullptr, lutf + c0, lutf + c1);
                     }
                     const f2 day2 = (pd.canopy + pd.soil) + pd.trans;        // :792
                     const f2 night2 = (pn.canopy + pn.soil) + pn.trans;
