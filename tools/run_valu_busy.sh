@@ -7,7 +7,7 @@ rm -rf $O && mkdir -p $O
 for cfg in "float64 fast" "float32 fast" "float32 mixed"; do
   set -- $cfg
   tag=$1_$2
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc VALUBusy MemUnitStalled --output-format csv -d $O/$tag -- python3 tools/kbench.py --child --rows 21600 --launches 4 --rounds 1 --dtype $1 --math $2 > $O/$tag.out 2> $O/$tag.err || tail -3 $O/$tag.err
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc VALUBusy MemUnitStalled --output-format csv -d $O/$tag -- python3 tools/tiledbench.py --no-plain --launches 4 --rounds 1 --dtype $1 --math $2 > $O/$tag.out 2> $O/$tag.err || tail -3 $O/$tag.err
   O=$O tag=$tag python - <<'PY'
 import csv, glob, os, collections
 O, tag = os.environ['O'], os.environ['tag']
