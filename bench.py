@@ -141,6 +141,21 @@ def cpu_baseline(max_workers):
         out['pool'] = {'value': cores * reps * tile_px / busy, 'cores': cores,
                        'sample': '%d workers x %d tiles of 1200x1200' % (cores, reps),
                        'wall_s': wall}
+    # SURVEY 8d form (2): the same totals as fused, strength-reduced numpy (oracle/fused_numpy.py)
+    from oracle import fused_numpy, mod16_oracle as oracle, synth
+    from mod16_amd.utils import restore_bplut, bplut_table
+    from mod16_amd.models import COLLECTION61_BPLUT
+    table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    cls, drv = synth.drivers(TILE, seed=SEED)
+    best2 = 1e30
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fused_numpy.evapotranspiration_raster(bplut, cls, *drv)
+        best2 = min(best2, time.perf_counter() - t0)
+    out['fused_numpy'] = {'value': tile_px / best2, 'unit': 'pixels/s', 'cores': 1, 'seconds_per_tile': best2,
+                          'sample': '3 runs of a 1200x1200 float64 tile (best), shared per-period terms, '
+                                    'conductance forms, one division per component'}
     out['global_grid_seconds_1core'] = 43200 * 21600 / out['value']
     try:
         with open('/proc/cpuinfo') as f:

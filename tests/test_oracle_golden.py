@@ -263,3 +263,22 @@ def test_f9_broadcast_rows_and_columns(golden):
     res = oracle.evapotranspiration(p, *drv, separate=True)
     for name, got in zip(SEP, list(res[0]) + list(res[1])):
         same(got, f['bcast_' + name])
+
+
+def test_fused_numpy_baseline_agrees_with_the_oracle(golden):
+    """bench.py's second CPU baseline (fused / strength-reduced numpy) is the
+    same computation: identical NaN and exact-zero masks, 1e-9, on the reference's F3
+    raster and on a synthetic tile with the generator's special values."""
+    from oracle import fused_numpy, synth
+    f = golden('f3_random64_f64')
+    bplut = {k: f['table'][:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    cases = [(f['cls'], list(f['drivers']), (f['day'], f['night']))]
+    cls, drv = synth.drivers((300, 400), seed=3)
+    cases.append((cls, drv, oracle.evapotranspiration_raster(bplut, cls, *drv)))
+    for cls, drv, want in cases:
+        got = fused_numpy.evapotranspiration_raster(bplut, cls, *drv)
+        for g, w in zip(got, want):
+            assert np.array_equal(np.isnan(g), np.isnan(w))
+            assert np.array_equal(g == 0, w == 0)
+            ok = np.isfinite(w) & (w != 0)
+            assert np.max(np.abs(g[ok] - w[ok]) / np.abs(w[ok])) < 1e-9
