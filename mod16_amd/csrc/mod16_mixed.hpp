@@ -82,7 +82,8 @@ __device__ __forceinline__ void humid64(double t, double vpd, const double* tb, 
     double resat = M::rcp(esat);
     double rh = avp * resat;
     rh = __builtin_fma(__builtin_fma(-rh, esat, avp), resat, rh);
-    rh = (avp < 0.0) ? 0.0 : ((rh > 1.0) ? 1.0 : rh);
+    rh = (rh > 1.0) ? 1.0 : rh;                 // flat selects (a nested conditional becomes a branch)
+    rh = (avp < 0.0) ? 0.0 : rh;
     dry = rh < 0.7;
     double rh2 = rh * rh;
     double fwet = dry ? 0.0 : rh2 * rh2;

@@ -571,7 +571,10 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     T resat = M::rcp(esat);
     T rh = avp * resat;
     rh = __builtin_fma(__builtin_fma(-rh, esat, avp), resat, rh);
-    rh = (avp < T(0)) ? T(0) : ((rh > T(1)) ? T(1) : rh);
+    // flat selects, innermost first: hipcc turns a NESTED conditional into exec-masked
+    // branches (s_and_saveexec / s_cbranch / v_mov / s_or: ~8 instructions a level)
+    rh = (rh > T(1)) ? T(1) : rh;
+    rh = (avp < T(0)) ? T(0) : rh;                                 // :670-673
     T rh2 = rh * rh;
     const bool dry = rh < T(0.7);                                  // :764 (NaN compares false)
     T fwet = dry ? T(0) : rh2 * rh2;
@@ -607,13 +610,13 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
         T den = __builtin_fma(slhv, g_e, sh.k_p * g_a);
         T evap = (numer * g_e) * M::rcp(den);
         // numer < 0 -> 0 (:959), then fw <= tiny or lai <= tiny -> 0 (:961): one select
-        canopy = ((numer < T(0)) || dry || sh.lai_tiny) ? T(0) : evap;
+        canopy = ((numer < T(0)) | dry | sh.lai_tiny) ? T(0) : evap;
     }
     // -- bare soil, :449-544 and :795-864
     {
-        T r0 = (vpd <= p.vpd_open) ? p.rbl_min
-               : ((vpd >= p.vpd_close) ? p.rbl_max
-                  : __builtin_fma(-(p.vpd_close - vpd), p.rbl_slope, p.rbl_max));
+        T r0 = __builtin_fma(-(p.vpd_close - vpd), p.rbl_slope, p.rbl_max);   // :527-531
+        r0 = (vpd >= p.vpd_close) ? p.rbl_max : r0;
+        r0 = (vpd <= p.vpd_open) ? p.rbl_min : r0;
         T r_tot = r0 * inv_rcorr;                                  // :533
         T w = __builtin_fma(r_tot, g_rr, T(1));                    // r_tot / r_as
         T num = __builtin_fma((s * rad_soil), r_tot, (rcfv * sh.omf) * w);
@@ -638,18 +641,18 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     {
         T g_s = T(0);
         if (DAY) {
-            T m_vpd = (vpd >= p.vpd_close) ? T(0)
-                      : ((vpd < p.vpd_open) ? T(1)
-                         : __builtin_fma(-(vpd - p.vpd_open), p.inv_dvpd, T(1)));
+            T m_vpd = __builtin_fma(-(vpd - p.vpd_open), p.inv_dvpd, T(1));
+            m_vpd = (vpd < p.vpd_open) ? T(1) : m_vpd;
+            m_vpd = (vpd >= p.vpd_close) ? T(0) : m_vpd;
             g_s = ((p.csl * sh.m_tmin) * m_vpd) * inv_rcorr;       // :1237
         }
         T gsc = __builtin_fma(p.g_cut, inv_rcorr, g_s);            // :1238
         T g_bl = sh.glsh_lai * omw;                                // :1242
         T p1 = g_bl * gsc;
         T s1 = __builtin_fma(sh.glsh_lai, omw, gsc);               // g_bl + gsc
-        bool open = sh.lai_pos && (omw > T(0));                    // :1245
+        bool open = sh.lai_pos & (omw > T(0));                     // :1245
         // g_canopy <= tiny  <=>  P1 <= tiny S1 (S1 > 0); NaN compares false
-        bool shut = !open || (p1 <= tiny * s1);                    // :1258
+        bool shut = !open | (p1 <= tiny * s1);                     // :1258
         T g_d = p.gl_sh + g_rr;                                    // 1 / r_a_dry, :1248
         T rad_c = x.fpar * rad_net;
         rad_c = (rad_c < T(0)) ? T(0) : rad_c;                     // :1251
@@ -678,14 +681,16 @@ __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const 
     // -- radiation received by the soil, :963-1119 (predicates verbatim)
     T a_d = __builtin_fma(x.sw_d, sh.oma, x.lw_d);
     T a_n = x.lw_n;
-    bool cond = (x.t_ann < T(273.15 + 25.0)) && (x.t_ann >= (K<T>::t0 + p.tmin_close)) &&
+    // `&` and `|`, not `&&` and `||`: the short-circuit forms make hipcc evaluate the
+    // right-hand comparison inside an exec-masked branch (saveexec / cbranch / restore)
+    bool cond = (x.t_ann < T(273.15 + 25.0)) & (x.t_ann >= (K<T>::t0 + p.tmin_close)) &
                 ((x.t_d - x.t_n) >= T(5));
     T g_d = cond ? __builtin_fma(T(4.73), x.t_d - K<T>::t0, T(-20.87)) : T(0);
     g_d = (__builtin_fabs(g_d) > (T(0.39) * __builtin_fabs(a_d))) ? T(0.39) * a_d : g_d;
     T g_n = cond ? __builtin_fma(T(4.73), x.t_n - K<T>::t0, T(-20.87)) : T(0);
     g_n = (__builtin_fabs(g_n) > (T(0.39) * __builtin_fabs(a_n))) ? T(0.39) * a_n : g_n;
-    g_d = ((a_d - g_d < T(0)) && (a_d > T(0))) ? a_d : g_d;
-    g_n = ((a_d > T(0)) && ((a_n - g_n) < (T(-0.5) * a_d))) ? __builtin_fma(T(0.5), a_d, a_n) : g_n;
+    g_d = ((a_d - g_d < T(0)) & (a_d > T(0))) ? a_d : g_d;
+    g_n = ((a_d > T(0)) & ((a_n - g_n) < (T(-0.5) * a_d))) ? __builtin_fma(T(0.5), a_d, a_n) : g_n;
     T rs_d = sh.omf * (a_d - g_d);
     T rs_n = sh.omf * (a_n - g_n);
     // -- period-independent terms
@@ -699,8 +704,9 @@ __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const 
     sh.glwv_l = p.gl_wv * sh.l_wet;
     sh.glsh_lai = p.gl_sh * x.lai;
     T tm = x.tmin - K<T>::t0;
-    sh.m_tmin = (tm >= p.tmin_open) ? T(1)
-                : ((tm < p.tmin_close) ? T(0) : (tm - p.tmin_close) * p.inv_dtmin);
+    sh.m_tmin = (tm - p.tmin_close) * p.inv_dtmin;
+    sh.m_tmin = (tm < p.tmin_close) ? T(0) : sh.m_tmin;
+    sh.m_tmin = (tm >= p.tmin_open) ? T(1) : sh.m_tmin;
     period_fast<T, true, PET>(x, p, sh, tb, x.t_d, x.vpd_d, a_d, rs_d, o.canopy_d, o.soil_d, o.trans_d,
                               &o.pet_d);
     T rn_n = __builtin_fma(x.sw_n, sh.oma, x.lw_n);

@@ -323,17 +323,23 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
             VT res[NOUT];
             if constexpr (stream_is_mixed(MODE)) {
                 static_assert(V == 4 || !stream_is_mixed(MODE), "the mixed form is for float32 rasters");
+                // class codes of the four pixels first (the range check's side effect would
+                // otherwise sit between the two pairs and keep their arithmetic apart)
+                unsigned cls_of[V];
+                bool cls_bad = false;
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const unsigned c = (bits[0] >> (8 * j)) & 0xffu;
+                    cls_bad = cls_bad | (c >= 13u);
+                    cls_of[j] = c >= 13u ? 13u : c;
+                }
+                if (cls_bad) atomicOr(a.status, kStatusClassRange);
 #pragma unroll
                 for (int jj = 0; jj < V; jj += 2) {   // pairs of pixels: packed float32 arithmetic
                     float pin[14][2];
 #pragma unroll
                     for (int k = 0; k < 14; ++k) { pin[k][0] = in[k][jj]; pin[k][1] = in[k][jj + 1]; }
-                    unsigned c0 = (bits[0] >> (8 * jj)) & 0xffu, c1 = (bits[0] >> (8 * jj + 8)) & 0xffu;
-                    if (c0 >= 13u || c1 >= 13u) {
-                        atomicOr(a.status, kStatusClassRange);
-                        c0 = c0 >= 13u ? 13u : c0;
-                        c1 = c1 >= 13u ? 13u : c1;
-                    }
+                    const unsigned c0 = cls_of[jj], c1 = cls_of[jj + 1];
                     Parts2 pd, pn;
                     constexpr bool kRawMixed = MODE == kStreamRawMixed || MODE == kStreamRawTotalMixed ||
                                                MODE == kStreamRawTotalHoursMixed;
@@ -381,6 +387,18 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
                     }
                 }
             } else {
+            // class codes of the V pixels first: the range check has a side effect (the status
+            // word), and between the pixels it would keep hipcc from interleaving their
+            // (independent) arithmetic
+            unsigned cls_of[V];
+            bool cls_bad = false;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const unsigned c = (bits[0] >> (8 * j)) & 0xffu;
+                cls_bad = cls_bad | (c >= 13u);
+                cls_of[j] = c >= 13u ? 13u : c;
+            }
+            if (cls_bad) atomicOr(a.status, kStatusClassRange);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 PixelIn<double> x;
@@ -399,11 +417,7 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
                                         (double)in[9][j], (double)in[10][j], (double)in[11][j],
                                         (double)in[12][j], (double)in[13][j]};
                 }
-                unsigned c = (bits[0] >> (8 * j)) & 0xffu;
-                if (c >= 13u) {
-                    atomicOr(a.status, kStatusClassRange);
-                    c = 13u;
-                }
+                const unsigned c = cls_of[j];
                 const double* l = lut + c;
                 ClassPar<double> p;
                 p.tmin_close = l[0 * kLutCols];
