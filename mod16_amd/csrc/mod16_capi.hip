@@ -909,6 +909,10 @@ static int graph_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drive
     g->ctx = ctx;
     g->device = ctx->device;
     int rc = [&]() -> int {
+        // the run below (outside the capture: it validates the arguments) reads the raster
+        // on the library's own stream: whatever the caller enqueued on other streams to
+        // fill it must have finished (set-up time only; replays are ordered by their stream)
+        HIPCHK(ctx, hipDeviceSynchronize());
         HIPCHK(ctx, hipMalloc(&g->counter, 128));
         ctx->force_counter = g->counter;
         // the graph's kernel nodes keep pointing at this workspace for as long as
@@ -1830,6 +1834,10 @@ static int graph_tiled_entry(mod16_ctx* ctx, const mod16_layout* lay, const uint
     g->ctx = ctx;
     g->device = ctx->device;
     int rc = [&]() -> int {
+        // the run below (outside the capture: it validates the arguments) reads the raster
+        // on the library's own stream: whatever the caller enqueued on other streams to
+        // fill it must have finished (set-up time only; replays are ordered by their stream)
+        HIPCHK(ctx, hipDeviceSynchronize());
         HIPCHK(ctx, hipMalloc(&g->counter, 128));
         ctx->force_counter = g->counter;
         int pv = 0, tsh = lay->tile > 0 ? tile_log2(lay->tile, 1) : -1;

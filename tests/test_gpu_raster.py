@@ -300,6 +300,32 @@ def test_bound_launch_equals_run(env, graph):
     assert torch.equal(torch.nan_to_num(b2), torch.nan_to_num(night))
 
 
+def test_bind_right_behind_the_generator(env):
+    """`bind` validates its arguments with one launch on the library's own stream: it
+    must wait for whatever the caller's stream is still writing into the raster (here the
+    generator over memory full of 0xff bytes -- class codes >= 13 if read too early)."""
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table)
+    n = 40 * 1200 * 1200
+    cls, drv, day, night = eng.alloc_raster(n)
+    for t in drv + [cls.view(torch.uint8)]:
+        t.view(torch.uint8).fill_(0xff)
+    torch.cuda.synchronize()
+    d = torch.zeros(8, dtype=torch.float64, device='cuda')
+    eng.synth(n, seed=12, out=(cls, drv))
+    step = eng.bind(cls, drv, day, night, d)          # no synchronisation in between
+    step()
+    eng.check()                                       # no IndexError: nothing was read early
+    r = eng.synth_tiled(eng.alloc_tiled(n), seed=12)
+    d2 = torch.zeros(8, dtype=torch.float64, device='cuda')
+    r.slab.fill_(0xff)
+    eng.synth_tiled(r, seed=12)
+    step2 = eng.bind_tiled(r, d2)
+    step2()
+    eng.check()
+    assert torch.equal(d, d2)
+
+
 def test_bound_graph_survives_workspace_growth(env):
     """A captured graph owns its diagnostics workspace: launches of LARGER
     rasters on the same engine (DEVICE and HOST mode) make the context's own
