@@ -323,7 +323,8 @@ def test_bind_right_behind_the_generator(env):
     step2 = eng.bind_tiled(r, d2)
     step2()
     eng.check()
-    assert torch.equal(d, d2)
+    # same pixels; the sums run over partials of different run lengths on the two layouts
+    assert torch.allclose(d, d2, rtol=1e-12, atol=0) and torch.equal(d[2:6], d2[2:6])
 
 
 def test_bound_graph_survives_workspace_growth(env):
