@@ -36,7 +36,6 @@
 namespace mod16 {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
-typedef int i2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
 // 1/x: v_rcp_f32 + one Newton step. The step is there for the degenerate
@@ -50,7 +49,13 @@ __device__ __forceinline__ f2 rcp2(f2 x) {
 }
 __device__ __forceinline__ f2 exp2_2(f2 x) { return f2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
 __device__ __forceinline__ f2 log2_2(f2 x) { return f2{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)}; }
-__device__ __forceinline__ i2 mask2(bool a, bool b) { return i2{a ? -1 : 0, b ? -1 : 0}; }
+// Predicates of the two pixels are pairs of plain bools (x_0, x_1), not an int vector: each
+// stays a lane mask in scalar registers (v_cmp -> s[..]), combines with s_or / s_and and
+// feeds v_cndmask directly. A vector mask costs two v_cndmask to materialise, two v_or /
+// v_and per combination and two more v_cmp to test, all on the vector pipe that bounds this
+// kernel. (Not a struct of two bools passed by value either: that is coerced to an i16 and
+// the bits are shifted in and out of it.)
+__device__ __forceinline__ f2 sel(bool m0, bool m1, f2 a, f2 b) { return f2{m0 ? a.x : b.x, m1 ? a.y : b.y}; }
 
 // class parameters of the two pixels, float32 (the LDS table is float64:
 // rounded on the way in, 15 conversions per pixel)
@@ -60,14 +65,14 @@ struct ClassPar2 {
 
 struct Shared2 {
     f2 fpar, omf, p_rel, k_p, p_mbar_k, glsh_l, glwv_l, glsh_lai, m_tmin;
-    i2 lai_pos, lai_tiny;
+    bool lai_pos[2], lai_tiny[2];
 };
 
 // what the float64 section hands to one period
 struct Humid2 {
     f2 esat, rh, fwet, omw;
-    i2 dry;       // rh < 0.7  (fwet = 0)
-    i2 open_w;    // 1 - fwet > 0
+    bool dry[2];       // rh < 0.7  (fwet = 0)
+    bool open_w[2];    // 1 - fwet > 0
 };
 
 // esat, rh, fwet, 1 - fwet of one pixel and period in float64, as in period_fast
@@ -120,17 +125,18 @@ __device__ __forceinline__ Parts2 period_mixed(const ClassPar2& p, const Shared2
     f2 radc_raw = sh.fpar * rad_net;
 
     // wet canopy, :866-961
-    f2 fw = h.dry ? tiny : h.fwet;                                           // :934 (fwet == 0 <=> dry)
+    f2 fw = sel(h.dry[0], h.dry[1], tiny, h.fwet);                                          // :934 (fwet == 0 <=> dry)
     f2 g_h = sh.glsh_l * fw, g_e = sh.glwv_l * fw, g_a = g_h + g_rr;
     f2 numer = fw * ((rcfv * sh.fpar) * g_a + s * radc_raw);
     f2 den = slhv * g_e + sh.k_p * g_a;
     f2 evap = (numer * g_e) * rcp2(den);
     // numer < 0 -> 0 (:959), fw <= tiny (<=> dry) or lai <= tiny -> 0 (:961): one select
-    f2 canopy = ((numer < zero) | h.dry | sh.lai_tiny) ? zero : evap;
+    f2 canopy = sel((numer.x < 0.f) | h.dry[0] | sh.lai_tiny[0], (numer.y < 0.f) | h.dry[1] | sh.lai_tiny[1], zero, evap);
 
     // bare soil, :449-544, :795-864
-    f2 r0 = (vpd <= p.vpd_open) ? p.rbl_min
-            : ((vpd >= p.vpd_close) ? p.rbl_max : p.rbl_max - (p.vpd_close - vpd) * p.rbl_slope);
+    f2 r0 = sel(vpd.x <= p.vpd_open.x, vpd.y <= p.vpd_open.y, p.rbl_min,
+                sel(vpd.x >= p.vpd_close.x, vpd.y >= p.vpd_close.y, p.rbl_max,
+                    p.rbl_max - (p.vpd_close - vpd) * p.rbl_slope));
     f2 r_tot = r0 * inv_rcorr;
     f2 w = r_tot * g_rr + one;
     f2 num = (s * rad_soil) * r_tot + (rcfv * sh.omf) * w;
@@ -138,34 +144,37 @@ __device__ __forceinline__ Parts2 period_mixed(const ClassPar2& p, const Shared2
     f2 q = num * rcp2(dens);
     f2 pw = exp2_2((vpd * p.inv_beta) * log2_2(h.rh));                      // rh ** (vpd / beta), :861
     f2 e = q * (h.omw * pw + h.fwet);
-    f2 soil = (q < zero) ? zero : e;
+    f2 soil = sel(q.x < 0.f, q.y < 0.f, zero, e);
 
     // transpiration, :1152-1258
     f2 g_s = zero;
     if (DAY) {
-        f2 m_vpd = (vpd >= p.vpd_close) ? zero
-                   : ((vpd < p.vpd_open) ? one : one - (vpd - p.vpd_open) * p.inv_dvpd);
+        f2 m_vpd = sel(vpd.x >= p.vpd_close.x, vpd.y >= p.vpd_close.y, zero,
+                       sel(vpd.x < p.vpd_open.x, vpd.y < p.vpd_open.y, one,
+                           one - (vpd - p.vpd_open) * p.inv_dvpd));
         g_s = ((p.csl * sh.m_tmin) * m_vpd) * inv_rcorr;
     }
     f2 gsc = g_s + p.g_cut * inv_rcorr;
     f2 g_bl = sh.glsh_lai * h.omw;
     f2 p1 = g_bl * gsc, s1 = g_bl + gsc;
-    i2 open = sh.lai_pos & h.open_w;                                         // :1245
-    i2 shut = ~open | (p1 <= tiny * s1);                                     // :1258
+    const f2 lim = tiny * s1;
+    // !(lai > 0 and 1 - fwet > 0) (:1245) or the conductances vanish (:1258)
+    const bool shut0 = !(sh.lai_pos[0] & h.open_w[0]) | (p1.x <= lim.x);
+    const bool shut1 = !(sh.lai_pos[1] & h.open_w[1]) | (p1.y <= lim.y);
     f2 g_d = p.gl_sh + g_rr;
-    f2 rad_c = (radc_raw < zero) ? zero : radc_raw;                          // :1251
+    f2 rad_c = sel(radc_raw.x < 0.f, radc_raw.y < 0.f, zero, radc_raw);                         // :1251
     f2 numt = (h.omw * ((rcfv * sh.fpar) * g_d + s * rad_c)) * p1;
     f2 dent = slhv * p1 + sh.k_p * (g_d * s1 + p1);
     f2 tr = numt * rcp2(dent);
     Parts2 o;
     o.canopy = canopy;
     o.soil = soil;
-    o.trans = shut ? zero : tr;
+    o.trans = sel(shut0, shut1, zero, tr);
     o.pet = zero;
     if (PET) {
         // sat + unsat without the rh^(vpd/beta) factor (two products, so that inf * 0 is
         // NaN as in :541-543) + Priestley-Taylor potential transpiration (:546-602)
-        f2 pot_soil = (q < zero) ? zero : __builtin_elementwise_fma(q, h.fwet, q * h.omw);
+        f2 pot_soil = sel(q.x < 0.f, q.y < 0.f, zero, __builtin_elementwise_fma(q, h.fwet, q * h.omw));
         f2 pot_tr = (splat((float)kPriestleyTaylorAlpha) * (s * radc_raw) * h.omw) * rcp2(slhv + sh.k_p);
         o.pet = (canopy + pot_soil) + pot_tr;
     }
@@ -199,27 +208,32 @@ __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], co
     const f2 a_n = lw_n;
     // x < 298.15 (float64) <=> x < RU(298.15); x >= 273.15 + tmin_close <=> x >= row 15 of
     // the table; t_d - t_n is exact in float32 for temperatures within a factor 2
-    const i2 cond = (t_ann < splat(298.150024f)) & (t_ann >= par(15)) & ((t_d - t_n) >= splat(5.f));
+    const f2 p15 = par(15), dtd = t_d - t_n;
+    const bool cond0 = (t_ann.x < 298.150024f) & (t_ann.x >= p15.x) & (dtd.x >= 5.f);
+    const bool cond1 = (t_ann.y < 298.150024f) & (t_ann.y >= p15.y) & (dtd.y >= 5.f);
     // t - 273.15 as (t - 273) - 0.15: both differences are exact or correctly rounded
-    const f2 gd0 = cond ? __builtin_elementwise_fma(splat(4.73f), (t_d - splat(273.f)) - splat(0.15f), splat(-20.87f)) : zero;
-    const f2 gn0 = cond ? __builtin_elementwise_fma(splat(4.73f), (t_n - splat(273.f)) - splat(0.15f), splat(-20.87f)) : zero;
+    const f2 gd0 = sel(cond0, cond1, __builtin_elementwise_fma(splat(4.73f), (t_d - splat(273.f)) - splat(0.15f), splat(-20.87f)), zero);
+    const f2 gn0 = sel(cond0, cond1, __builtin_elementwise_fma(splat(4.73f), (t_n - splat(273.f)) - splat(0.15f), splat(-20.87f)), zero);
     const f2 lim_d = splat(0.39f) * __builtin_elementwise_abs(a_d), lim_n = splat(0.39f) * __builtin_elementwise_abs(a_n);
     const f2 agd = __builtin_elementwise_abs(gd0), agn = __builtin_elementwise_abs(gn0);
-    const f2 gd1 = (agd > lim_d) ? splat(0.39f) * a_d : gd0;
-    const f2 gn1 = (agn > lim_n) ? splat(0.39f) * a_n : gn0;
+    const f2 gd1 = sel(agd.x > lim_d.x, agd.y > lim_d.y, splat(0.39f) * a_d, gd0);
+    const f2 gn1 = sel(agn.x > lim_n.x, agn.y > lim_n.y, splat(0.39f) * a_n, gn0);
     const f2 dd = a_d - gd1;
-    const f2 gd2 = ((dd < zero) & (a_d > zero)) ? a_d : gd1;
+    const f2 gd2 = sel((dd.x < 0.f) & (a_d.x > 0.f), (dd.y < 0.f) & (a_d.y > 0.f), a_d, gd1);
     const f2 dn = (a_n - gn1) + splat(0.5f) * a_d;
-    const f2 gn2 = ((a_d > zero) & (dn < zero)) ? a_n + splat(0.5f) * a_d : gn1;
+    const f2 gn2 = sel((a_d.x > 0.f) & (dn.x < 0.f), (a_d.y > 0.f) & (dn.y < 0.f), a_n + splat(0.5f) * a_d, gn1);
     f2 rs_d = omf * (a_d - gd2), rs_n = omf * (a_n - gn2);
     f2 rn_n = __builtin_elementwise_fma(sw_n, oma, lw_n);
     // near-ties of the computed comparisons: operands within 1e-3 W m-2 (their float32
     // errors are below 1e-4) -> this wave redoes the balance in float64 for these pixels
     const f2 tol = splat(1e-3f);
-    const i2 near = (__builtin_elementwise_abs(agd - lim_d) <= tol) | (__builtin_elementwise_abs(agn - lim_n) <= tol) |
-                    (__builtin_elementwise_abs(dd) <= tol) | (__builtin_elementwise_abs(a_d) <= tol) |
-                    (__builtin_elementwise_abs(dn) <= tol);
-    if (__any((near.x | near.y) != 0)) {
+    // (the smallest of the five distances of each pixel against the tolerance: packed min,
+    // one comparison per pixel)
+    const f2 dist = __builtin_elementwise_min(
+        __builtin_elementwise_min(__builtin_elementwise_abs(agd - lim_d), __builtin_elementwise_abs(agn - lim_n)),
+        __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_abs(dd), __builtin_elementwise_abs(a_d)),
+                                  __builtin_elementwise_abs(dn)));
+    if (__any((dist.x <= tol.x) | (dist.y <= tol.y))) {
         float r[4][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -244,22 +258,24 @@ __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], co
         a_d = f2{r[0][0], r[0][1]}; rs_d = f2{r[1][0], r[1][1]};
         rs_n = f2{r[2][0], r[2][1]}; rn_n = f2{r[3][0], r[3][1]};
     }
-    // ---- float64: humidity of both periods
+    // ---- float64: humidity of both periods (an all-float32 form of this section was
+    // built and measured in round 2 -- value + error pairs for esat, 67 packed instructions
+    // per two pixels and period against 2 x 45 here: same error table, same kernel time;
+    // profiles/r02_experiments_not_kept.txt)
     Humid2 hd, hn;
-    bool dry_d[2], dry_n[2], open_d[2], open_n[2];
-    float esat_d[2], rh_d[2], fwet_d[2], omw_d[2], esat_n[2], rh_n[2], fwet_n[2], omw_n[2];
+    {
+        float esat_d[2], rh_d[2], fwet_d[2], omw_d[2], esat_n[2], rh_n[2], fwet_n[2], omw_n[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const double vd = vpd64 ? vpd64[0][j] : (double)in[9][j], vn = vpd64 ? vpd64[1][j] : (double)in[10][j];
-        humid64((double)in[5][j], vd, tb, esat_d[j], rh_d[j], fwet_d[j], omw_d[j], dry_d[j], open_d[j]);
-        humid64((double)in[6][j], vn, tb, esat_n[j], rh_n[j], fwet_n[j], omw_n[j], dry_n[j], open_n[j]);
+        for (int j = 0; j < 2; ++j) {
+            const double vd = vpd64 ? vpd64[0][j] : (double)in[9][j], vn = vpd64 ? vpd64[1][j] : (double)in[10][j];
+            humid64((double)in[5][j], vd, tb, esat_d[j], rh_d[j], fwet_d[j], omw_d[j], hd.dry[j], hd.open_w[j]);
+            humid64((double)in[6][j], vn, tb, esat_n[j], rh_n[j], fwet_n[j], omw_n[j], hn.dry[j], hn.open_w[j]);
+        }
+        hd.esat = f2{esat_d[0], esat_d[1]}; hd.rh = f2{rh_d[0], rh_d[1]};
+        hd.fwet = f2{fwet_d[0], fwet_d[1]}; hd.omw = f2{omw_d[0], omw_d[1]};
+        hn.esat = f2{esat_n[0], esat_n[1]}; hn.rh = f2{rh_n[0], rh_n[1]};
+        hn.fwet = f2{fwet_n[0], fwet_n[1]}; hn.omw = f2{omw_n[0], omw_n[1]};
     }
-    hd.esat = f2{esat_d[0], esat_d[1]}; hd.rh = f2{rh_d[0], rh_d[1]};
-    hd.fwet = f2{fwet_d[0], fwet_d[1]}; hd.omw = f2{omw_d[0], omw_d[1]};
-    hd.dry = mask2(dry_d[0], dry_d[1]); hd.open_w = mask2(open_d[0], open_d[1]);
-    hn.esat = f2{esat_n[0], esat_n[1]}; hn.rh = f2{rh_n[0], rh_n[1]};
-    hn.fwet = f2{fwet_n[0], fwet_n[1]}; hn.omw = f2{omw_n[0], omw_n[1]};
-    hn.dry = mask2(dry_n[0], dry_n[1]); hn.open_w = mask2(open_n[0], open_n[1]);
 
     // ---- float32, packed
     ClassPar2 p;
@@ -273,16 +289,17 @@ __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], co
     sh.p_rel = pa * splat((float)(1.0 / 101300.0));
     sh.k_p = pa * splat((float)(1013.0 / 0.622));
     sh.p_mbar_k = pa * splat((float)(0.348444 / 100.0));
-    const f2 l_wet = (lai == splat(0.f)) ? splat(1e-7f) : lai;               // :935
-    sh.lai_tiny = l_wet <= splat(1e-7f);
-    sh.lai_pos = lai > splat(0.f);
+    const f2 l_wet = sel(lai.x == 0.f, lai.y == 0.f, splat(1e-7f), lai);              // :935
+    sh.lai_tiny[0] = l_wet.x <= 1e-7f; sh.lai_tiny[1] = l_wet.y <= 1e-7f;
+    sh.lai_pos[0] = lai.x > 0.f; sh.lai_pos[1] = lai.y > 0.f;
     sh.glsh_l = p.gl_sh * l_wet;
     sh.glwv_l = p.gl_wv * l_wet;
     sh.glsh_lai = p.gl_sh * lai;
     // Tmin ramp, :1148 (continuous: a float32 tie decides nothing)
     const f2 tm = (col(8) - splat(273.f)) - splat(0.15f);
     const f2 tmin_close = par(0), tmin_open = par(1);
-    sh.m_tmin = (tm >= tmin_open) ? splat(1.f) : ((tm < tmin_close) ? zero : (tm - tmin_close) * par(11));
+    sh.m_tmin = sel(tm.x >= tmin_open.x, tm.y >= tmin_open.y, splat(1.f),
+                    sel(tm.x < tmin_close.x, tm.y < tmin_close.y, zero, (tm - tmin_close) * par(11)));
     day = period_mixed<true, PET>(p, sh, hd, t_d, col(9), a_d, rs_d);
     night = period_mixed<false, PET>(p, sh, hn, t_n, col(10), rn_n, rs_n);
 }
