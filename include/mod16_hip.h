@@ -479,6 +479,39 @@ MOD16_API int mod16_synth_tiled_f32(mod16_ctx* ctx, const mod16_layout* layout,
                        uint64_t seed, int64_t step, int64_t pixel_offset, int64_t n,
                        uint8_t* cls, float* const* drivers, void* stream);
 
+/*
+ * The other forms of the forward run on a tiled raster -- what mod16_et_pet_*,
+ * mod16_et_* with out_sep and mod16_et_raw_* compute on plain arrays, on the
+ * layout above (device pointers, MOD16_MATH_FAST or, float32, MOD16_MATH_MIXED;
+ * asynchronous on `stream`). `wide`: the form's driver arrays (driver_row applies to
+ * each), `bytes`: its byte rasters (cls_row applies to each), `outs`: its outputs
+ * (out_row applies to each); every array of the form is required:
+ *
+ *   form                          wide                      bytes                     outs
+ *   MOD16_FORM_TOTALS             14 drivers                cls                       day, night
+ *   MOD16_FORM_PET                14 drivers                cls                       day, night, pet day, pet night
+ *   MOD16_FORM_COMPONENTS         14 drivers                cls                       canopy, soil, transpiration (day), then (night)
+ *   MOD16_FORM_TOTALS_COMPONENTS  14 drivers                cls                       day, night, then the six components
+ *   MOD16_FORM_RAW                14 raw (mod16_raw_driver) cls, fpar_pct, lai_x10    day, night
+ *   MOD16_FORM_RAW_TOTAL8         14 raw                    cls, fpar_pct, lai_x10    day, night, total8 (day_hours: one value)
+ *   MOD16_FORM_RAW_TOTAL8_HOURS   14 raw + hours of daylight cls, fpar_pct, lai_x10   day, night, total8
+ *
+ * mod16_form_shape() returns the three counts of a form.
+ */
+enum mod16_form {
+    MOD16_FORM_TOTALS = 0, MOD16_FORM_PET, MOD16_FORM_COMPONENTS, MOD16_FORM_TOTALS_COMPONENTS,
+    MOD16_FORM_RAW, MOD16_FORM_RAW_TOTAL8, MOD16_FORM_RAW_TOTAL8_HOURS
+};
+MOD16_API int mod16_form_shape(int form, int* n_wide, int* n_bytes, int* n_out);
+MOD16_API int mod16_et_form_tiled_f64(mod16_ctx* ctx, const mod16_layout* layout, int form,
+                       const uint8_t* const* bytes, const double* const* wide,
+                       double* const* outs, double day_hours, int64_t n,
+                       unsigned flags, void* stream);
+MOD16_API int mod16_et_form_tiled_f32(mod16_ctx* ctx, const mod16_layout* layout, int form,
+                       const uint8_t* const* bytes, const float* const* wide,
+                       float* const* outs, double day_hours, int64_t n,
+                       unsigned flags, void* stream);
+
 /* mod16_time_et for a tiled raster: `launches` back-to-back direct (not captured)
  * launches of mod16_et_tiled_*, HIP events on `stream`, mean milliseconds per launch.
  * For steps shorter than a graph replay's fixed cost (a 1200 x 1200 tile) this is

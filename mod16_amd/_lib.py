@@ -18,6 +18,12 @@ N_COMPONENTS = 6
 HOST, DEVICE = 0, 1
 BC_SCALAR, BC_DENSE, BC_ROW, BC_COL = 0, 1, 2, 3      # enum mod16_broadcast
 MATH_FAST, MATH_EXACT, MATH_MIXED = 0, 1, 2
+# enum mod16_form: (wide arrays, byte rasters, outputs) of each form of the forward run
+(FORM_TOTALS, FORM_PET, FORM_COMPONENTS, FORM_TOTALS_COMPONENTS, FORM_RAW, FORM_RAW_TOTAL8,
+ FORM_RAW_TOTAL8_HOURS) = range(7)
+FORM_SHAPE = {FORM_TOTALS: (14, 1, 2), FORM_PET: (14, 1, 4), FORM_COMPONENTS: (14, 1, 6),
+              FORM_TOTALS_COMPONENTS: (14, 1, 8), FORM_RAW: (14, 3, 2), FORM_RAW_TOTAL8: (14, 3, 3),
+              FORM_RAW_TOTAL8_HOURS: (15, 3, 3)}
 
 METHOD_MAX_IN = 13
 (M_SVP, M_SVP_SLOPE, M_LHV, M_PSYCHROMETRIC, M_RADIATION_NET, M_AIR_DENSITY,
@@ -157,6 +163,11 @@ PROTOTYPES = {
     'mod16_synth_tiled_f32': (C.c_int, [
         C.c_void_p, _LAYP, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
         _PP, C.c_void_p]),
+    'mod16_form_shape': (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'mod16_et_form_tiled_f64': (C.c_int, [
+        C.c_void_p, _LAYP, C.c_int, _PP, _PP, _PP, C.c_double, C.c_int64, C.c_uint, C.c_void_p]),
+    'mod16_et_form_tiled_f32': (C.c_int, [
+        C.c_void_p, _LAYP, C.c_int, _PP, _PP, _PP, C.c_double, C.c_int64, C.c_uint, C.c_void_p]),
     'mod16_time_et_tiled': (C.c_int, [
         C.c_void_p, C.c_int, _LAYP, C.c_void_p, _PP, C.c_int64, C.c_void_p, C.c_void_p,
         C.c_uint, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),

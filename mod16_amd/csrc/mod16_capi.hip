@@ -1823,6 +1823,115 @@ extern "C" int mod16_et_tiled_f32(mod16_ctx* ctx, const mod16_layout* layout, co
     return tiled_entry<float>(ctx, layout, cls, drivers, n, out_day, out_night, flags, ddiag, stream);
 }
 
+// The other forms of the forward run (potential ET, components, raw drivers) on the same
+// layout: `wide` holds the form's 16-byte-per-lane input arrays, `bytes` its byte rasters
+// (class raster first), `outs` its outputs, in the order of mod16_form_shape().
+static bool form_shape(int form, int* nw, int* nb, int* no) {
+    switch (form) {
+    case MOD16_FORM_TOTALS: *nw = 14; *nb = 1; *no = 2; return true;
+    case MOD16_FORM_PET: *nw = 14; *nb = 1; *no = 4; return true;
+    case MOD16_FORM_COMPONENTS: *nw = 14; *nb = 1; *no = 6; return true;
+    case MOD16_FORM_TOTALS_COMPONENTS: *nw = 14; *nb = 1; *no = 8; return true;
+    case MOD16_FORM_RAW: *nw = 14; *nb = 3; *no = 2; return true;
+    case MOD16_FORM_RAW_TOTAL8: *nw = 14; *nb = 3; *no = 3; return true;
+    case MOD16_FORM_RAW_TOTAL8_HOURS: *nw = 15; *nb = 3; *no = 3; return true;
+    }
+    return false;
+}
+
+extern "C" int mod16_form_shape(int form, int* n_wide, int* n_bytes, int* n_out) {
+    int nw, nb, no;
+    if (!form_shape(form, &nw, &nb, &no)) return MOD16_ERR_ARG;
+    if (n_wide) *n_wide = nw;
+    if (n_bytes) *n_bytes = nb;
+    if (n_out) *n_out = no;
+    return MOD16_OK;
+}
+
+template <typename T>
+static int form_tiled_entry(mod16_ctx* ctx, const mod16_layout* lay, int form,
+                            const uint8_t* const* bytes, const T* const* wide, T* const* outs,
+                            double day_hours, int64_t n, unsigned flags, void* stream) {
+    constexpr int V = VecOf<T>::v;
+    if (!ctx) return MOD16_ERR_ARG;
+    int nw, nb, no;
+    if (!form_shape(form, &nw, &nb, &no)) return fail(ctx, MOD16_ERR_ARG, "mod16_et_form_tiled: unknown form");
+    if (!lay || !bytes || !wide || !outs || n < 0)
+        return fail(ctx, MOD16_ERR_ARG, "mod16_et_form_tiled: NULL argument or n < 0");
+    if (!ctx->have_lut) return fail(ctx, MOD16_ERR_NO_BPLUT, "mod16_et_form_tiled: mod16_set_bplut_f64 was not called");
+    if (flags & MOD16_MATH_EXACT) return fail(ctx, MOD16_ERR_ARG, "mod16_et_form_tiled: MOD16_MATH_EXACT runs on plain arrays only");
+    const int px_shift = tile_log2(lay->tile, (int64_t)64 * V * kDynRun);
+    if (px_shift < 0) return fail(ctx, MOD16_ERR_ARG, "mod16_et_form_tiled: tile must be a power of two of at least 8 KiB per field");
+    auto al16 = [](const void* p) { return p && reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    bool ok = lay->driver_row >= lay->tile && lay->out_row >= lay->tile && lay->cls_row >= lay->tile &&
+              lay->driver_row % V == 0 && lay->out_row % V == 0 && lay->cls_row % V == 0 && n % V == 0;
+    for (int k = 0; k < nw && ok; ++k) ok = al16(wide[k]);
+    for (int k = 0; k < no && ok; ++k) ok = al16(outs[k]);
+    for (int k = 0; k < nb && ok; ++k) ok = bytes[k] && reinterpret_cast<uintptr_t>(bytes[k]) % V == 0;
+    if (!ok) return fail(ctx, MOD16_ERR_ARG, "mod16_et_form_tiled: every array of the form is required, 16-byte aligned; rows >= tile and multiples of the vector width, n a multiple of it");
+    if (n == 0) return MOD16_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    StreamArgs<T> s;
+    memset(&s, 0, sizeof s);
+    for (int k = 0; k < nw; ++k) s.wide[k] = wide[k];
+    for (int k = 0; k < nb; ++k) s.bytes[k] = bytes[k];
+    for (int k = 0; k < no; ++k) s.out[k] = outs[k];
+    s.hours = day_hours;
+    s.n = n;
+    int pv = 0;
+    while ((1 << pv) < 64 * V) ++pv;
+    s.tile_shift = px_shift - pv;
+    s.wide_row = lay->driver_row;
+    s.out_row = lay->out_row;
+    s.byte_row = lay->cls_row;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = MOD16_OK;
+    bool mixed = false;
+    if constexpr (std::is_same<T, float>::value) {
+        mixed = (flags & MOD16_MATH_MIXED) != 0;
+        if (mixed) {
+            switch (form) {
+            case MOD16_FORM_TOTALS: rc = launch_stream<T, kStreamTotalsMixed>(ctx, s, st); break;
+            case MOD16_FORM_PET: rc = launch_stream<T, kStreamPetMixed>(ctx, s, st); break;
+            case MOD16_FORM_COMPONENTS: rc = launch_stream<T, kStreamSep6Mixed>(ctx, s, st); break;
+            case MOD16_FORM_TOTALS_COMPONENTS: rc = launch_stream<T, kStreamSep8Mixed>(ctx, s, st); break;
+            case MOD16_FORM_RAW: rc = launch_stream<T, kStreamRawMixed>(ctx, s, st); break;
+            case MOD16_FORM_RAW_TOTAL8: rc = launch_stream<T, kStreamRawTotalMixed>(ctx, s, st); break;
+            default: rc = launch_stream<T, kStreamRawTotalHoursMixed>(ctx, s, st); break;
+            }
+        }
+    }
+    if (!mixed) {
+        switch (form) {
+        case MOD16_FORM_TOTALS: rc = launch_stream<T, kStreamTotals>(ctx, s, st); break;
+        case MOD16_FORM_PET: rc = launch_stream<T, kStreamPet>(ctx, s, st); break;
+        case MOD16_FORM_COMPONENTS: rc = launch_stream<T, kStreamSep6>(ctx, s, st); break;
+        case MOD16_FORM_TOTALS_COMPONENTS: rc = launch_stream<T, kStreamSep8>(ctx, s, st); break;
+        case MOD16_FORM_RAW: rc = launch_stream<T, kStreamRaw>(ctx, s, st); break;
+        case MOD16_FORM_RAW_TOTAL8: rc = launch_stream<T, kStreamRawTotal>(ctx, s, st); break;
+        default: rc = launch_stream<T, kStreamRawTotalHours>(ctx, s, st); break;
+        }
+    }
+    if (rc != MOD16_OK) return rc;
+    HIPCHK(ctx, hipGetLastError());
+    return MOD16_OK;
+}
+
+extern "C" int mod16_et_form_tiled_f64(mod16_ctx* ctx, const mod16_layout* layout, int form,
+                                       const uint8_t* const* bytes, const double* const* wide,
+                                       double* const* outs, double day_hours, int64_t n,
+                                       unsigned flags, void* stream) {
+    MOD16_LOCK(ctx);
+    return form_tiled_entry<double>(ctx, layout, form, bytes, wide, outs, day_hours, n, flags, stream);
+}
+extern "C" int mod16_et_form_tiled_f32(mod16_ctx* ctx, const mod16_layout* layout, int form,
+                                       const uint8_t* const* bytes, const float* const* wide,
+                                       float* const* outs, double day_hours, int64_t n,
+                                       unsigned flags, void* stream) {
+    MOD16_LOCK(ctx);
+    return form_tiled_entry<float>(ctx, layout, form, bytes, wide, outs, day_hours, n, flags, stream);
+}
+
 template <typename T>
 static int graph_tiled_entry(mod16_ctx* ctx, const mod16_layout* lay, const uint8_t* cls,
                              const T* const* drivers, int64_t n, T* out_day, T* out_night,

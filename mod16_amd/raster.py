@@ -47,7 +47,11 @@ class TiledRaster(object):
     in include/mod16_hip.h): the pixels are cut into tiles of ``tile`` pixels and
     the 14 driver arrays interleaved tile by tile -- ``[tile][driver][tile
     pixels]`` -- the two outputs likewise in a block of their own, the class
-    raster as plain bytes. Every array is still an array: ``drivers[k]``, ``day``,
+    raster as plain bytes. ``form`` (``_lib.FORM_*``, ``enum mod16_form``) selects
+    another form of the forward run -- potential ET, components, raw drivers -- with
+    its own counts of arrays: ``wide`` (the drivers), ``bytes`` (class raster first,
+    then the uint8 fPAR / LAI of the raw forms) and ``outs``, in the order of
+    include/mod16_hip.h. Every array is still an array: ``drivers[k]``, ``day``,
     ``night`` and ``cls`` are 2-D strided ``torch`` views of shape ``(ntiles,
     tile)`` into one allocation, so ``drivers[5].copy_(temp.view(-1, tile))``,
     slicing and reductions work as on any tensor. Why: streamed side by side, 16
@@ -57,10 +61,12 @@ class TiledRaster(object):
     The storage is padded to whole tiles; ``n`` is the number of real pixels.
     '''
 
-    def __init__(self, engine, n, tile=None):
+    def __init__(self, engine, n, tile=None, form=_lib.FORM_TOTALS):
         torch = _torch()
         esz = engine.np_dtype.itemsize
         self.n = int(n)
+        self.form = int(form)
+        nw, nb, no = _lib.FORM_SHAPE[self.form]
         self.tile = int(tile) if tile else engine.TILE_BYTES // esz
         if self.tile & (self.tile - 1) or self.tile * esz < 8192:
             raise ValueError('tile must be a power of two of at least 8 KiB per field')
@@ -69,15 +75,21 @@ class TiledRaster(object):
             raise ValueError('a tiled raster holds a multiple of %d pixels' % vec)
         self.ntiles = max(1, -(-self.n // self.tile))
         P, nt = self.tile, self.ntiles
-        in_bytes, out_bytes = nt * 14 * P * esz, nt * 2 * P * esz
-        self.slab = torch.empty(in_bytes + out_bytes + nt * P + 4096, dtype=torch.uint8,
+        in_bytes, out_bytes, byte_bytes = nt * nw * P * esz, nt * no * P * esz, nt * nb * P
+        self.slab = torch.empty(in_bytes + out_bytes + byte_bytes + 4096, dtype=torch.uint8,
                                 device=engine._dev())
-        wide = self.slab[:in_bytes].view(engine.dtype).view(nt, 14, P)
-        self.drivers = [wide[:, k, :] for k in range(14)]
-        outs = self.slab[in_bytes:in_bytes + out_bytes].view(engine.dtype).view(nt, 2, P)
-        self.day, self.night = outs[:, 0, :], outs[:, 1, :]
-        self.cls = self.slab[in_bytes + out_bytes:in_bytes + out_bytes + nt * P].view(nt, P)
-        self.layout = _lib.Layout(P, 14 * P, 2 * P, P)
+        wide = self.slab[:in_bytes].view(engine.dtype).view(nt, nw, P)
+        self.wide = [wide[:, k, :] for k in range(nw)]
+        outs = self.slab[in_bytes:in_bytes + out_bytes].view(engine.dtype).view(nt, no, P)
+        self.outs = [outs[:, k, :] for k in range(no)]
+        rasters = self.slab[in_bytes + out_bytes:in_bytes + out_bytes + byte_bytes].view(nt, nb, P)
+        self.bytes = [rasters[:, k, :] for k in range(nb)]
+        # the names of the totals form (the production step)
+        self.drivers = self.wide[:14]
+        self.cls = self.bytes[0]
+        totals = self.form != _lib.FORM_COMPONENTS
+        self.day, self.night = (self.outs[0], self.outs[1]) if totals else (None, None)
+        self.layout = _lib.Layout(P, nw * P, no * P, nb * P)
         self.dtype = engine.dtype
 
     def flat(self, field, lo=0, hi=None):
@@ -473,10 +485,29 @@ class RasterEngine(object):
         return step
 
     # ------------------------------------------------------ tiled rasters
-    def alloc_tiled(self, n, tile=None):
+    def alloc_tiled(self, n, tile=None, form=_lib.FORM_TOTALS):
         '''A ``TiledRaster`` for n pixels (``tile`` pixels per tile, default
-        ``TILE_BYTES`` per field).'''
-        return TiledRaster(self, n, tile)
+        ``TILE_BYTES`` per field) of one form of the forward run.'''
+        return TiledRaster(self, n, tile, form)
+
+    def run_form_tiled(self, r, day_hours=None):
+        '''The forward run of the raster's form over a tiled raster
+        (``mod16_et_form_tiled_*``): what ``run_pet``, ``run(out_sep=...)`` and
+        ``run_raw`` compute on plain arrays. ``day_hours``: the hours of daylight of
+        ``FORM_RAW_TOTAL8`` (one value; ``FORM_RAW_TOTAL8_HOURS`` reads them per pixel
+        from ``r.wide[14]``). Asynchronous on the current stream; returns ``r.outs``.'''
+        if r.form == _lib.FORM_RAW_TOTAL8 and day_hours is None:
+            raise ValueError('FORM_RAW_TOTAL8 needs day_hours')
+        fn = self.ctx.lib.mod16_et_form_tiled_f32 if self.np_dtype == np.float32 \
+            else self.ctx.lib.mod16_et_form_tiled_f64
+        self.ctx.check(fn(
+            self.ctx.handle, C.byref(r.layout), r.form,
+            _lib.ptr_array([b.data_ptr() for b in r.bytes]),
+            _lib.ptr_array([w.data_ptr() for w in r.wide]),
+            _lib.ptr_array([o.data_ptr() for o in r.outs]),
+            float(day_hours) if day_hours is not None else 0.0, r.n, int(self.math),
+            self._stream()))
+        return r.outs
 
     def _tiled_args(self, r):
         return (C.byref(r.layout), r.cls.data_ptr(),

@@ -149,3 +149,86 @@ def test_tiled_series_matches_the_oracle(env):
         eng.run_tiled(r, diag=d)
         assert torch.equal(d, diag[s]), s
     assert not torch.equal(diag[0], diag[1])
+
+
+def _raw_fields(torch, eng, n, drv, seed=3):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    u = lambda lo, hi: torch.empty(n, dtype=eng.dtype, device='cuda').uniform_(lo, hi, generator=g)
+    raw = list(drv[:9]) + [u(0.001, 0.02), u(0.001, 0.02), u(7e4, 1.0134e5), u(7e4, 1.0134e5), u(0, 3500)]
+    fpar = torch.randint(0, 101, (n,), dtype=torch.uint8, device='cuda', generator=g)
+    lai = torch.randint(0, 71, (n,), dtype=torch.uint8, device='cuda', generator=g)
+    fpar[::97] = 255                                    # MODIS fill codes -> NaN
+    lai[::89] = 250
+    return raw, fpar, lai, u(8, 16)
+
+
+@pytest.mark.parametrize('dtype,math', [('float64', 'fast'), ('float32', 'fast'), ('float32', 'mixed')])
+@pytest.mark.parametrize('n', [8192 * 24 + 4 * 333, 4 * 700])
+def test_every_form_on_a_tiled_raster_equals_the_plain_arrays(env, dtype, math, n):
+    """mod16_et_form_tiled_*: potential ET, components and raw drivers on the tiled layout
+    against mod16_et_pet_* / out_sep / mod16_et_raw_* on plain arrays -- same kernel, same
+    arithmetic: identical bits, every output of every form."""
+    torch, RasterEngine, table, _lib = env
+    m = {'fast': _lib.MATH_FAST, 'mixed': _lib.MATH_MIXED}[math]
+    eng = RasterEngine(table, dtype=dtype, math=m)
+    cls, drv = eng.synth(n, seed=11, step=1)
+    raw, fpar, lai, hours = _raw_fields(torch, eng, n, drv)
+
+    def tiled(form, wide, rasters, day_hours=None):
+        r = eng.alloc_tiled(n, form=form)
+        r.slab.fill_(0xff)
+        for dst, src in zip(r.wide, wide):
+            r.put(dst, src)
+        for dst, src in zip(r.bytes, rasters):
+            r.put(dst, src)
+        outs = eng.run_form_tiled(r, day_hours=day_hours)
+        eng.check()
+        return [r.flat(o) for o in outs]
+
+    day, night = eng.run(cls, drv)
+    got = tiled(_lib.FORM_TOTALS, drv, [cls])
+    assert same(got[0], day) and same(got[1], night)
+
+    want = eng.run_pet(cls, drv)
+    got = tiled(_lib.FORM_PET, drv, [cls])
+    for k in range(4):
+        assert same(got[k], want[k]), ('pet', k)
+
+    sep = eng.empty(n, 6)
+    eng.run(cls, drv, out_sep=sep)
+    got = tiled(_lib.FORM_COMPONENTS, drv, [cls])
+    for k in range(6):
+        assert same(got[k], sep[k]), ('components', k)
+    d2, n2 = eng.run(cls, drv, *eng.empty(n, 2), out_sep=sep)
+    got = tiled(_lib.FORM_TOTALS_COMPONENTS, drv, [cls])
+    assert same(got[0], d2) and same(got[1], n2)
+    for k in range(6):
+        assert same(got[2 + k], sep[k]), ('totals + components', k)
+
+    want = eng.run_raw(cls, raw, fpar, lai)
+    got = tiled(_lib.FORM_RAW, raw, [cls, fpar, lai])
+    assert same(got[0], want[0]) and same(got[1], want[1])
+    # (one value for the hours of daylight: on plain device arrays the pipeline takes it
+    # per pixel -- same arithmetic)
+    want = eng.run_raw(cls, raw, fpar, lai, day_hours=torch.full_like(hours, 11.5))
+    got = tiled(_lib.FORM_RAW_TOTAL8, raw, [cls, fpar, lai], day_hours=11.5)
+    for k in range(3):
+        assert same(got[k], want[k]), ('raw total8', k)
+    want = eng.run_raw(cls, raw, fpar, lai, day_hours=hours)
+    got = tiled(_lib.FORM_RAW_TOTAL8_HOURS, raw + [hours], [cls, fpar, lai])
+    for k in range(3):
+        assert same(got[k], want[k]), ('raw total8, hours per pixel', k)
+    eng.check()
+
+
+def test_form_tiled_argument_errors(env):
+    torch, RasterEngine, table, _lib = env
+    eng = RasterEngine(table)
+    r = eng.alloc_tiled(8192, form=_lib.FORM_RAW_TOTAL8)
+    with pytest.raises(ValueError):
+        eng.run_form_tiled(r)                           # hours of daylight missing
+    r = eng.alloc_tiled(8192, form=_lib.FORM_PET)
+    r.form = 17
+    with pytest.raises(Exception) as e:
+        eng.run_form_tiled(r)
+    assert 'unknown form' in str(e.value)
