@@ -34,9 +34,17 @@ constexpr size_t kStagger = 33 * 1024;              // see RasterEngine.STAGGER_
 // graph owns its own, so growing the context's never pulls memory from under
 // a graph that is replayed later.
 struct DiagWs {
-    double* partial = nullptr;   // device [capacity][kDiag]
+    double* partial = nullptr;   // device [capacity][kDiag], then 128 bytes: the "blocks done" counter
     int64_t capacity = 0;        // in partials
+    unsigned* done() const { return reinterpret_cast<unsigned*>(partial + capacity * 8); }
 };
+// hipMalloc of a workspace for `blocks` partials + the (zeroed) counter behind them
+static hipError_t ws_alloc(DiagWs& ws, int64_t blocks) {
+    hipError_t e = hipMalloc(&ws.partial, sizeof(double) * (blocks * 8 + 16));
+    if (e != hipSuccess) return e;
+    ws.capacity = blocks;
+    return hipMemset(ws.done(), 0, 128);
+}
 
 struct mod16_ctx {
     std::recursive_mutex api_mu;     // every entry point holds it: a ctx may be shared by threads
@@ -196,8 +204,7 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
         HIPCHK(ctx, hipMalloc(&ctx->status, sizeof(unsigned)));
         HIPCHK(ctx, hipMemset(ctx->status, 0, sizeof(unsigned)));
         HIPCHK(ctx, hipHostMalloc(&ctx->status_host, sizeof(unsigned)));
-        HIPCHK(ctx, hipMalloc(&ctx->ws.partial, sizeof(double) * kDiagBlocks * kDiag));
-        ctx->ws.capacity = kDiagBlocks;
+        HIPCHK(ctx, ws_alloc(ctx->ws, kDiagBlocks));
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming));
         HIPCHK(ctx, hipMalloc(&ctx->diag_dev, sizeof(double) * kDiag));
         HIPCHK(ctx, hipHostMalloc(&ctx->diag_host, sizeof(double) * kDiag));
@@ -326,8 +333,7 @@ static int reserve_diag(mod16_ctx* ctx, int64_t blocks, DiagWs** out = nullptr) 
     ctx->ws.partial = nullptr;
     ctx->ws.capacity = 0;
     ctx->ws_pending = false;
-    HIPCHK(ctx, hipMalloc(&ctx->ws.partial, sizeof(double) * blocks * kDiag));
-    ctx->ws.capacity = blocks;
+    HIPCHK(ctx, ws_alloc(ctx->ws, blocks));
     return MOD16_OK;
 }
 
@@ -389,6 +395,7 @@ static StreamGeom stream_geom(const mod16_ctx* ctx, int64_t n, int V, int tile_s
     return g;
 }
 constexpr int kStage = 1024;     // slices of the two-level sum of the per-run partials
+constexpr int64_t kFuseFinalBelow = 16384;   // partials up to which the pipeline kernel sums them itself
 
 // The production pipeline for dense class rasters (mod16_stream.hpp). s.n must
 // be a multiple of the vector width. ddiag != NULL: also the fixed-order sum
@@ -400,25 +407,33 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     s.lut64 = ctx->lut64;
     s.tab = ctx->tab64;
     s.status = ctx->status;
-    unsigned long long* ctr = ctx->force_counter ? ctx->force_counter
-                                                 : ctx->dyn_counters + 16 * (ctx->dyn_next++ % 64);
-    HIPCHK(ctx, hipMemsetAsync(ctr, 0, sizeof(unsigned long long), st));
-    s.dyn_counter = ctr;
     if (s.tile_shift <= 0) {       // plain arrays: one "tile"
         s.tile_shift = kNoTile;
         s.wide_row = s.out_row = s.byte_row = 0;
     }
     const StreamGeom g = stream_geom(ctx, s.n, V, s.tile_shift);
+    unsigned long long* ctr = ctx->force_counter ? ctx->force_counter
+                                                 : ctx->dyn_counters + 16 * (ctx->dyn_next++ % 64);
+    // the ticket counter of the dynamic schedule; a statically scheduled (small) raster
+    // never reads it, and the fill is a dispatch of its own (4 us + the gap behind it)
+    if (!g.static_sched) HIPCHK(ctx, hipMemsetAsync(ctr, 0, sizeof(unsigned long long), st));
+    s.dyn_counter = ctr;
     s.run_shift = g.run_shift;
     s.static_sched = g.static_sched;
-    const int64_t nruns = g.nruns;
     const int grid = g.grid;
+    // partials: one per run, or (static schedule) one per wave that has a run
+    const int64_t nruns = g.static_sched ? std::min<int64_t>(g.nruns, (int64_t)grid * (kBlock / 64)) : g.nruns;
     DiagWs* ws = nullptr;
     int rc = reserve_diag(ctx, nruns + kStage, &ws);
     if (rc != MOD16_OK) return rc;
     rc = ws_acquire(ctx, st);
     if (rc != MOD16_OK) return rc;
     s.diag_partial = ws->partial;
+    // few partials: the kernel's last block adds them up itself (two dispatches less)
+    const bool fused_final = ddiag && nruns <= kFuseFinalBelow;
+    s.diag_out = fused_final ? ddiag : nullptr;
+    s.done_counter = ws->done();
+    s.nruns = nruns;
     // equally spaced wide arrays (one slab): scalar base + k * pitch
     constexpr int NW = StreamSpec<MODE>::NW;
     const ptrdiff_t pitch_b = reinterpret_cast<const char*>(s.wide[1]) - reinterpret_cast<const char*>(s.wide[0]);
@@ -428,7 +443,7 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     s.wide_pitch = pitched ? pitch_b / (ptrdiff_t)sizeof(T) : 0;
     if (pitched) hipLaunchKernelGGL((et_stream_kernel<T, MODE, true>), dim3(grid), dim3(kBlock), 0, st, s);
     else hipLaunchKernelGGL((et_stream_kernel<T, MODE, false>), dim3(grid), dim3(kBlock), 0, st, s);
-    if (ddiag) {
+    if (ddiag && !fused_final) {
         const double* fin = ws->partial;
         int64_t count = nruns;
         if (count > 4 * kStage) {   // two-level: 1024 fixed slices, then one block
@@ -921,8 +936,7 @@ static int graph_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drive
         ctx->force_counter = g->counter;
         // the graph's kernel nodes keep pointing at this workspace for as long as
         // the graph lives, whatever the context's own workspace does meanwhile
-        g->ws.capacity = std::max<int64_t>(kDiagBlocks, stream_geom(ctx, std::max<int64_t>(n, 0), VecOf<T>::v).nruns + kStage);
-        HIPCHK(ctx, hipMalloc(&g->ws.partial, sizeof(double) * g->ws.capacity * kDiag));
+        HIPCHK(ctx, ws_alloc(g->ws, std::max<int64_t>(kDiagBlocks, stream_geom(ctx, std::max<int64_t>(n, 0), VecOf<T>::v).nruns + kStage)));
         ctx->force_ws = &g->ws;
         // once outside a capture: validates the arguments and brings the workspace to size
         int r = et_diag_entry<T>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, st);
@@ -1956,8 +1970,7 @@ static int graph_tiled_entry(mod16_ctx* ctx, const mod16_layout* lay, const uint
         int pv = 0, tsh = lay->tile > 0 ? tile_log2(lay->tile, 1) : -1;
         while ((1 << pv) < 64 * VecOf<T>::v) ++pv;
         if (tsh < pv) return fail(ctx, MOD16_ERR_ARG, "mod16_graph_et_tiled: bad tile");
-        g->ws.capacity = std::max<int64_t>(kDiagBlocks, stream_geom(ctx, std::max<int64_t>(n, 0), VecOf<T>::v, tsh - pv).nruns + kStage);
-        HIPCHK(ctx, hipMalloc(&g->ws.partial, sizeof(double) * g->ws.capacity * kDiag));
+        HIPCHK(ctx, ws_alloc(g->ws, std::max<int64_t>(kDiagBlocks, stream_geom(ctx, std::max<int64_t>(n, 0), VecOf<T>::v, tsh - pv).nruns + kStage)));
         ctx->force_ws = &g->ws;
         int r = tiled_entry<T>(ctx, lay, cls, drivers, n, out_day, out_night, flags, ddiag, st);
         if (r != MOD16_OK) return r;

@@ -105,6 +105,11 @@ template <typename T> struct StreamArgs {
     int64_t wide_row;          // elements between successive tiles of a wide array
     int64_t out_row;           // ... of an output array
     int64_t byte_row;          // bytes between successive tiles of a byte array
+    // Small rasters: the block that finishes last adds up the per-run partials itself and
+    // writes the diagnostics vector (NULL: a separate kernel does, after this one)
+    double* diag_out;          // 8 doubles
+    unsigned* done_counter;    // blocks finished; the last block leaves it at 0 again
+    int64_t nruns;             // partials to add (runs, or waves with work under the static schedule)
 };
 constexpr int kNoTile = 40;    // more pieces per "tile" than any raster has: one tile, plain arrays
 static_assert(__builtin_offsetof(StreamArgs<double>, wide) == 0 &&
@@ -478,8 +483,10 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
             for (int k = 0; k < NOUT; ++k)
                 __builtin_nontemporal_store(res[k], reinterpret_cast<VT*>((a.out[k] + first) + lane_elem));
         }
-        flushed = (run_n == 0 || cb_n + run_n >= npiece);
-        if (flushed) {   // per-run diagnostics partial: butterfly, then lanes 0..7 store the 8 fields
+        // diagnostics partial: one per run (dynamic schedule: which wave computes a run is not
+        // fixed, the run's pixels are) or one per wave (static schedule: the wave's runs are)
+        flushed = cb_n + run_n >= npiece || (run_n == 0 && !a.static_sched);
+        if (flushed) {   // butterfly, then lanes 0..7 store the 8 fields
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 dsum_d += __shfl_xor(dsum_d, off, 64);
@@ -491,7 +498,11 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
             const double cnt_n = (double)__builtin_amdgcn_readfirstlane(nan_n);
             const double f = lane == 0 ? dsum_d : lane == 1 ? dsum_n : lane == 4 ? cnt_d
                            : lane == 5 ? cnt_n : lane == 6 ? dmax_d : lane == 7 ? dmax_n : 0.0;
-            if (lane < kDiag) a.diag_partial[(cbase >> rs) * kDiag + lane] = f;
+            const int64_t slot = a.static_sched ? (int64_t)blockIdx.x * (kBlock / 64) + wave : cbase >> rs;
+            // (agent scope = written through to memory: the block that adds the partials up
+            // may sit behind another L2)
+            if (lane < kDiag)
+                __hip_atomic_store(a.diag_partial + slot * kDiag + lane, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             dsum_d = dsum_n = 0.0;
             dmax_d = dmax_n = -__builtin_huge_val();
             nan_d = nan_n = 0;
@@ -499,6 +510,67 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
         cbase = cb_n;
         run = run_n;
         v = vn;
+    }
+    // -- diagnostics of a small raster, finished in this launch: every block counts itself
+    // done once its partials are in memory; the block that counts last adds all of them up in
+    // a fixed order (thread t: partials t, t + 256, ...; then the wave and block trees), so
+    // the sums depend on n and the device only -- not on which block was last. Partials are
+    // stored and loaded at agent scope (through the L2s, which are per XCD) and the stores
+    // are waited for before the count: no cache write-back or invalidate is needed, and a
+    // full release fence here (an L2 write-back per block, 512 blocks ending together)
+    // measured 19 us on a 1200 x 1200 raster -- more than the two dispatches it replaces.
+    if (a.diag_out) {
+        __shared__ int last_block;
+        __shared__ double fin[kBlock / 64][kDiag];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            last_block = __hip_atomic_fetch_add(a.done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        __syncthreads();
+        if (last_block) {
+            double acc[kDiag] = {0, 0, 0, 0, 0, 0, -__builtin_huge_val(), -__builtin_huge_val()};
+            // four partials in flight per thread
+            for (int64_t b0 = threadIdx.x; b0 < a.nruns; b0 += 4 * kBlock) {
+                double o[4][kDiag];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t b = b0 + j * kBlock;
+#pragma unroll
+                    for (int k = 0; k < kDiag; ++k)
+                        o[j][k] = b < a.nruns ? __hip_atomic_load(a.diag_partial + b * kDiag + k, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_AGENT)
+                                              : (k < 6 ? 0.0 : -__builtin_huge_val());
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) diag_merge(acc, o[j]);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                double o[kDiag];
+#pragma unroll
+                for (int k = 0; k < kDiag; ++k) o[k] = __shfl_down(acc[k], off, 64);
+                diag_merge(acc, o);
+            }
+            if (lane == 0)
+                for (int k = 0; k < kDiag; ++k) fin[wave][k] = acc[k];
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (int w = 1; w < kBlock / 64; ++w) {
+                    double o[kDiag];
+                    for (int k = 0; k < kDiag; ++k) o[k] = fin[w][k];
+                    diag_merge(acc, o);
+                }
+                a.diag_out[0] = acc[0];
+                a.diag_out[1] = acc[1];
+                a.diag_out[2] = (double)a.n - acc[4];
+                a.diag_out[3] = (double)a.n - acc[5];
+                a.diag_out[4] = acc[4];
+                a.diag_out[5] = acc[5];
+                a.diag_out[6] = acc[6];
+                a.diag_out[7] = acc[7];
+                __hip_atomic_store(a.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 

@@ -117,6 +117,50 @@ def test_diagnostics_fused_standalone_numpy(env):
         assert torch.equal(fused, again)
 
 
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_small_rasters_finish_their_diagnostics_in_the_kernel(env, dtype):
+    """A small raster's partials are added up by the pipeline kernel's last block (one
+    partial per wave under the static schedule, per run otherwise, up to 16384 of them).
+    Sizes: one wave, a few blocks, a 1200 x 1200 tile, the largest statically scheduled
+    rasters and the first dynamically scheduled ones, plain arrays and tiled, launches back to
+    back on one stream and alternating between two: always the stand-alone reduction's sums
+    and counts, and the same bits every time (whichever block happens to finish last)."""
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table, dtype=dtype)
+    vec = 16 // eng.np_dtype.itemsize
+    side = torch.cuda.Stream()
+    for n in (vec * 64, vec * 64 * 9, 1200 * 1200, vec * 64 * 2 * 16000, vec * 64 * 2 * 16500,
+              vec * 64 * 8 * 16300):
+        for tiled in (False, True):
+            if tiled:
+                r = eng.synth_tiled(eng.alloc_tiled(n), seed=3)
+                launch = lambda d: eng.run_tiled(r, diag=d)
+                flat = lambda: (r.flat(r.day), r.flat(r.night))
+            else:
+                cls, drv, day, night = eng.alloc_raster(n)
+                eng.synth(n, seed=3, out=(cls, drv))
+                launch = lambda d: eng.run(cls, drv, day, night, diag=d)
+                flat = lambda: (day, night)
+            vecs = [torch.zeros(8, dtype=torch.float64, device='cuda') for _ in range(24)]
+            for d in vecs[:16]:
+                launch(d)
+            torch.cuda.synchronize()
+            for i, d in enumerate(vecs[16:]):           # two streams take turns
+                if i % 2:
+                    with torch.cuda.stream(side):
+                        launch(d)
+                else:
+                    launch(d)
+            torch.cuda.synchronize()
+            alone = eng.diagnostics(*flat())
+            eng.check()
+            for d in vecs[1:]:
+                assert torch.equal(vecs[0], d), (n, tiled)
+            got, ref = vecs[0].cpu().numpy(), alone.cpu().numpy()
+            np.testing.assert_allclose(got[:2], ref[:2], rtol=1e-12, err_msg=str((n, tiled)))
+            assert np.array_equal(got[2:], ref[2:]), (n, tiled, got, ref)
+
+
 def test_diagnostics_are_schedule_independent_at_size(env):
     """The production kernel hands runs of pixels to whichever wave is ready;
     its diagnostics are accumulated per run and summed in fixed order, so
