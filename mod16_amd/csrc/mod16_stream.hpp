@@ -519,6 +519,8 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
     // are waited for before the count: no cache write-back or invalidate is needed, and a
     // full release fence here (an L2 write-back per block, 512 blocks ending together)
     // measured 19 us on a 1200 x 1200 raster -- more than the two dispatches it replaces.
+    // (MOD16_NO_FUSED_FINAL: compiled out, for instruction counts of the loop -- tools/isa_count.py)
+#ifndef MOD16_NO_FUSED_FINAL
     if (a.diag_out) {
         __shared__ int last_block;
         __shared__ double fin[kBlock / 64][kDiag];
@@ -572,6 +574,7 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
             }
         }
     }
+#endif
 }
 
 }  // namespace mod16
