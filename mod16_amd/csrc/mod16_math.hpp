@@ -90,13 +90,28 @@ template <> struct FastMath<double> {
 
     // e^x for finite x (no clamp: a huge |x| saturates through v_cvt_i32 and
     // v_ldexp to 0 or inf; NaN -> NaN; +-inf -> NaN, callers clamp where -inf
-    // can occur). 12 f64-rate operations, relative error ~2e-16.
+    // can occur). 12 f64-rate operations, relative error ~2e-16 (esat wants all of it: rh =
+    // (esat - vpd) / esat amplifies its error by 1 / rh in dry air).
     static __device__ __forceinline__ T exp_tab(T x, const T* tb) {
         T kf = __builtin_rint(x * 92.33248261689366);               // 64 / ln 2
         T r = __builtin_fma(kf, -0x1.62e42fee00000p-7, x);          // ln2/64, 32-bit head
         r = __builtin_fma(kf, -0x1.a39ef35793c76p-39, r);
         T p = fma_kk(r, 1.0 / 120.0, 1.0 / 24.0);                   // |r| <= ln2/128
         p = __builtin_fma(p, r, 1.0 / 6.0);
+        p = __builtin_fma(p, r, 0.5);
+        p = __builtin_fma(p, r, 1.0);
+        p = __builtin_fma(p, r, 1.0);
+        int ki = (int)kf;
+        return __builtin_amdgcn_ldexp(tb[ki & 63] * p, ki >> 6);
+    }
+
+    // the same with a quartic: the first term left out is r^5/120 <= 4e-14 relative -- for
+    // results that are not differenced afterwards (rh^(vpd/beta))
+    static __device__ __forceinline__ T exp_tab4(T x, const T* tb) {
+        T kf = __builtin_rint(x * 92.33248261689366);
+        T r = __builtin_fma(kf, -0x1.62e42fee00000p-7, x);
+        r = __builtin_fma(kf, -0x1.a39ef35793c76p-39, r);
+        T p = fma_kk(r, 1.0 / 24.0, 1.0 / 6.0);
         p = __builtin_fma(p, r, 0.5);
         p = __builtin_fma(p, r, 1.0);
         p = __builtin_fma(p, r, 1.0);
@@ -118,7 +133,7 @@ template <> struct FastMath<double> {
 
     // ln(x) for x > 0 normal (x is a relative humidity in (0, 1] here);
     // log(1) is exactly 0 by construction of table entry 0; x = 0 -> -inf.
-    // Absolute error ~1e-16 (what matters: the result feeds exp(y log x)).
+    // Absolute error ~1e-15 (what matters: the result feeds exp(y log x)).
     static __device__ __forceinline__ T log_tab(T x, const T* tb) {
         const unsigned hi = (unsigned)__double2hiint(x);
         const int e = (int)(hi >> 20) - 1023;
@@ -134,15 +149,16 @@ template <> struct FastMath<double> {
         v = __builtin_fma(ed, 7.371002565167799e-13, v);
         return (x == 0.0) ? -__builtin_huge_val() : v;
     }
-    // r - r^2/2 + ... - r^6/6 ; the host evaluates the same sequence (std::fma)
-    // to make table entry 0 cancel exactly at x = 1
+    // r - r^2/2 + ... + r^5/5 on |r| <= 1/256: the next term, r^6/6, is below 6e-16 (the
+    // exponent vpd / beta reaches thousands on the calibration path, where beta is sampled
+    // down to ~1: a quartic's 1.9e-13 showed as 1e-9 there); the host evaluates the same
+    // sequence (std::fma) to make table entry 0 cancel exactly at x = 1
     static __host__ __device__ __forceinline__ T log1p_poly(T r) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        T p = fma_kk(r, -1.0 / 6.0, 1.0 / 5.0);
+        T p = fma_kk(r, 0.2, -0.25);
 #else
-        T p = __builtin_fma(r, -1.0 / 6.0, 1.0 / 5.0);
+        T p = __builtin_fma(r, 0.2, -0.25);
 #endif
-        p = __builtin_fma(p, r, -0.25);
         p = __builtin_fma(p, r, 1.0 / 3.0);
         p = __builtin_fma(p, r, -0.5);
         return __builtin_fma(r * r, p, r);
@@ -154,7 +170,7 @@ template <> struct FastMath<double> {
     static __device__ __forceinline__ T pow01_tab(T x, T y, const T* tb) {
         T yc = vmin_k(y, 1e300);
         T t = vmax_k(yc * log_tab(x, tb), -746.0);
-        return exp_tab(t, tb);
+        return exp_tab4(t, tb);
     }
 };
 

@@ -523,7 +523,7 @@ __device__ __forceinline__ double static_period_eval(const StaticPixel& px, cons
     const double num = __builtin_fma(c.s * rad_soil, r_tot, (c.rcfv * px.omf) * w);
     const double q = num * M::rcp(r_tot * __builtin_fma(c.gamma, w, c.s));
     const double yc = __builtin_fmin(c.vpd * d.inv_beta, 1e300);
-    const double pw = M::exp_tab(__builtin_fmax(yc * c.logrh, -746.0), tb);  // rh ** (vpd / beta), :376
+    const double pw = M::exp_tab4(__builtin_fmax(yc * c.logrh, -746.0), tb);  // rh ** (vpd / beta), :376
     const double e_soil = q * __builtin_fma(c.omw, pw, c.fw);
     return (tr + e_can) + e_soil;                                            // :380
 }
@@ -561,10 +561,16 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     const T cp = K<T>::cp;
     // -- humidity, :646-673 and :763-764
     T tc = t - K<T>::t0;
-    // tc * 0 is NaN for a NaN (or infinite) temperature and 0 otherwise: it
-    // carries the NaN that exp_tab's integer path would drop
-    T esat = __builtin_fma(T(1e3 * 0.6108),
-                           M::exp_tab((T(17.27) * tc) * M::rcp(tc + T(237.3)), tb), tc * T(0));
+    // the two reciprocals of the temperature terms -- 1 / (tc + 237.3) for esat and
+    // 1 / (tc + 239) for the slope of the curve -- from ONE v_rcp_f64 of their product
+    // (a quarter-rate instruction and its Newton step against two multiplications)
+    T d_es = tc + T(237.3);
+    T ta = tc + T(239.0);                                          // (239 + T) - 273.15 to 1 ulp, :1395
+    T r_both = M::rcp(d_es * ta);
+    T r_es = r_both * ta, rta = r_both * d_es;
+    // (a NaN temperature stays NaN through exp_tab: rint, the fmas and the table product
+    // all propagate it; an infinite one gives inf * 0 in r_es)
+    T esat = T(1e3 * 0.6108) * M::exp_tab((T(17.27) * tc) * r_es, tb);
     T avp = esat - vpd;
     // rh drives the thresholds (rh < 0.7, 1 - fwet > 0), so this one quotient is
     // finished like an IEEE division (residual correction): x / x = 1 exactly
@@ -580,8 +586,6 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     T fwet = dry ? T(0) : rh2 * rh2;
     T omw = T(1) - fwet;
     // -- slope of the SVP curve (:1395-1397), latent heat (:121)
-    T ta = (T(239.0) + t) - K<T>::t0;
-    T rta = M::rcp(ta);
     T s = (T(17.38 * 239.0) * esat) * (rta * rta);
     T lhv = M::fma_kk(tc, T(-0.002361e6), T(2.501e6));         // (2.501 - 0.002361 tc) 1e6, :121
     T slhv = s * lhv;
