@@ -87,13 +87,19 @@ template <> struct FastMath<double> {
     // tb[0..63]      = 2^(j/64)
     // tb[64 + 2j..]  = { 1/c_j rounded, -log(1/c_j) },  c_j = 1 + (j + 1/2)/128
     static constexpr int kTabDoubles = 64 + 2 * 128;
+    static constexpr double kRintShift = 6755399441055744.0;       // 1.5 * 2^52
 
     // e^x for finite x (no clamp: a huge |x| saturates through v_cvt_i32 and
     // v_ldexp to 0 or inf; NaN -> NaN; +-inf -> NaN, callers clamp where -inf
     // can occur). 12 f64-rate operations, relative error ~2e-16 (esat wants all of it: rh =
     // (esat - vpd) / esat amplifies its error by 1 / rh in dry air).
     static __device__ __forceinline__ T exp_tab(T x, const T* tb) {
-        T kf = __builtin_rint(x * 92.33248261689366);               // 64 / ln 2
+        // k = rint(x 64 / ln 2) by the 1.5 * 2^52 shift: the integer is then the low word of
+        // the shifted sum (no v_cvt_i32_f64). |x| beyond 2^31 ln2 / 64 = 2.3e7 is not reduced
+        // properly any more (the callers' arguments are bounded: [-746, 0], or 17.3 tc / (tc + 237)
+        // of a temperature)
+        T km = __builtin_fma(x, 92.33248261689366, kRintShift);     // 64 / ln 2
+        T kf = km - kRintShift;
         T r = __builtin_fma(kf, -0x1.62e42fee00000p-7, x);          // ln2/64, 32-bit head
         r = __builtin_fma(kf, -0x1.a39ef35793c76p-39, r);
         T p = fma_kk(r, 1.0 / 120.0, 1.0 / 24.0);                   // |r| <= ln2/128
@@ -101,33 +107,35 @@ template <> struct FastMath<double> {
         p = __builtin_fma(p, r, 0.5);
         p = __builtin_fma(p, r, 1.0);
         p = __builtin_fma(p, r, 1.0);
-        int ki = (int)kf;
+        int ki = __double2loint(km);
         return __builtin_amdgcn_ldexp(tb[ki & 63] * p, ki >> 6);
     }
 
     // the same with a quartic: the first term left out is r^5/120 <= 4e-14 relative -- for
     // results that are not differenced afterwards (rh^(vpd/beta))
     static __device__ __forceinline__ T exp_tab4(T x, const T* tb) {
-        T kf = __builtin_rint(x * 92.33248261689366);
+        T km = __builtin_fma(x, 92.33248261689366, kRintShift);
+        T kf = km - kRintShift;
         T r = __builtin_fma(kf, -0x1.62e42fee00000p-7, x);
         r = __builtin_fma(kf, -0x1.a39ef35793c76p-39, r);
         T p = fma_kk(r, 1.0 / 24.0, 1.0 / 6.0);
         p = __builtin_fma(p, r, 0.5);
         p = __builtin_fma(p, r, 1.0);
         p = __builtin_fma(p, r, 1.0);
-        int ki = (int)kf;
+        int ki = __double2loint(km);
         return __builtin_amdgcn_ldexp(tb[ki & 63] * p, ki >> 6);
     }
 
     // the same to 4e-11 (cubic): for results that end up in float32 (mod16_mixed.hpp)
     static __device__ __forceinline__ T exp_tab3(T x, const T* tb) {
-        T kf = __builtin_rint(x * 92.33248261689366);
+        T km = __builtin_fma(x, 92.33248261689366, kRintShift);
+        T kf = km - kRintShift;
         T r = __builtin_fma(kf, -0x1.62e42fee00000p-7, x);
         r = __builtin_fma(kf, -0x1.a39ef35793c76p-39, r);
         T p = fma_kk(r, 1.0 / 6.0, 0.5);
         p = __builtin_fma(p, r, 1.0);
         p = __builtin_fma(p, r, 1.0);
-        int ki = (int)kf;
+        int ki = __double2loint(km);
         return __builtin_amdgcn_ldexp(tb[ki & 63] * p, ki >> 6);
     }
 

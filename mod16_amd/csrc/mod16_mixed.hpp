@@ -81,14 +81,16 @@ __device__ __forceinline__ void humid64(double t, double vpd, const double* tb, 
                                         bool& open_w) {
     typedef FastMath<double> M;
     double tc = t - K<double>::t0;
-    // exp to 4e-11 (cubic on the table's |r| <= ln2/128): the float32 results below keep 6e-8
-    double esat = __builtin_fma(1e3 * 0.6108, M::exp_tab3((17.27 * tc) * M::rcp(tc + 237.3), tb), tc * 0.0);
-    double avp = esat - vpd;
-    double resat = M::rcp(esat);
-    double rh = avp * resat;
-    rh = __builtin_fma(__builtin_fma(-rh, esat, avp), resat, rh);
-    rh = (rh > 1.0) ? 1.0 : rh;                 // flat selects (a nested conditional becomes a branch)
-    rh = (avp < 0.0) ? 0.0 : rh;
+    // exp to 4e-11 (cubic on the table's |r| <= ln2/128): the float32 results below keep 6e-8.
+    // (A NaN temperature stays NaN through exp_tab3; an infinite one through the reciprocal.)
+    double esat = (1e3 * 0.6108) * M::exp_tab3((17.27 * tc) * M::rcp(tc + 237.3), tb);
+    // rh = avp / esat = 1 - vpd / esat in one fma: exactly 1 for vpd = 0 (fwet = 1 and the
+    // 1 - fwet > 0 decision depend on it), 3e-14 absolute otherwise (the reciprocal's) -- the
+    // results are float32. The two clamps test the inputs themselves, as the reference's
+    // avp < 0 and rh > 1 do in exact arithmetic.
+    double rh = __builtin_fma(-vpd, M::rcp(esat), 1.0);
+    rh = (vpd < 0.0) ? 1.0 : rh;                // rh > 1 -> 1 (flat selects: a nested conditional becomes a branch)
+    rh = (vpd > esat) ? 0.0 : rh;               // avp < 0 -> 0
     dry = rh < 0.7;
     double rh2 = rh * rh;
     double fwet = dry ? 0.0 : rh2 * rh2;

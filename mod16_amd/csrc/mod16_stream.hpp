@@ -227,7 +227,13 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
     };
     int64_t v = vec_of(cbase, run);
     double dsum_d = 0, dsum_n = 0, dmax_d = -__builtin_huge_val(), dmax_n = -__builtin_huge_val();
+    float fmax_d = -__builtin_huge_valf(), fmax_n = -__builtin_huge_valf();   // mixed forms: maxima of float32 values
     unsigned nan_d = 0, nan_n = 0;
+    auto vmax_f32 = [](float a, float b) {     // maxNum as one v_max_f32 (results of arithmetic: already quiet)
+        float d;
+        asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+        return d;
+    };
 
     struct Ptrs { const char* w[NW]; const char* b[NB]; };
     // scalar loads from the kernel-argument segment, ahead of the wait for the DMA
@@ -381,14 +387,15 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
                     }
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const double d = (double)day2[e], g = (double)night2[e];
+                        // NaN -> 0 while still float32 (one v_cndmask, not two), sums in float64
+                        const float d = day2[e], g = night2[e];
                         const bool dn = d != d, gn = g != g;
                         nan_d += (unsigned)__builtin_popcountll(__ballot(dn));
                         nan_n += (unsigned)__builtin_popcountll(__ballot(gn));
-                        dsum_d += dn ? 0.0 : d;
-                        dsum_n += gn ? 0.0 : g;
-                        dmax_d = FastMath<double>::vmax(dmax_d, d);
-                        dmax_n = FastMath<double>::vmax(dmax_n, g);
+                        dsum_d += (double)(dn ? 0.f : d);
+                        dsum_n += (double)(gn ? 0.f : g);
+                        fmax_d = vmax_f32(fmax_d, d);
+                        fmax_n = vmax_f32(fmax_n, g);
                     }
                 }
             } else {
@@ -487,6 +494,11 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
         // fixed, the run's pixels are) or one per wave (static schedule: the wave's runs are)
         flushed = cb_n + run_n >= npiece || (run_n == 0 && !a.static_sched);
         if (flushed) {   // butterfly, then lanes 0..7 store the 8 fields
+            if constexpr (stream_is_mixed(MODE)) {
+                dmax_d = (double)fmax_d;
+                dmax_n = (double)fmax_n;
+                fmax_d = fmax_n = -__builtin_huge_valf();
+            }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 dsum_d += __shfl_xor(dsum_d, off, 64);
