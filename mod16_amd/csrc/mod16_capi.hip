@@ -272,7 +272,11 @@ template <typename T, int V>
 static void launch_variant(const EtArgs<T>& a, bool lut, bool fast, bool sep, bool dense,
                            int grid, hipStream_t st) {
     // FAST on float32 with 4 pixels per thread is never built (see launch_et): EXACT only
+#ifdef MOD16_REPRO_V4   // reproduction builds of DESIGN.md 5.2 only (tools/repro_v4.py)
+    constexpr bool kFastOk = true;
+#else
     constexpr bool kFastOk = !(std::is_same<T, float>::value && V == 4);
+#endif
     if (a.out[8] || a.out[9]) {   // potential ET wanted: the generic all-outputs form
 #define MOD16_LAUNCH_PET(LUT, FAST) \
     hipLaunchKernelGGL((et_kernel<T, V, LUT, FAST, true, false, true>), dim3(grid), dim3(kBlock), 0, st, a)
@@ -553,13 +557,15 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
     } else if (nbody) {
         EtArgs<T> b = a;
         b.n = nbody;
-        // float32 rasters with the FAST (float64) arithmetic: 2 pixels per thread. With 4
-        // the kernel needs ~400 registers and spills inside divergent code, and hipcc 7.2
-        // then miscompiles it (wrong values in ~10 % of the pixels of the potential-ET
-        // variant, found by tests/test_gpu_stream.py's boundary-size test).
+        // float32 rasters with the FAST (float64) arithmetic: 2 pixels per thread. The
+        // 4-pixel instances need ~400 registers; built from the round-1 sources at -O2 / -O3
+        // they computed wrong values (which instance goes wrong moves with the
+        // scheduler's settings, -O1 is right, today's sources are right) -- they stay unbuilt.
+#ifndef MOD16_REPRO_V4
         if (fast && std::is_same<T, float>::value)
             launch_variant<T, 2>(b, lut, fast, sep, dense, grid_for(ctx, nbody / 2), st);
         else
+#endif
             launch_variant<T, V>(b, lut, fast, sep, dense, grid_for(ctx, nbody / V), st);
     }
     if (nbody < a.n) {   // ragged tail (or unaligned input): scalar variant
