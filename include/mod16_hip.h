@@ -79,7 +79,18 @@ enum mod16_status {
 
 enum mod16_where { MOD16_HOST = 0, MOD16_DEVICE = 1 };
 
-/* flags of mod16_et_* */
+/* flags of mod16_et_*
+ *
+ * MOD16_MATH_FAST rearranges the smooth arithmetic (conductances instead of resistances,
+ * shared per-period terms, table exp / log) and keeps every comparison of the reference:
+ * within 1e-9 of the reference-order kernel, NaN and exact-zero masks identical, on finite
+ * drivers of physical magnitude -- NaN anywhere, zeros, the usual fill values in the
+ * radiation / albedo / VPD / fPAR / LAI fields included. Outside that domain (an infinite
+ * driver, magnitudes whose products overflow float64, a temperature above 1332 K where the
+ * latent heat of vaporization turns negative or exactly on the pole of the saturation
+ * formula at 35.85 K, a negative pressure) the reference computes garbage from garbage and
+ * FAST computes other garbage; MOD16_MATH_EXACT reproduces the reference's there as well
+ * (tests/test_gpu_parity.py::test_special_values_*, tools/fuzz_special_values.py). */
 #define MOD16_MATH_FAST   0u  /* strength-reduced arithmetic (default)          */
 #define MOD16_MATH_EXACT  1u  /* reference operation order, IEEE divide/pow     */
 #define MOD16_MATH_MIXED  2u  /* float32 rasters: float64 where it decides a mask or

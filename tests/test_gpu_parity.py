@@ -451,3 +451,67 @@ def test_rows_and_columns_over_several_staged_tiles(m16):
     assert got32[0].dtype == np.float32
     assert_parity(got32[0], want32[0].astype(np.float32), 1e-6, 'day f32')
     assert_parity(got32[1], want32[1].astype(np.float32), 1e-6, 'night f32')
+
+
+def _special_value_rasters(values, per=200, seed=123):
+    """Plausible drivers with one special value in one driver per pixel: `per` pixels for
+    every (driver, value) pair. Returns (class raster, 14 drivers, pair index per pixel)."""
+    rng = np.random.default_rng(seed)
+    n = per * 14 * len(values)
+    t_d = rng.uniform(255, 305, n)
+    t_n = t_d - rng.uniform(0, 12, n)
+    es = lambda t: 610.8 * np.exp(17.27 * (t - 273.15) / (t - 273.15 + 237.3))
+    drv = [rng.uniform(-100, 0, n), rng.uniform(-50, 0, n), rng.uniform(0, 360, n), np.zeros(n),
+           rng.uniform(0.1, 0.22, n), t_d, t_n, rng.uniform(265, 300, n), t_n - rng.uniform(0, 3, n),
+           es(t_d) * (1 - rng.uniform(0.05, 1, n)), es(t_n) * (1 - rng.uniform(0.05, 1, n)),
+           rng.uniform(7e4, 101340, n), rng.uniform(0.02, 0.89, n), rng.uniform(0.13, 5.34, n)]
+    which = np.repeat(np.arange(14 * len(values)), per)
+    for j in range(14):
+        for s, v in enumerate(values):
+            drv[j][which == j * len(values) + s] = v
+    cls = rng.choice(np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12], np.uint8), n)
+    return cls, drv, which
+
+
+def test_special_values_reference_order_kernel(m16, golden):
+    """Zeros, NaN, infinities, fill values, the pole of the Tetens formula (35.85 K), the
+    largest float32, 1e+-300 -- one of them in one driver per pixel, every driver: the kernel
+    that keeps the reference's operation order reproduces the oracle's NaN, zero AND inf masks
+    on all of them and the values to 1e-10 (whatever garbage the reference computes from
+    garbage, this computes the same)."""
+    values = [0.0, -0.0, np.nan, -9999.0, 65535.0, 1.0, -1.0, 1e-7, 273.15, 35.85, 34.15, 3.4e38,
+              -3.4e38, 1e300, -1e300, 1e-300, np.inf, -np.inf]
+    cls, drv, _ = _special_value_rasters(values)
+    table = golden('f3_random64_f64')['table']
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    with np.errstate(all='ignore'):
+        want = oracle.evapotranspiration_raster(bplut, cls, *drv)
+    got = m16.evapotranspiration_raster(table, cls, *drv, math=m16._lib.MATH_EXACT)
+    assert_parity(got[0], want[0], 1e-10, 'day')
+    assert_parity(got[1], want[1], 1e-10, 'night')
+
+
+def test_special_values_fast_kernel(m16, golden):
+    """The strength-reduced (default) arithmetic on the same construction, within its domain:
+    NaN anywhere, zeros, signed zeros, the usual fill values (-9999, 65535, +-3.4e38) and tiny
+    numbers in the radiation, albedo, VPD, fPAR and LAI fields, and NaN / 0 / -9999 / 1e-300 in
+    the temperatures and the pressure: masks identical, values to 1e-8. Outside it -- infinities,
+    magnitudes whose products overflow float64, a temperature above 1332 K (negative latent heat)
+    or exactly on the pole, a negative pressure -- the rearranged arithmetic computes other
+    garbage than the reference does (tools/fuzz_special_values.py lists the cases):
+    that is what MOD16_MATH_EXACT is for."""
+    values = [0.0, -0.0, np.nan, -9999.0, 65535.0, 1.0, 1e-7, 273.15, 34.15, 3.4e38, -3.4e38, 1e-300]
+    cls, drv, which = _special_value_rasters(values)
+    table = golden('f3_random64_f64')['table']
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    with np.errstate(all='ignore'):
+        want = oracle.evapotranspiration_raster(bplut, cls, *drv)
+    got = m16.evapotranspiration_raster(table, cls, *drv, math=m16._lib.MATH_FAST)
+    driver, value = which // len(values), np.array(values)[which % len(values)]
+    temperature = (driver >= 5) & (driver <= 8)
+    outside = (temperature & (np.abs(value) > 1300)) | ((driver == 11) & (value < 0)) | \
+        ((driver == 11) & (np.abs(value) > 1e30)) | ((driver == 13) & (np.abs(value) > 1e30))
+    keep = ~outside
+    assert keep.sum() > 0.85 * keep.size
+    assert_parity(got[0][keep], want[0][keep], 1e-8, 'day')
+    assert_parity(got[1][keep], want[1][keep], 1e-8, 'night')
