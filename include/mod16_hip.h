@@ -90,7 +90,7 @@ enum mod16_where { MOD16_HOST = 0, MOD16_DEVICE = 1 };
  * latent heat of vaporization turns negative or exactly on the pole of the saturation
  * formula at 35.85 K, a negative pressure) the reference computes garbage from garbage and
  * FAST computes other garbage; MOD16_MATH_EXACT reproduces the reference's there as well
- * (tests/test_gpu_parity.py::test_special_values_*, tools/fuzz_special_values.py). */
+ * (tests/test_gpu_parity.py::test_special_values_*, tests/fuzz_special_values.py). */
 #define MOD16_MATH_FAST   0u  /* strength-reduced arithmetic (default)          */
 #define MOD16_MATH_EXACT  1u  /* reference operation order, IEEE divide/pow     */
 #define MOD16_MATH_MIXED  2u  /* float32 rasters: float64 where it decides a mask or

@@ -2,7 +2,9 @@
 """Special values in the drivers (zeros, NaN, infinities, fill values, huge and tiny numbers): the
 EXACT and FAST kernels against the numpy oracle, one special value in one driver per pixel, and
 then pairs. Prints, per arithmetic, the pixels whose NaN / zero / inf masks differ from the
-oracle's, tallied by (driver, value). Uses oracle/ as the checker: a test tool, not product."""
+oracle's, tallied by (driver, value). Uses oracle/ as the checker, so it lives under tests/ (run it as a script:
+`python tests/fuzz_special_values.py`); the two assertions that came out of it are
+tests/test_gpu_parity.py::test_special_values_*."""
 import os
 import sys
 

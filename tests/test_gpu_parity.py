@@ -498,7 +498,7 @@ def test_special_values_fast_kernel(m16, golden):
     the temperatures and the pressure: masks identical, values to 1e-8. Outside it -- infinities,
     magnitudes whose products overflow float64, a temperature above 1332 K (negative latent heat)
     or exactly on the pole, a negative pressure -- the rearranged arithmetic computes other
-    garbage than the reference does (tools/fuzz_special_values.py lists the cases):
+    garbage than the reference does (tests/fuzz_special_values.py lists the cases):
     that is what MOD16_MATH_EXACT is for."""
     values = [0.0, -0.0, np.nan, -9999.0, 65535.0, 1.0, 1e-7, 273.15, 34.15, 3.4e38, -3.4e38, 1e-300]
     cls, drv, which = _special_value_rasters(values)
