@@ -95,7 +95,9 @@ enum mod16_where { MOD16_HOST = 0, MOD16_DEVICE = 1 };
 #define MOD16_MATH_EXACT  1u  /* reference operation order, IEEE divide/pow     */
 #define MOD16_MATH_MIXED  2u  /* float32 rasters: float64 where it decides a mask or
                                  feeds the humidity terms, packed float32 elsewhere
-                                 (dense class rasters; other shapes run FAST)       */
+                                 (dense class rasters; other shapes run FAST). Domain:
+                                 FAST's, less what overflows or underflows float32
+                                 products (a +-3.4e38 fill, a temperature near 0 K) */
 
 typedef struct mod16_ctx mod16_ctx;
 
