@@ -119,3 +119,16 @@ def test_no_kernel_spills_vector_registers(tmp_path):
         body = body.split('.section')[0]
         assert not re.search(r'^\s*scratch_(load|store)', body, flags=re.M), name
         assert not re.search(r'^\s*v_accvgpr_(read|write)', body, flags=re.M), name
+
+
+def test_form_table_matches_the_library():
+    """_lib.FORM_SHAPE (what TiledRaster allocates for a form) against mod16_form_shape()
+    (what mod16_et_form_tiled_* reads): same counts of wide arrays, byte rasters, outputs."""
+    import ctypes as C
+    from mod16_amd import _lib
+    lib = _lib.load()
+    nw, nb, no = C.c_int(), C.c_int(), C.c_int()
+    for form, shape in _lib.FORM_SHAPE.items():
+        assert lib.mod16_form_shape(form, C.byref(nw), C.byref(nb), C.byref(no)) == 0
+        assert (nw.value, nb.value, no.value) == shape, form
+    assert lib.mod16_form_shape(len(_lib.FORM_SHAPE), None, None, None) != 0
