@@ -16,7 +16,6 @@ import numpy as np  # noqa: E402
 
 def dump(path):
     os.environ['MOD16_NO_DMA'] = '1'            # plain kernels only
-    import torch
     from mod16_amd.raster import RasterEngine
     from mod16_amd.utils import restore_bplut, bplut_table
     from mod16_amd.models import COLLECTION61_BPLUT

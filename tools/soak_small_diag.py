@@ -3,9 +3,12 @@
 finishes last adds them up; agent-scope stores and loads, no fences): 60 x 64 launches per
 size and data type, three streams taking turns, every result compared bit for bit with the
 first and once with the stand-alone reduction."""
-import sys, torch, numpy as np
-sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
-from mod16_amd import _lib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 from mod16_amd.raster import RasterEngine
 from mod16_amd.utils import restore_bplut, bplut_table
 from mod16_amd.models import COLLECTION61_BPLUT
