@@ -242,8 +242,9 @@ def merge_compare(dst, src):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100,
+                    help='timed steps (default 100: a 2 s timed region on one MI355X)')
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--rows', type=int, default=21600, help='global raster rows')
     ap.add_argument('--cols', type=int, default=43200, help='global raster columns')
     ap.add_argument('--dtype', default='float64', choices=['float64', 'float32'])
