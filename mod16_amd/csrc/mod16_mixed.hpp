@@ -321,8 +321,12 @@ __device__ __forceinline__ void raw_pair_mixed(const float (&raw)[14][2], const 
     for (int j = 0; j < 2; ++j) {
         auto vpd = [&](double qv, double ps, double t) {                     // MOD16.vpd, :604-644
             const double tc = t - 273.15;
-            const double avp = (qv * ps) * M::rcp(0.622 + 0.379 * qv);
-            const double sv = __builtin_fma(610.7, M::exp_tab((17.38 * tc) * M::rcp(239.0 + tc), tb), tc * 0.0);
+            // one reciprocal for both quotients; the cubic exp (4e-11) is what the humidity
+            // section uses on the same quantity
+            const double d_avp = __builtin_fma(0.379, qv, 0.622), d_sv = 239.0 + tc;
+            const double r = M::rcp(d_avp * d_sv);
+            const double avp = (qv * ps) * (r * d_sv);
+            const double sv = 610.7 * M::exp_tab3((17.38 * tc) * (r * d_avp), tb);
             return sv - avp;
         };
         vpd64[0][j] = vpd(raw[9][j], raw[11][j], raw[5][j]);

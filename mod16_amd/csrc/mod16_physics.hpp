@@ -755,8 +755,12 @@ __device__ __forceinline__ PixelIn<double> raw_to_pixel_fast(const RawIn<double>
     x.t_d = r.t_d; x.t_n = r.t_n; x.t_ann = r.t_ann; x.tmin = r.tmin;
     auto vpd = [&](double qv, double ps, double t) {
         double tc = t - 273.15;
-        double avp = (qv * ps) * M::rcp(0.622 + 0.379 * qv);
-        double sv = __builtin_fma(610.7, M::exp_tab((17.38 * tc) * M::rcp(239.0 + tc), tb), tc * 0.0);
+        // both quotients from one reciprocal (of the product of the denominators); a NaN
+        // temperature stays NaN through exp_tab
+        double d_avp = __builtin_fma(0.379, qv, 0.622), d_sv = 239.0 + tc;
+        double r = M::rcp(d_avp * d_sv);
+        double avp = (qv * ps) * (r * d_sv);
+        double sv = 610.7 * M::exp_tab((17.38 * tc) * (r * d_avp), tb);
         return sv - avp;
     };
     x.vpd_d = vpd(r.qv_d, r.ps_d, r.t_d);
@@ -766,7 +770,7 @@ __device__ __forceinline__ PixelIn<double> raw_to_pixel_fast(const RawIn<double>
     double ratio = __builtin_fma(r.elev, -0.0065 / 288.15, 1.0);
     x.pa = 101325.0 * M::exp_tab(
         (9.80665 / (0.0065 * (8.3143 / 28.9644e-3))) * M::log_tab(ratio, tb), tb);
-    x.pa = (ratio == ratio) ? x.pa : ratio;      // log_tab's integer path drops a NaN
+    x.pa = __builtin_fma(ratio, 0.0, x.pa);      // log_tab's integer path drops a NaN: ratio * 0 carries it
     const double nan = __builtin_nan("");
     x.fpar = (r.fpar_pct >= 249u) ? nan : (double)r.fpar_pct * 0.01;
     x.lai = (r.lai_x10 >= 249u) ? nan : (double)r.lai_x10 * 0.1;
