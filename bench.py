@@ -99,6 +99,25 @@ def spawn(argv, gpus):
     return rc
 
 
+def gpu_process_census():
+    """Processes of this user that hold the GPU open (/dev/kfd), by command: the GPU boxes
+    allow 6 at a time (a 7th ends the whole run without a message), and under
+    torch.distributed.run the elastic agent can be one of them beside the ranks."""
+    found = []
+    for pid in os.listdir('/proc'):
+        if not pid.isdigit():
+            continue
+        try:
+            fds = os.listdir('/proc/%s/fd' % pid)
+            if any(os.readlink('/proc/%s/fd/%s' % (pid, fd)) == '/dev/kfd' for fd in fds):
+                with open('/proc/%s/cmdline' % pid, 'rb') as f:
+                    cmd = f.read().replace(b'\0', b' ').decode(errors='replace').strip()
+                found.append({'pid': int(pid), 'cmd': cmd[:120]})
+        except OSError:
+            continue
+    return found
+
+
 # -------------------------------------------------------------- CPU baseline
 def cpu_tile_seconds(reps):
     """Worker of the CPU baseline: time `reps` oracle runs on one tile."""
@@ -362,6 +381,8 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # MOD16_BENCH_CENSUS=1: who holds the GPU open while all ranks are up
+    census = gpu_process_census() if rank == 0 and os.environ.get('MOD16_BENCH_CENSUS') == '1' else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -524,6 +545,8 @@ def main():
             'configs': configs,
             'diagnostics': dict(zip(DIAG_NAMES, [float(v) for v in diag_host])),
         }
+        if census is not None:
+            line['gpu_process_census'] = census
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -282,7 +282,16 @@ static void launch_variant(const EtArgs<T>& a, bool lut, bool fast, bool sep, bo
     hipLaunchKernelGGL((et_kernel<T, V, LUT, FAST, true, false, true>), dim3(grid), dim3(kBlock), 0, st, a)
         if constexpr (kFastOk) {
             if (fast) {
-                if (lut) MOD16_LAUNCH_PET(true, true); else MOD16_LAUNCH_PET(false, true);
+                if (lut) {
+                    MOD16_LAUNCH_PET(true, true);
+                } else {
+                    // per-pixel parameter arrays + potential ET: one pixel per thread (with two,
+                    // the 25 inputs, 10 outputs and the guard's slow branch do not fit the
+                    // register budget of two waves per SIMD without spilling)
+                    const int g1 = (int)std::min<int64_t>((a.n + kBlock - 1) / kBlock, (int64_t)grid * V);
+                    hipLaunchKernelGGL((et_kernel<T, 1, false, true, true, false, true>), dim3(std::max(1, g1)),
+                                       dim3(kBlock), 0, st, a);
+                }
                 return;
             }
         }
@@ -297,9 +306,14 @@ static void launch_variant(const EtArgs<T>& a, bool lut, bool fast, bool sep, bo
             if (lut) {
                 if (sep) { if (dense) MOD16_LAUNCH(true, true, true, true); else MOD16_LAUNCH(true, true, true, false); }
                 else     { if (dense) MOD16_LAUNCH(true, true, false, true); else MOD16_LAUNCH(true, true, false, false); }
+            } else if (sep) {
+                // per-pixel parameter arrays + the six components: one pixel per thread (with two,
+                // 25 inputs, 8 outputs and the guard's slow branch spill two registers)
+                const int g1 = (int)std::min<int64_t>((a.n + kBlock - 1) / kBlock, (int64_t)grid * V);
+                hipLaunchKernelGGL((et_kernel<T, 1, false, true, true, false>), dim3(std::max(1, g1)),
+                                   dim3(kBlock), 0, st, a);
             } else {
-                if (sep) { if (dense) MOD16_LAUNCH(false, true, true, true); else MOD16_LAUNCH(false, true, true, false); }
-                else     { if (dense) MOD16_LAUNCH(false, true, false, true); else MOD16_LAUNCH(false, true, false, false); }
+                if (dense) MOD16_LAUNCH(false, true, false, true); else MOD16_LAUNCH(false, true, false, false);
             }
             return;
         }
@@ -447,6 +461,15 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     s.wide_pitch = pitched ? pitch_b / (ptrdiff_t)sizeof(T) : 0;
     if (pitched) hipLaunchKernelGGL((et_stream_kernel<T, MODE, true>), dim3(grid), dim3(kBlock), 0, st, s);
     else hipLaunchKernelGGL((et_stream_kernel<T, MODE, false>), dim3(grid), dim3(kBlock), 0, st, s);
+    // pixels outside the domain of the production arithmetic (mod16_physics.hpp, "domain
+    // guard"): a statically scheduled (small) raster has revisited them inside the kernel; a
+    // large one left one flag per piece in its runs' partials for this kernel
+    if (!g.static_sched) {
+        const int64_t groups = (nruns + 63) / 64;
+        const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>((groups + kBlock / 64 - 1) / (kBlock / 64),
+                                                                      (int64_t)ctx->cus * 4));
+        hipLaunchKernelGGL((et_stream_redo_kernel<T, MODE>), dim3(rgrid), dim3(kBlock), 0, st, s);
+    }
     if (ddiag && !fused_final) {
         const double* fin = ws->partial;
         int64_t count = nruns;

@@ -94,7 +94,7 @@ __device__ __forceinline__ void store_vec(T* __restrict__ p, int64_t i, const T 
 // parameter inputs), FAST = strength-reduced arithmetic, SEP = also store the
 // six components, DENSE = every driver is a dense array (no broadcast checks).
 template <typename T, int V, bool LUT, bool FAST, bool SEP, bool DENSE, bool PET = false>
-__global__ void __launch_bounds__(kBlock) et_kernel(const EtArgs<T> a) {
+__global__ void __launch_bounds__(kBlock, FAST ? 2 : 1) et_kernel(const EtArgs<T> a) {
     // FAST always computes in float64 (float32 data are widened on load and
     // the result rounded once on store); EXACT computes in the data type, as
     // numpy does for the reference code.
@@ -150,18 +150,29 @@ __global__ void __launch_bounds__(kBlock) et_kernel(const EtArgs<T> a) {
         }
         }
         T res[10][V];
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-            PixelIn<C> x = {(C)in[0][j], (C)in[1][j], (C)in[2][j], (C)in[3][j], (C)in[4][j],
-                            (C)in[5][j], (C)in[6][j], (C)in[7][j], (C)in[8][j], (C)in[9][j],
-                            (C)in[10][j], (C)in[11][j], (C)in[12][j], (C)in[13][j]};
+        unsigned bad = 0;      // FAST: bit j set = pixel j is outside the domain of that arithmetic
+        auto emit = [&](int j, const PixelOut<C>& o) {
+            // mod16/__init__.py:792: (canopy + soil) + transpiration
+            res[0][j] = (T)((o.canopy_d + o.soil_d) + o.trans_d);
+            res[1][j] = (T)((o.canopy_n + o.soil_n) + o.trans_n);
+            if (SEP) {
+                res[2][j] = (T)o.canopy_d;
+                res[3][j] = (T)o.soil_d;
+                res[4][j] = (T)o.trans_d;
+                res[5][j] = (T)o.canopy_n;
+                res[6][j] = (T)o.soil_n;
+                res[7][j] = (T)o.trans_n;
+            }
+            if (PET) {
+                res[8][j] = (T)o.pet_d;
+                res[9][j] = (T)o.pet_n;
+            }
+        };
+        // the class parameters of a pixel: its column of the table in LDS (class code c) or
+        // the 11 per-pixel / scalar parameter inputs
+        auto params = [&](unsigned c, auto&& par) {
             ClassPar<C> p;
             if (LUT) {
-                unsigned c = (cbits >> (8 * j)) & 0xffu;
-                if (c >= 13u) {   // numpy would raise IndexError: flag it, give NaN
-                    atomicOr(a.status, kStatusClassRange);
-                    c = 13u;
-                }
                 const C* l = lut + c;
                 p.tmin_close = l[0 * kLutCols];
                 p.tmin_open = l[1 * kLutCols];
@@ -181,36 +192,77 @@ __global__ void __launch_bounds__(kBlock) et_kernel(const EtArgs<T> a) {
                     p.inv_beta = l[14 * kLutCols];
                 }
             } else {
-                p.tmin_close = (C)pin[0][j];
-                p.tmin_open = (C)pin[1][j];
-                p.vpd_open = (C)pin[2][j];
-                p.vpd_close = (C)pin[3][j];
-                p.gl_sh = (C)pin[4][j];
-                p.gl_wv = (C)pin[5][j];
-                p.g_cut = (C)pin[6][j];
-                p.csl = (C)pin[7][j];
-                p.rbl_min = (C)pin[8][j];
-                p.rbl_max = (C)pin[9][j];
-                p.beta = (C)pin[10][j];
+                p.tmin_close = (C)par(0);
+                p.tmin_open = (C)par(1);
+                p.vpd_open = (C)par(2);
+                p.vpd_close = (C)par(3);
+                p.gl_sh = (C)par(4);
+                p.gl_wv = (C)par(5);
+                p.g_cut = (C)par(6);
+                p.csl = (C)par(7);
+                p.rbl_min = (C)par(8);
+                p.rbl_max = (C)par(9);
+                p.beta = (C)par(10);
                 if (FAST) p.derive();
             }
-            PixelOut<C> o;
-            if constexpr (FAST) o = et_pixel_fast<double, PET>(x, p, tab);
-            else o = et_pixel_exact<T, PET>(x, p);
-            // mod16/__init__.py:792: (canopy + soil) + transpiration
-            res[0][j] = (T)((o.canopy_d + o.soil_d) + o.trans_d);
-            res[1][j] = (T)((o.canopy_n + o.soil_n) + o.trans_n);
-            if (SEP) {
-                res[2][j] = (T)o.canopy_d;
-                res[3][j] = (T)o.soil_d;
-                res[4][j] = (T)o.trans_d;
-                res[5][j] = (T)o.canopy_n;
-                res[6][j] = (T)o.soil_n;
-                res[7][j] = (T)o.trans_n;
+            return p;
+        };
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            PixelIn<C> x = {(C)in[0][j], (C)in[1][j], (C)in[2][j], (C)in[3][j], (C)in[4][j],
+                            (C)in[5][j], (C)in[6][j], (C)in[7][j], (C)in[8][j], (C)in[9][j],
+                            (C)in[10][j], (C)in[11][j], (C)in[12][j], (C)in[13][j]};
+            unsigned c = 0;
+            if (LUT) {
+                c = (cbits >> (8 * j)) & 0xffu;
+                if (c >= 13u) {   // numpy would raise IndexError: flag it, give NaN
+                    atomicOr(a.status, kStatusClassRange);
+                    c = 13u;
+                }
             }
-            if (PET) {
-                res[8][j] = (T)o.pet_d;
-                res[9][j] = (T)o.pet_n;
+            const ClassPar<C> p = params(c, [&](int k) { return pin[k][j]; });
+            PixelOut<C> o;
+            if constexpr (FAST) {
+                o = et_pixel_fast<double, PET>(x, p, tab);
+                bad |= fast_out_of_domain(x) ? 1u << j : 0u;
+            } else {
+                o = et_pixel_exact<T, PET>(x, p);
+            }
+            emit(j, o);
+        }
+        if constexpr (FAST) {
+            // pixels outside the domain of the strength-reduced arithmetic: again, in the
+            // reference's operation order (mod16_physics.hpp, "domain guard"); a wave enters only
+            // if one of its lanes has such a pixel, every lane takes its own one at a time
+            if (__builtin_expect(__any(bad != 0u), 0)) {
+                unsigned pend = bad;
+#pragma nounroll
+                while (__any(pend != 0u)) {
+                    if (pend != 0u) {
+                        const int j = __builtin_ctz(pend);
+                        pend &= pend - 1u;
+                        // V > 1: the pixel's inputs again from memory (dense array or broadcast
+                        // scalar) -- keeping the V pixels' 14 + 11 inputs alive across this branch
+                        // would push the kernel over its register budget
+                        auto drv = [&](int k) -> double {
+                            if constexpr (V == 1) return (double)in[k][0];
+                            else return (double)((DENSE || ((a.dense_drv >> k) & 1u)) ? a.drv[k][i + j] : a.drv[k][0]);
+                        };
+                        auto par = [&](int k) -> double {
+                            if constexpr (V == 1) return (double)pin[k][0];
+                            else return (double)(((a.dense_par >> k) & 1u) ? a.par[k][i + j] : a.par[k][0]);
+                        };
+                        const PixelIn<double> x = {drv(0), drv(1), drv(2), drv(3), drv(4), drv(5), drv(6),
+                                                   drv(7), drv(8), drv(9), drv(10), drv(11), drv(12), drv(13)};
+                        unsigned c = (cbits >> (8 * j)) & 0xffu;
+                        c = c >= 13u ? 13u : c;
+                        const ClassPar<double> p = params(c, par);
+                        const PixelOut<double> o = et_pixel_exact<double, PET, true>(x, p);
+#pragma unroll
+                        for (int jj = 0; jj < V; ++jj)
+                            if (j == jj) emit(jj, o);
+                    }
+                }
             }
         }
 #pragma unroll

@@ -29,15 +29,21 @@ template <typename T> struct FastMath;   // float64 only: FAST kernels always co
 template <> struct FastMath<double> {
     typedef double T;
 
-    // x * m + c with two CONSTANTS m and c: one v_fma_f64 with m in a scalar register
-    // pair and c in a vector register pair. For this shape hipcc 7.2 emits v_mov_b64
+    // x * m + c with two CONSTANTS m and c: one v_fma_f64 with m and c in registers of their own. For this shape hipcc 7.2 emits v_mov_b64
     // (copy c) + v_fmac_f64 -- two vector instructions; 28 of them per pair of pixels.
+    // (m in a VECTOR register pair as well since round 3: the domain guard's few extra scalar
+    // values made the pipeline's loop spill scalar registers -- every "s" constant occupies a
+    // pair all through the loop, v_fma_f64 takes no literal on gfx9 -- while vector registers
+    // are to spare at two waves per SIMD. -DMOD16_KK_M='"s"' restores the scalar form.)
+#ifndef MOD16_KK_M
+#define MOD16_KK_M "v"
+#endif
     static __device__ __forceinline__ T fma_kk(T x, T m, T c) {
 #ifdef MOD16_NO_FMA_KK
         return __builtin_fma(x, m, c);
 #else
         T d;
-        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"(m), "v"(c));
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(x), MOD16_KK_M(m), "v"(c));
         return d;
 #endif
     }

@@ -417,8 +417,14 @@ __global__ void __launch_bounds__(kBlock) et_raw_kernel(const RawArgs<T> a) {
         p.inv_dtmin = l[11 * kLutCols]; p.inv_dvpd = l[12 * kLutCols];
         p.rbl_slope = l[13 * kLutCols]; p.inv_beta = l[14 * kLutCols];
         PixelOut<C> o;
-        if constexpr (FAST) o = et_pixel_fast<double>(raw_to_pixel_fast(r, tab), p, tab);
-        else o = et_pixel_exact<T>(raw_to_pixel_exact<T>(r), p);
+        if constexpr (FAST) {
+            o = et_pixel_fast<double>(raw_to_pixel_fast(r, tab), p, tab);
+            // outside the domain of the fast forms: the reference's operation order
+            // (mod16_physics.hpp, "domain guard")
+            if (raw_out_of_domain(r)) o = et_pixel_exact<double, false, true>(raw_to_pixel_exact<double, true>(r), p);
+        } else {
+            o = et_pixel_exact<T>(raw_to_pixel_exact<T>(r), p);
+        }
         C day = (o.canopy_d + o.soil_d) + o.trans_d;
         C night = (o.canopy_n + o.soil_n) + o.trans_n;
         if (a.out[0]) a.out[0][i] = (T)day;

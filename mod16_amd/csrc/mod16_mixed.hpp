@@ -343,6 +343,103 @@ __device__ __forceinline__ void raw_pair_mixed(const float (&raw)[14][2], const 
     in[11][0] = pa.x; in[11][1] = pa.y;
 }
 
+// ---- domain guard of the mixed-precision form (see mod16_physics.hpp, "domain guard").
+// float32 products leave their range long before float64 ones do, and the form is only
+// meant for physical drivers, so its domain is drawn tightly around them (mapped with
+// tests/fuzz_domain.py: outside it NaN / zero masks start to differ from the float64
+// arithmetic's, or values by more than 1e-3):
+//     |lw|, |sw|, |albedo|, |vpd|, |fpar|, |lai| < 1e5;  1e3 <= pressure < 1e7 Pa;
+//     90 K < temp_day, temp_night < 1332 K                  (NaN anywhere: inside)
+// Every condition is brought to the form |y| >= 1e5 -- the temperatures and the pressure by
+// one packed fma for both pixels -- and the twelve values of a pixel go through one chain of
+// v_max3_f32 with |.| modifiers, which ignores NaN operands: 8.5 vector instructions per pixel.
+// A flagged pixel is computed again by et_pixel_exact<double> on the widened inputs, like a
+// flagged pixel of the FAST form on a float32 raster (mod16_stream.hpp).
+__device__ __forceinline__ float max3_abs_f32(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+constexpr float kGuardMixed = 1e5f;
+// bit e set: pixel e of the pair has a |y[k]| >= 1e5
+template <int N>
+__device__ __forceinline__ unsigned pair_guard(const f2 (&y)[N]) {
+#ifdef MOD16_NO_GUARD
+    return 0u;
+#else
+    static_assert(N >= 3, "at least one v_max3");
+    unsigned bad = 0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        float m = max3_abs_f32(y[0][e], y[1][e], y[2][e]);
+#pragma unroll
+        for (int k = 3; k + 1 < N; k += 2) m = max3_abs_f32(m, y[k][e], y[k + 1][e]);
+        if ((N - 3) & 1) m = max3_abs_f32(m, y[N - 1][e], y[N - 1][e]);
+        bad |= (m >= kGuardMixed) ? 1u << e : 0u;
+    }
+    return bad;
+#endif
+}
+// 90 < t < 1332  <=>  |t - 711| < 621 ;  1e3 <= p < 1e7  <=>  |p - 5.0005e6| <= 4.9995e6
+__device__ __forceinline__ f2 guard_scale_t(f2 t) {
+    return __builtin_elementwise_fma(t, splat(kGuardMixed / 621.f), splat(-711.f * (kGuardMixed / 621.f)));
+}
+__device__ __forceinline__ f2 guard_scale_p(f2 p) {
+    return __builtin_elementwise_fma(p, splat(kGuardMixed / 4.9995e6f), splat(-5.0005e6f * (kGuardMixed / 4.9995e6f)));
+}
+__device__ __forceinline__ unsigned pair_out_of_domain(const float (&in)[14][2]) {
+    auto col = [&](int k) { return f2{in[k][0], in[k][1]}; };
+    const f2 y[12] = {col(0), col(1), col(2), col(3), col(4), col(9), col(10), col(12), col(13),
+                      guard_scale_t(col(5)), guard_scale_t(col(6)), guard_scale_p(col(11))};
+    return pair_guard<12>(y);
+}
+// raw drivers (raw_pair_mixed): the fields that pass through as above; specific humidity
+// below 1 kg/kg, the surface pressures like the air pressure, elevation below 40 km
+__device__ __forceinline__ unsigned raw_pair_out_of_domain(const float (&raw)[14][2]) {
+    auto col = [&](int k) { return f2{raw[k][0], raw[k][1]}; };
+    const f2 y[12] = {col(0), col(1), col(2), col(3), col(4), col(9) * splat(kGuardMixed),
+                      col(10) * splat(kGuardMixed), col(13) * splat(2.5f),
+                      guard_scale_t(col(5)), guard_scale_t(col(6)), guard_scale_p(col(11)),
+                      guard_scale_p(col(12))};
+    return pair_guard<12>(y);
+}
+
+// The same two guards for ONE pixel given as (widened) float64 values -- the slow branch
+// re-reads a pixel's inputs and asks again which of a thread's pixels it was. Same float32
+// operations as above, so the answer is the same.
+__device__ __forceinline__ bool guard_list_f32(const float* y, int n) {
+    float m = 0.f;
+    for (int k = 0; k < n; ++k) m = max3_abs_f32(m, y[k], y[k]);
+    return m >= kGuardMixed;
+}
+__device__ __forceinline__ float guard_scale_t1(float t) {
+    return __builtin_fmaf(t, kGuardMixed / 621.f, -711.f * (kGuardMixed / 621.f));
+}
+__device__ __forceinline__ float guard_scale_p1(float p) {
+    return __builtin_fmaf(p, kGuardMixed / 4.9995e6f, -5.0005e6f * (kGuardMixed / 4.9995e6f));
+}
+__device__ __forceinline__ bool out_of_domain_f32(const PixelIn<double>& x) {
+#ifdef MOD16_NO_GUARD
+    return false;
+#else
+    const float y[12] = {(float)x.lw_d, (float)x.lw_n, (float)x.sw_d, (float)x.sw_n, (float)x.alb,
+                         (float)x.vpd_d, (float)x.vpd_n, (float)x.fpar, (float)x.lai,
+                         guard_scale_t1((float)x.t_d), guard_scale_t1((float)x.t_n), guard_scale_p1((float)x.pa)};
+    return guard_list_f32(y, 12);
+#endif
+}
+__device__ __forceinline__ bool raw_out_of_domain_f32(const RawIn<double>& r) {
+#ifdef MOD16_NO_GUARD
+    return false;
+#else
+    const float y[12] = {(float)r.lw_d, (float)r.lw_n, (float)r.sw_d, (float)r.sw_n, (float)r.alb,
+                         (float)r.qv_d * kGuardMixed, (float)r.qv_n * kGuardMixed, (float)r.elev * 2.5f,
+                         guard_scale_t1((float)r.t_d), guard_scale_t1((float)r.t_n),
+                         guard_scale_p1((float)r.ps_d), guard_scale_p1((float)r.ps_n)};
+    return guard_list_f32(y, 12);
+#endif
+}
+
 // totals only (mod16/__init__.py:792: (canopy + soil) + transpiration)
 __device__ __forceinline__ void et_pair_mixed(const float (&in)[14][2], const double* l0,
                                               const double* l1, int ls, const double* tb,

@@ -276,12 +276,18 @@ __device__ __forceinline__ T pet_exact(const ClassPar<T>& p, const PixelIn<T>& x
     return (canopy + e / lhv) + ptr / lhv;
 }
 
-template <typename T, bool PET = false>
+// SERIAL: scheduling fences between the components, so that the code is laid out (and its
+// registers allocated) one component at a time -- for the slow branch of the production
+// kernels (domain guard below), where this function shares the register file with the
+// state of a pipeline that wants two waves per SIMD. Same operations, same results.
+template <typename T, bool PET = false, bool SERIAL = false>
 __device__ __forceinline__ PixelOut<T> et_pixel_exact(const PixelIn<T>& x, const ClassPar<T>& p) {
 #pragma clang fp contract(off)
     PixelOut<T> o;
     T rs_d, rs_n;
+    auto fence = [] { if (SERIAL) __builtin_amdgcn_sched_barrier(0); };
     rad_soil_exact(x, p, rs_d, rs_n);                             // :737
+    fence();
     {   // day, :751-792
         T rad_net = x.sw_d * (T(1) - x.alb) + x.lw_d;
         T rad_c = x.fpar * rad_net;
@@ -289,12 +295,17 @@ __device__ __forceinline__ PixelOut<T> et_pixel_exact(const PixelIn<T>& x, const
         T fw = fwet_exact(rh);
         T lhv = lhv_exact(x.t_d);
         T rc = rcorr_exact(x.pa, x.t_d);
+        fence();
         o.canopy_d = wet_canopy_exact(p, x.pa, x.t_d, x.vpd_d, x.lai, x.fpar, rad_c, lhv, rh, fw);
+        fence();
         o.soil_d = soil_exact(p, x.pa, x.t_d, x.vpd_d, x.fpar, rs_d, rc, lhv, rh, fw);
+        fence();
         o.trans_d = transpiration_exact<T, true>(p, x.pa, x.t_d, x.vpd_d, x.lai, x.fpar, rad_c,
                                                  x.tmin, rc, lhv, rh, fw);
+        fence();
         if (PET) o.pet_d = pet_exact(p, x, x.t_d, x.vpd_d, x.lw_d, x.sw_d, rs_d, o.canopy_d, rc, lhv, rh, fw);
     }
+    fence();
     {   // night
         T rad_net = x.sw_n * (T(1) - x.alb) + x.lw_n;
         T rad_c = x.fpar * rad_net;
@@ -302,10 +313,14 @@ __device__ __forceinline__ PixelOut<T> et_pixel_exact(const PixelIn<T>& x, const
         T fw = fwet_exact(rh);
         T lhv = lhv_exact(x.t_n);
         T rc = rcorr_exact(x.pa, x.t_n);
+        fence();
         o.canopy_n = wet_canopy_exact(p, x.pa, x.t_n, x.vpd_n, x.lai, x.fpar, rad_c, lhv, rh, fw);
+        fence();
         o.soil_n = soil_exact(p, x.pa, x.t_n, x.vpd_n, x.fpar, rs_n, rc, lhv, rh, fw);
+        fence();
         o.trans_n = transpiration_exact<T, false>(p, x.pa, x.t_n, x.vpd_n, x.lai, x.fpar, rad_c,
                                                   x.tmin, rc, lhv, rh, fw);
+        fence();
         if (PET) o.pet_n = pet_exact(p, x, x.t_n, x.vpd_n, x.lw_n, x.sw_n, rs_n, o.canopy_n, rc, lhv, rh, fw);
     }
     return o;
@@ -719,6 +734,76 @@ __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const 
     return o;
 }
 
+// =============================================================== domain guard
+// The strength-reduced arithmetic above is the reference's arithmetic rearranged, and a
+// rearrangement is only the same function where nothing overflows, no reciprocal meets a
+// zero and every sign is the physical one. Outside that domain -- a fill value left in a
+// temperature or the pressure, an infinity -- the reference (plain IEEE numpy,
+// mod16/__init__.py:646-673, :121, :795-864, :1340-1367) still returns definite NaN / zero /
+// inf / finite results, and the default arithmetic must return the same. The domain was
+// mapped on the GPU with a ladder of 56 magnitudes in every driver (tests/fuzz_domain.py,
+// profiles/r03_fuzz_domain_*.txt); et_pixel_fast differs from the reference exactly for
+//   - an infinite lw_net_day / lw_net_night / sw_rad_day / sw_albedo / fpar / vpd (inf * 0 or
+//     inf - inf where the reference has separate operations; vpd = -inf shows in the components
+//     only), |lai| or |pressure| >= 1e200 (products overflow),
+//   - a negative pressure (the merged clamps assume rho, r_corr > 0),
+//   - a temperature above 1332.4 K (latent heat <= 0: the reference's soil evaporation turns
+//     negative where the merged clamp gives 0) or within 2e-4 K of 35.85 K (the pole of the
+//     Tetens formula: the table exp is not reduced for |x| > 2.3e7);
+// NaN anywhere, zeros, negative or huge values elsewhere are inside the domain. The guard
+// below is wider than that map (1e100, everything below 36 K) and costs 15 vector
+// instructions per pixel; a pixel it flags is computed again by et_pixel_exact -- the
+// reference's own operation order -- in a branch that a wave enters only if one of its
+// lanes holds such a pixel (stream kernels: mod16_stream.hpp; plain kernels: et_kernel).
+// NaN compares false everywhere here: a NaN driver never sends a pixel to the slow branch.
+__device__ __forceinline__ double max_abs(double a, double b) {   // maxNum(|a|, |b|): ignores a NaN
+    double d;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ double max_abs_signed(double a, double b) {   // maxNum(|a|, b)
+    double d;
+    asm("v_max_f64 %0, |%1|, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+constexpr double kGuardHuge = 1e100;          // |x| at or beyond this (or infinite): reference order
+                                              // (the products of the fast form hold up to the square of 1e150)
+constexpr double kGuardTmin = 36.0;           // K; 35.85 K is the pole of the Tetens formula
+constexpr double kGuardTmax = 1332.0;         // K; latent heat of vaporization <= 0 from 1332.4 K
+
+// One chain of v_max_f64 with |.| modifiers over everything that has a bound -- NaN operands
+// are ignored, so a NaN driver never flags a pixel -- and ONE comparison at the end (one lane
+// mask: the pixel function itself already keeps the scalar registers full). The temperatures
+// enter as (t - 684) * (1e100 / 648): 36 < t < 1332 <=> |t - 684| < 648.
+// (The guard's constants live in VECTOR registers: the pixel function fills the scalar register
+// file with its own -- v_fma_f64 takes no literal on gfx9 -- and four more pairs there made the
+// loop spill scalar registers; vector registers are to spare at two waves per SIMD.)
+__device__ __forceinline__ double in_vgpr(double k) {
+    asm("" : "+v"(k));
+    return k;
+}
+__device__ __forceinline__ double guard_temperature(double t) {
+    constexpr double mid = 0.5 * (kGuardTmin + kGuardTmax), k = kGuardHuge / (0.5 * (kGuardTmax - kGuardTmin));
+    return __builtin_fma(t, in_vgpr(k), in_vgpr(-mid * k));
+}
+__device__ __forceinline__ bool fast_out_of_domain(const PixelIn<double>& x) {
+#ifdef MOD16_NO_GUARD      // measurement / mapping builds only (tests/fuzz_domain.py)
+    return false;
+#else
+    double m = max_abs(x.lw_d, x.lw_n);
+    m = max_abs(m, x.sw_d);
+    m = max_abs(m, x.alb);
+    m = max_abs(m, x.fpar);
+    m = max_abs(m, x.lai);
+    m = max_abs(m, x.pa);
+    m = max_abs(m, x.vpd_d);
+    m = max_abs(m, x.vpd_n);
+    m = max_abs(m, guard_temperature(x.t_d));
+    m = max_abs(m, guard_temperature(x.t_n));
+    return (m >= in_vgpr(kGuardHuge)) | (x.pa < 0.0);
+#endif
+}
+
 // ================================================================ raw drivers
 // the driver pre-processing the reference does in
 // front of the forward run (mod16/calibration.py:380-423) folded into the
@@ -732,15 +817,20 @@ template <typename T> struct RawIn {
     unsigned fpar_pct, lai_x10;
 };
 
-template <typename T> __device__ __forceinline__ PixelIn<T> raw_to_pixel_exact(const RawIn<T>& r) {
+template <typename T, bool SERIAL = false>
+__device__ __forceinline__ PixelIn<T> raw_to_pixel_exact(const RawIn<T>& r) {
 #pragma clang fp contract(off)
     PixelIn<T> x;
+    auto fence = [] { if (SERIAL) __builtin_amdgcn_sched_barrier(0); };   // see et_pixel_exact
     x.lw_d = r.lw_d; x.lw_n = r.lw_n; x.sw_d = r.sw_d; x.sw_n = r.sw_n; x.alb = r.alb;
     x.t_d = r.t_d; x.t_n = r.t_n; x.t_ann = r.t_ann; x.tmin = r.tmin;
     x.vpd_d = vpd_exact(r.qv_d, r.ps_d, r.t_d);
+    fence();
     T vn = vpd_exact(r.qv_n, r.ps_n, r.t_n);
     x.vpd_n = (vn < T(0)) ? T(0) : vn;
+    fence();
     x.pa = air_pressure_exact(r.elev);
+    fence();
     const T nan = __builtin_nan("");
     x.fpar = (r.fpar_pct >= 249u) ? nan : T(r.fpar_pct) / T(100);
     x.lai = (r.lai_x10 >= 249u) ? nan : T(r.lai_x10) / T(10);
@@ -775,6 +865,29 @@ __device__ __forceinline__ PixelIn<double> raw_to_pixel_fast(const RawIn<double>
     x.fpar = (r.fpar_pct >= 249u) ? nan : (double)r.fpar_pct * 0.01;
     x.lai = (r.lai_x10 >= 249u) ? nan : (double)r.lai_x10 * 0.1;
     return x;
+}
+
+// Domain of raw_to_pixel_fast + et_pixel_fast on raw drivers: as above for the fields that
+// pass through, plus what the fused pre-processing assumes: a specific humidity below 1 kg/kg
+// (0.379 qv + 0.622 > 0: one reciprocal serves both quotients), a finite surface pressure, an
+// elevation below 40 km (1 - 0.0065 z / 288.15 > 0: log_tab wants a positive normal number).
+// fPAR, LAI (byte decodings) and the air pressure (from the bounded elevation) cannot leave it.
+__device__ __forceinline__ bool raw_out_of_domain(const RawIn<double>& r) {
+#ifdef MOD16_NO_GUARD
+    return false;
+#else
+    double m = max_abs(r.lw_d, r.lw_n);
+    m = max_abs(m, r.sw_d);
+    m = max_abs(m, r.alb);
+    m = max_abs(m, r.ps_d);
+    m = max_abs(m, r.ps_n);
+    m = max_abs(m, r.qv_d * in_vgpr(kGuardHuge));          // |qv| < 1
+    m = max_abs(m, r.qv_n * in_vgpr(kGuardHuge));
+    m = max_abs(m, r.elev * in_vgpr(kGuardHuge / 4e4));  // |z| < 40 km
+    m = max_abs(m, guard_temperature(r.t_d));
+    m = max_abs(m, guard_temperature(r.t_n));
+    return m >= in_vgpr(kGuardHuge);
+#endif
 }
 
 }  // namespace mod16

@@ -172,11 +172,137 @@ template <> struct SlotRead<15, 3> {
 #undef MOD16_RD14
 #undef MOD16_W14
 
+// ---- The slow branch of the domain guard (mod16_physics.hpp): the pixels the production
+// arithmetic flagged, again, in the reference's operation order -- float64 whatever the storage
+// type, like the FAST form. NOT inside the pipeline's loop: there its ~3000 instructions made the
+// compiler hoist ~150 constants in front of the loop and keep them in registers all through it,
+// and the loop -- which fills the scalar register file on its own -- spilled (+9 % instructions
+// per iteration, +5.8 % kernel time, measured; a function call inside the loop did the same
+// through the calling convention's register classes). The loop only records WHICH pieces had
+// a flagged pixel -- one bit per piece in an otherwise unused field of the run's diagnostics
+// partial -- and poisons the flagged pixels (NaN fPAR -> both totals NaN, counted as NaN, nothing
+// added to the sums). Afterwards every flagged piece is revisited:
+//   - large rasters (dynamic schedule): et_stream_redo_kernel, launched behind the pipeline
+//     kernel, one wave per 64 runs: reads the masks, redoes the flagged pieces, corrects the
+//     runs' partials before the fixed-order sum adds them up;
+//   - small rasters (static schedule, latency-bound): every wave redoes its own flagged pieces
+//     behind its loop, before it stores its partial -- no second dispatch.
+// redo_piece: lane `lane`'s V pixels of piece `piece`: reads the inputs again from memory, asks
+// the guard again (exactly the hot path's predicate, so exactly the flagged pixels are redone),
+// stores the outputs element by element, and accumulates what the diagnostics must get back.
+struct RedoAcc {
+    double sum_d = 0.0, sum_n = 0.0, max_d = -__builtin_huge_val(), max_n = -__builtin_huge_val();
+    unsigned num_d = 0, num_n = 0;      // flagged pixels whose true total is a number (per lane)
+};
+
+template <typename T, int MODE>
+__device__ __forceinline__ void redo_piece(const StreamArgs<T>& a, const double* lut, int64_t piece, int lane,
+                                           RedoAcc& acc) {
+    typedef StreamSpec<MODE> S;
+    constexpr int V = 16 / (int)sizeof(T);
+    constexpr int NW = S::NW, NB = S::NB;
+    constexpr bool kSep6 = MODE == kStreamSep6 || MODE == kStreamSep6Mixed;
+    constexpr bool kSep8 = MODE == kStreamSep8 || MODE == kStreamSep8Mixed;
+    constexpr bool kPet = MODE == kStreamPet || MODE == kStreamPetMixed;
+    constexpr bool kHoursArr = MODE == kStreamRawTotalHours || MODE == kStreamRawTotalHoursMixed;
+    constexpr bool kTotal8 = kHoursArr || MODE == kStreamRawTotal || MODE == kStreamRawTotalMixed;
+    constexpr bool kRawAny = MODE == kStreamRaw || MODE == kStreamRawTotal || MODE == kStreamRawTotalHours ||
+                             MODE == kStreamRawMixed || MODE == kStreamRawTotalMixed ||
+                             MODE == kStreamRawTotalHoursMixed;
+    if ((piece * 64 + lane) * V >= a.n) return;          // the ragged last piece
+    const int64_t tile = piece >> a.tile_shift;
+    const int64_t q = (piece - (tile << a.tile_shift)) * (int64_t)(64 * V) + (int64_t)lane * V;
+    const int64_t ow = tile * a.wide_row + q, oo = tile * a.out_row + q, ob = tile * a.byte_row + q;
+#pragma nounroll
+    for (int j = 0; j < V; ++j) {
+        auto wide = [&](int k) -> double { return (double)a.wide[k][ow + j]; };
+        PixelIn<double> x;
+        RawIn<double> r;
+        bool out;
+        if constexpr (kRawAny) {
+            r = RawIn<double>{wide(0), wide(1), wide(2), wide(3), wide(4), wide(5), wide(6),
+                              wide(7), wide(8), wide(9), wide(10), wide(11), wide(12), wide(13),
+                              (unsigned)a.bytes[NB > 1 ? 1 : 0][ob + j], (unsigned)a.bytes[NB > 2 ? 2 : 0][ob + j]};
+            if constexpr (stream_is_mixed(MODE)) out = raw_out_of_domain_f32(r);
+            else out = raw_out_of_domain(r);
+        } else {
+            x = PixelIn<double>{wide(0), wide(1), wide(2), wide(3), wide(4), wide(5), wide(6),
+                                wide(7), wide(8), wide(9), wide(10), wide(11), wide(12), wide(13)};
+            if constexpr (stream_is_mixed(MODE)) out = out_of_domain_f32(x);
+            else out = fast_out_of_domain(x);
+        }
+        if (!out) continue;
+        if constexpr (kRawAny) x = raw_to_pixel_exact<double, true>(r);
+        unsigned c = a.bytes[0][ob + j];
+        c = c >= 13u ? 13u : c;
+        const double* l = lut + c;
+        ClassPar<double> p;
+        p.tmin_close = l[0 * kLutCols];
+        p.tmin_open = l[1 * kLutCols];
+        p.vpd_open = l[2 * kLutCols];
+        p.vpd_close = l[3 * kLutCols];
+        p.gl_sh = l[4 * kLutCols];
+        p.gl_wv = l[5 * kLutCols];
+        p.g_cut = l[6 * kLutCols];
+        p.csl = l[7 * kLutCols];
+        p.rbl_min = l[8 * kLutCols];
+        p.rbl_max = l[9 * kLutCols];
+        p.beta = l[10 * kLutCols];
+        const PixelOut<double> o = et_pixel_exact<double, kPet, true>(x, p);
+        const double day = (o.canopy_d + o.soil_d) + o.trans_d;      // :792
+        const double night = (o.canopy_n + o.soil_n) + o.trans_n;
+        auto put = [&](int k, double val) { a.out[k][oo + j] = (T)val; };
+        if constexpr (kSep6) {
+            put(0, o.canopy_d); put(1, o.soil_d); put(2, o.trans_d);
+            put(3, o.canopy_n); put(4, o.soil_n); put(5, o.trans_n);
+        } else {
+            put(0, day);
+            put(1, night);
+        }
+        if constexpr (kPet) { put(2, o.pet_d); put(3, o.pet_n); }
+        if constexpr (kSep8) {
+            put(2, o.canopy_d); put(3, o.soil_d); put(4, o.trans_d);
+            put(5, o.canopy_n); put(6, o.soil_n); put(7, o.trans_n);
+        }
+        if constexpr (kTotal8) {
+#pragma clang fp contract(off)
+            // tests/verification/verify2.py:113-115
+            double h = a.hours;
+            if constexpr (kHoursArr) h = wide(NW - 1);
+            put(2, (day * h * 8.0 * 60.0 * 60.0) + (night * (24.0 - h) * 8.0 * 60.0 * 60.0));
+        }
+        const double d = (double)(T)day, g = (double)(T)night;      // as stored
+        if (d == d) { acc.sum_d += d; acc.num_d += 1u; acc.max_d = d > acc.max_d ? d : acc.max_d; }
+        if (g == g) { acc.sum_n += g; acc.num_n += 1u; acc.max_n = g > acc.max_n ? g : acc.max_n; }
+    }
+}
+
+// Folds the lanes' corrections (fixed butterfly order) into the 8 fields of a partial held one
+// field per lane (lane k < 8 holds field k): sums += , NaN counts -= , maxima = max.
+__device__ __forceinline__ double redo_fold(const RedoAcc& acc, int lane, double f) {
+    double sd = acc.sum_d, sn = acc.sum_n, md = acc.max_d, mn = acc.max_n;
+    double nd = (double)acc.num_d, nn = (double)acc.num_n;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sd += __shfl_xor(sd, off, 64);
+        sn += __shfl_xor(sn, off, 64);
+        nd += __shfl_xor(nd, off, 64);
+        nn += __shfl_xor(nn, off, 64);
+        const double od = __shfl_xor(md, off, 64), on = __shfl_xor(mn, off, 64);
+        md = od > md ? od : md;
+        mn = on > mn ? on : mn;
+    }
+    return lane == 0 ? f + sd : lane == 1 ? f + sn : lane == 4 ? f - nd : lane == 5 ? f - nn
+         : lane == 6 ? (md > f ? md : f) : lane == 7 ? (mn > f ? mn : f) : f;
+}
+constexpr int kFlagField = 2;        // the field of a diagnostics partial that carries the flags
+constexpr int kFlagBits = 52;        // ... as an exact integer in a double
+
 // PITCHED: the wide arrays are equally spaced (one slab, as
 // RasterEngine.alloc_raster lays them out): array k's address is wide[0] +
 // k * pitch by two scalar adds instead of a pointer load.
 template <typename T, int MODE, bool PITCHED = false>
-__global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a) {
+__global__ void __launch_bounds__(kBlock, 2) et_stream_kernel(const StreamArgs<T> a) {
     typedef StreamSpec<MODE> S;
     constexpr int V = 16 / (int)sizeof(T);
     constexpr int NW = S::NW, NB = S::NB, NOUT = S::NOUT;
@@ -235,6 +361,34 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
         return d;
     };
 
+    unsigned long long flags = 0;      // pieces of the current run (static schedule: of this wave) with a flagged pixel
+    int iters = 0;                     // iterations this wave has done
+    const int64_t first_cbase = cbase;
+    // the 8 fields of a diagnostics partial, one per lane (lane k < 8: field k), from the
+    // accumulators, which are reset: butterfly sums in a fixed order; field kFlagField = `flags`
+    auto diag_fields = [&]() -> double {
+        if constexpr (stream_is_mixed(MODE)) {
+            dmax_d = (double)fmax_d;
+            dmax_n = (double)fmax_n;
+            fmax_d = fmax_n = -__builtin_huge_valf();
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            dsum_d += __shfl_xor(dsum_d, off, 64);
+            dsum_n += __shfl_xor(dsum_n, off, 64);
+            dmax_d = FastMath<double>::vmax(dmax_d, __shfl_xor(dmax_d, off, 64));
+            dmax_n = FastMath<double>::vmax(dmax_n, __shfl_xor(dmax_n, off, 64));
+        }
+        const double cnt_d = (double)__builtin_amdgcn_readfirstlane(nan_d);
+        const double cnt_n = (double)__builtin_amdgcn_readfirstlane(nan_n);
+        const double f = lane == 0 ? dsum_d : lane == 1 ? dsum_n : lane == kFlagField ? (double)flags
+                       : lane == 4 ? cnt_d : lane == 5 ? cnt_n : lane == 6 ? dmax_d : lane == 7 ? dmax_n : 0.0;
+        dsum_d = dsum_n = 0.0;
+        dmax_d = dmax_n = -__builtin_huge_val();
+        nan_d = nan_n = 0;
+        flags = 0;
+        return f;
+    };
     struct Ptrs { const char* w[NW]; const char* b[NB]; };
     // scalar loads from the kernel-argument segment, ahead of the wait for the DMA
     auto load_ptrs = [&](Ptrs& p) {
@@ -332,6 +486,14 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
 
         if (v < nvec) {   // only the last piece is ragged
             VT res[NOUT];
+            // `bad`: one of this thread's pixels lies outside the domain of the production arithmetic
+            // (mod16_physics.hpp, "domain guard"). Such a pixel gets a NaN fPAR, which makes both
+            // of its totals NaN whatever else it holds, so the diagnostics below count it as NaN
+            // and add nothing for it; what runs behind the loop computes it again in the
+            // reference's operation order and puts its true values into the outputs and the
+            // diagnostics (redo_piece). A raster without such pixels executes the instructions it
+            // did before the guard existed, plus the guard's (15 per pixel) and one select.
+            bool bad = false;
             if constexpr (stream_is_mixed(MODE)) {
                 static_assert(V == 4 || !stream_is_mixed(MODE), "the mixed form is for float32 rasters");
                 // class codes of the four pixels first (the range check's side effect would
@@ -355,13 +517,21 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
                     constexpr bool kRawMixed = MODE == kStreamRawMixed || MODE == kStreamRawTotalMixed ||
                                                MODE == kStreamRawTotalHoursMixed;
                     if constexpr (kRawMixed) {
-                        const unsigned fp[2] = {(bits[1] >> (8 * jj)) & 0xffu, (bits[1] >> (8 * jj + 8)) & 0xffu};
+                        unsigned fp[2] = {(bits[1] >> (8 * jj)) & 0xffu, (bits[1] >> (8 * jj + 8)) & 0xffu};
                         const unsigned lx[2] = {(bits[2] >> (8 * jj)) & 0xffu, (bits[2] >> (8 * jj + 8)) & 0xffu};
                         float din[14][2];
                         double vpd64[2][2];
+                        const unsigned b2 = raw_pair_out_of_domain(pin);
+                        bad |= b2 != 0u;
+                        fp[0] = (b2 & 1u) ? 255u : fp[0];        // a fill code: fPAR = NaN
+                        fp[1] = (b2 & 2u) ? 255u : fp[1];
                         raw_pair_mixed(pin, fp, lx, tab, din, vpd64);
                         et_pair_mixed_parts<false, true>(din, lut + c0, lut + c1, kLutCols, tab, pd, pn, vpd64, lutf + c0, lutf + c1);
                     } else {
+                        const unsigned b2 = pair_out_of_domain(pin);
+                        bad |= b2 != 0u;
+                        pin[12][0] = (b2 & 1u) ? __builtin_nanf("") : pin[12][0];
+                        pin[12][1] = (b2 & 2u) ? __builtin_nanf("") : pin[12][1];
                         et_pair_mixed_parts<MODE == kStreamPetMixed, true>(pin, lut + c0, lut + c1, kLutCols, tab, pd, pn, nullptr, lutf + c0, lutf + c1);
                     }
                     const f2 day2 = (pd.canopy + pd.soil) + pd.trans;        // :792
@@ -421,13 +591,20 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
                                        (double)in[9][j], (double)in[10][j], (double)in[11][j],
                                        (double)in[12][j], (double)in[13][j],
                                        (bits[1] >> (8 * j)) & 0xffu, (bits[2] >> (8 * j)) & 0xffu};
+                    const bool out = raw_out_of_domain(r);
+                    bad |= out;
                     x = raw_to_pixel_fast(r, tab);
+                    x.fpar = out ? __builtin_nan("") : x.fpar;
                 } else {
                     x = PixelIn<double>{(double)in[0][j], (double)in[1][j], (double)in[2][j],
                                         (double)in[3][j], (double)in[4][j], (double)in[5][j],
                                         (double)in[6][j], (double)in[7][j], (double)in[8][j],
                                         (double)in[9][j], (double)in[10][j], (double)in[11][j],
                                         (double)in[12][j], (double)in[13][j]};
+                    const bool out = fast_out_of_domain(x);
+                    bad |= out;
+                    // (the high word decides: 0x7ff80000'xxxxxxxx is a quiet NaN -- one v_cndmask)
+                    x.fpar = __hiloint2double(out ? 0x7ff80000 : __double2hiint(x.fpar), __double2loint(x.fpar));
                 }
                 const unsigned c = cls_of[j];
                 const double* l = lut + c;
@@ -489,39 +666,50 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
 #pragma unroll
             for (int k = 0; k < NOUT; ++k)
                 __builtin_nontemporal_store(res[k], reinterpret_cast<VT*>((a.out[k] + first) + lane_elem));
+            // a flagged pixel in this piece: remember the piece (see redo_piece above)
+            if (__builtin_expect(__any(bad), 0)) {
+                const int bit = a.static_sched ? iters : run;
+                flags |= 1ull << (bit < kFlagBits - 1 ? bit : kFlagBits - 1);
+            }
         }
+        ++iters;
         // diagnostics partial: one per run (dynamic schedule: which wave computes a run is not
-        // fixed, the run's pixels are) or one per wave (static schedule: the wave's runs are)
-        flushed = cb_n + run_n >= npiece || (run_n == 0 && !a.static_sched);
-        if (flushed) {   // butterfly, then lanes 0..7 store the 8 fields
-            if constexpr (stream_is_mixed(MODE)) {
-                dmax_d = (double)fmax_d;
-                dmax_n = (double)fmax_n;
-                fmax_d = fmax_n = -__builtin_huge_valf();
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                dsum_d += __shfl_xor(dsum_d, off, 64);
-                dsum_n += __shfl_xor(dsum_n, off, 64);
-                dmax_d = FastMath<double>::vmax(dmax_d, __shfl_xor(dmax_d, off, 64));
-                dmax_n = FastMath<double>::vmax(dmax_n, __shfl_xor(dmax_n, off, 64));
-            }
-            const double cnt_d = (double)__builtin_amdgcn_readfirstlane(nan_d);
-            const double cnt_n = (double)__builtin_amdgcn_readfirstlane(nan_n);
-            const double f = lane == 0 ? dsum_d : lane == 1 ? dsum_n : lane == 4 ? cnt_d
-                           : lane == 5 ? cnt_n : lane == 6 ? dmax_d : lane == 7 ? dmax_n : 0.0;
-            const int64_t slot = a.static_sched ? (int64_t)blockIdx.x * (kBlock / 64) + wave : cbase >> rs;
+        // fixed, the run's pixels are) or one per wave (static schedule: the wave's runs are;
+        // stored behind the loop, once the wave has revisited its flagged pieces)
+        flushed = !a.static_sched && (cb_n + run_n >= npiece || run_n == 0);
+        if (flushed) {
+            const double f = diag_fields();
             // (agent scope = written through to memory: the block that adds the partials up
             // may sit behind another L2)
             if (lane < kDiag)
-                __hip_atomic_store(a.diag_partial + slot * kDiag + lane, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            dsum_d = dsum_n = 0.0;
-            dmax_d = dmax_n = -__builtin_huge_val();
-            nan_d = nan_n = 0;
+                __hip_atomic_store(a.diag_partial + (cbase >> rs) * kDiag + lane, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         cbase = cb_n;
         run = run_n;
         v = vn;
+    }
+    // -- static schedule (small rasters): the wave's flagged pieces again in the reference's
+    // operation order, then its one partial. Iteration i of wave w was piece
+    // ((w + (i >> rs) nwaves) << rs) + (i & (rl - 1)); the last flag bit stands for every
+    // iteration from there on.
+    if (a.static_sched && first_cbase < npiece) {
+        const unsigned long long mine = flags;     // (diag_fields() stores and clears them)
+        double f = diag_fields();
+        if (__builtin_expect(mine != 0ull, 0)) {
+            RedoAcc acc;
+            const int64_t w0 = first_cbase >> rs;
+#pragma nounroll
+            for (int i = 0; i < iters; ++i) {
+                const int bit = i < kFlagBits - 1 ? i : kFlagBits - 1;
+                if (!((mine >> bit) & 1ull)) continue;
+                const int64_t piece = ((w0 + (int64_t)(i >> rs) * nwaves) << rs) + (i & (rl - 1));
+                redo_piece<T, MODE>(a, lut, piece, lane, acc);
+            }
+            f = redo_fold(acc, lane, f);
+        }
+        if (lane < kDiag)
+            __hip_atomic_store(a.diag_partial + ((int64_t)blockIdx.x * (kBlock / 64) + wave) * kDiag + lane, f,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // -- diagnostics of a small raster, finished in this launch: every block counts itself
     // done once its partials are in memory; the block that counts last adds all of them up in
@@ -587,6 +775,46 @@ __global__ void __launch_bounds__(kBlock) et_stream_kernel(const StreamArgs<T> a
         }
     }
 #endif
+}
+
+// The flagged pieces of a large raster (dynamic schedule), behind the pipeline kernel: a wave
+// takes 64 runs at a time (lane l reads the flag field of run r0 + l), and for every run with a
+// flag revisits its flagged pieces and corrects the run's partial -- it is the only one touching
+// that run here, and the fixed-order sum over the partials runs behind this kernel. A raster
+// without flagged pixels costs this kernel one 8-byte load per run (global grid: 3.5 MB).
+template <typename T, int MODE>
+__global__ void __launch_bounds__(kBlock) et_stream_redo_kernel(const StreamArgs<T> a) {
+    constexpr int V = 16 / (int)sizeof(T);
+    __shared__ double lut[MOD16_LUT_ROWS * kLutCols];
+    for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) lut[i] = a.lut64[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t npiece = (a.n / V + 63) / 64;
+    const int rs = a.run_shift;
+    for (int64_t r0 = wave * 64; r0 < a.nruns; r0 += nwaves * 64) {
+        const int64_t mine = r0 + lane;
+        const double fl = mine < a.nruns ? a.diag_partial[mine * kDiag + kFlagField] : 0.0;
+        unsigned long long any = __ballot(fl != 0.0);
+        while (any) {
+            const int src = __builtin_ctzll(any);
+            any &= any - 1ull;
+            const int64_t run = r0 + src;
+            const unsigned long long flags = (unsigned long long)__shfl(fl, src, 64);
+            RedoAcc acc;
+#pragma nounroll
+            for (int i = 0; i < (1 << rs); ++i) {
+                const int bit = i < kFlagBits - 1 ? i : kFlagBits - 1;
+                const int64_t piece = (run << rs) + i;
+                if (((flags >> bit) & 1ull) && piece < npiece) redo_piece<T, MODE>(a, lut, piece, lane, acc);
+            }
+            double* part = a.diag_partial + run * kDiag;
+            const double f = lane < kDiag ? part[lane] : 0.0;
+            const double g = redo_fold(acc, lane, f);
+            if (lane < kDiag) part[lane] = g;
+        }
+    }
 }
 
 }  // namespace mod16

@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Maps the domain of the strength-reduced (FAST) and mixed-precision arithmetic: one probe
+value in one driver per pixel, a ladder of magnitudes per driver, against the numpy oracle.
+Prints, per arithmetic and driver, the probe values at which a NaN / zero / inf mask differs
+from the oracle's or a value is off by more than 1e-8 (float64) / 1e-4 (mixed). With the
+domain guard in place (mod16_physics.hpp: fast_out_of_domain) every list must be empty; with
+MOD16_NO_GUARD=1 in the environment of the BUILD (-DMOD16_NO_GUARD) the lists are the map the
+guard was drawn from. Uses oracle/ as the checker, so it lives under tests/
+(`python tests/fuzz_domain.py`)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import mod16_amd as m16  # noqa: E402
+from mod16_amd.utils import restore_bplut, bplut_table  # noqa: E402
+from mod16_amd.models import COLLECTION61_BPLUT  # noqa: E402
+from oracle import mod16_oracle as oracle  # noqa: E402
+
+NAMES = ['lw_net_day', 'lw_net_night', 'sw_rad_day', 'sw_rad_night', 'sw_albedo', 'temp_day',
+         'temp_night', 'temp_annual', 'tmin', 'vpd_day', 'vpd_night', 'pressure', 'fpar', 'lai']
+LADDER = [0.0, -0.0, np.nan, np.inf, -np.inf, 1e-300, -1e-300, 1e-7, -1e-7, 1.0, -1.0, 34.15, 35.85,
+          50.0, 100.0, 120.0, 150.0, 180.0, 200.0, 273.15, 350.0, 400.0, 500.0, 700.0, 1000.0, 1300.0,
+          1332.0, 1400.0, 2000.0, -100.0, -273.15, -9999.0, 9999.0, 65535.0, 1e6, -1e6, 1e8, 1e10,
+          -1e10, 1e15, -1e15, 1e20, 1e25, 1e30, -1e30, 1e35, 3.4e38, -3.4e38, 1e45, 1e60, 1e100,
+          -1e100, 1e150, 1e200, 1e300, -1e300]
+
+
+def rasters(values, per, seed=123):
+    rng = np.random.default_rng(seed)
+    n = per * 14 * len(values)
+    t_d = rng.uniform(255, 305, n)
+    t_n = t_d - rng.uniform(0, 12, n)
+    es = lambda t: 610.8 * np.exp(17.27 * (t - 273.15) / (t - 273.15 + 237.3))
+    drv = [rng.uniform(-100, 0, n), rng.uniform(-50, 0, n), rng.uniform(0, 360, n), np.zeros(n),
+           rng.uniform(0.1, 0.22, n), t_d, t_n, rng.uniform(265, 300, n), t_n - rng.uniform(0, 3, n),
+           es(t_d) * (1 - rng.uniform(0.05, 1, n)), es(t_n) * (1 - rng.uniform(0.05, 1, n)),
+           rng.uniform(7e4, 101340, n), rng.uniform(0.02, 0.89, n), rng.uniform(0.13, 5.34, n)]
+    which = np.repeat(np.arange(14 * len(values)), per)
+    for j in range(14):
+        for s, v in enumerate(values):
+            drv[j][which == j * len(values) + s] = v
+    cls = rng.choice(np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12], np.uint8), n)
+    return cls, drv, which
+
+
+def report(name, got, want, which, values, tol, mixed=False):
+    n = which.size
+    bad = np.zeros(n, bool)
+    off = np.zeros(n, bool)
+    for g, w in zip(got, want):
+        g = g.astype(np.float64)
+        if mixed:   # parity.assert_mixed_parity: float32 subnormals count as zero, absolute bound
+            tiny = float(np.finfo(np.float32).tiny)
+            g = np.where(np.abs(g) < tiny, 0, g)
+            w = np.where(np.abs(w) < tiny, 0, w)
+        bad |= (np.isnan(g) != np.isnan(w)) | ((g == 0) != (w == 0)) | (np.isinf(g) != np.isinf(w))
+        ok = np.isfinite(w) & (w != 0) & np.isfinite(g)
+        rel = np.zeros(n)
+        rel[ok] = np.abs(g[ok] - w[ok]) / np.abs(w[ok])
+        if mixed and ok.any():
+            rel[ok] = np.where(np.abs(g[ok] - w[ok]) <= 1e-6 * np.abs(w[ok]).max(), 0, rel[ok])
+        off |= rel > tol
+    off &= ~bad
+    print('%s: %d of %d pixels with a mask that differs from the oracle, %d more off by > %g'
+          % (name, int(bad.sum()), n, int(off.sum()), tol))
+    for what, sel in (('masks', bad), ('values', off)):
+        tally = np.bincount(which[sel], minlength=14 * len(values)).reshape(14, len(values))
+        for j in range(14):
+            hits = ['%g' % values[s] for s in range(len(values)) if tally[j, s]]
+            if hits:
+                print('   %-6s %-13s %s' % (what, NAMES[j], ' '.join(hits)))
+    return int(bad.sum()), int(off.sum())
+
+
+def main():
+    table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    cls, drv, which = rasters(LADDER, per=128)
+    total = 0
+    with np.errstate(all='ignore'):
+        want = oracle.evapotranspiration_raster(bplut, cls, *drv)
+    got = m16.evapotranspiration_raster(table, cls, *drv, math=m16._lib.MATH_FAST)
+    total += sum(report('fast float64', got, want, which, LADDER, 1e-8))
+    with np.errstate(all='ignore'):
+        want6 = oracle.evapotranspiration_raster(bplut, cls, *drv, separate=True)
+    got6 = m16.evapotranspiration_raster(table, cls, *drv, separate=True, math=m16._lib.MATH_FAST)
+    for k, part in enumerate(('canopy', 'soil', 'transpiration')):
+        total += sum(report('fast float64, ' + part, [got6[0][k], got6[1][k]], [want6[0][k], want6[1][k]],
+                            which, LADDER, 1e-8))
+    # float32 rasters: the checker is the float64 oracle on the widened inputs, rounded once
+    lad32 = [v for v in LADDER if not np.isfinite(v) or v == 0 or 1e-37 < abs(v) < 3.41e38]
+    cls, drv, which = rasters(lad32, per=128)
+    d32 = [d.astype(np.float32) for d in drv]
+    with np.errstate(all='ignore'):
+        want = [w.astype(np.float32).astype(np.float64) for w in
+                oracle.evapotranspiration_raster(bplut, cls, *[d.astype(np.float64) for d in d32])]
+    got = m16.evapotranspiration_raster(table, cls, *d32, math=m16._lib.MATH_FAST)
+    total += sum(report('fast float32', got, want, which, lad32, 1e-6))
+    got = m16.evapotranspiration_raster(table, cls, *d32, math=m16._lib.MATH_MIXED)
+    total += sum(report('mixed float32', got, want, which, lad32, 1e-3, mixed=True))
+    total += raw_forms(table, bplut)
+    return 0 if total == 0 else 1
+
+
+RAW_NAMES = NAMES[:9] + ['qv10m_day', 'qv10m_night', 'ps_day', 'ps_night', 'elevation']
+RAW_LADDER = LADDER + [-1.7, -1.65, -0.5, 0.5, 0.99, 1.5, 8848.0, 2e4, 4e4, 44330.0, 44331.0, 5e4, -5e4]
+
+
+def raw_forms(table, bplut):
+    """The raw-driver forms (N1): special values in the raw fields."""
+    global NAMES
+    total = 0
+    for name, dtype, math, tol in (('raw float64', np.float64, m16._lib.MATH_FAST, 1e-8),
+                                   ('raw fast float32', np.float32, m16._lib.MATH_FAST, 1e-6),
+                                   ('raw mixed float32', np.float32, m16._lib.MATH_MIXED, 1e-3)):
+        values = RAW_LADDER if dtype == np.float64 else \
+            [v for v in RAW_LADDER if not np.isfinite(v) or v == 0 or 1e-37 < abs(v) < 3.41e38]
+        rng = np.random.default_rng(7)
+        per = 96
+        n = per * 14 * len(values)
+        t_d = rng.uniform(255, 305, n)
+        t_n = t_d - rng.uniform(0, 12, n)
+        raw = [rng.uniform(-100, 0, n), rng.uniform(-50, 0, n), rng.uniform(0, 360, n), np.zeros(n),
+               rng.uniform(0.1, 0.22, n), t_d, t_n, rng.uniform(265, 300, n), t_n - rng.uniform(0, 3, n),
+               rng.uniform(5e-4, 2e-2, n), rng.uniform(5e-4, 2e-2, n),
+               rng.uniform(70000, 101340, n), rng.uniform(70000, 101340, n), rng.uniform(-50, 4500, n)]
+        which = np.repeat(np.arange(14 * len(values)), per)
+        for j in range(14):
+            for s, v in enumerate(values):
+                raw[j][which == j * len(values) + s] = v
+        raw = [a.astype(dtype) for a in raw]
+        fpar = rng.integers(0, 101, n).astype(np.uint8)
+        lai = rng.integers(0, 70, n).astype(np.uint8)
+        cls = rng.choice(np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12], np.uint8), n)
+        with np.errstate(all='ignore'):
+            want = oracle.evapotranspiration_raw(bplut, cls, [a.astype(np.float64) for a in raw], fpar, lai)
+            want = [w.astype(dtype).astype(np.float64) for w in want]
+        got = m16.evapotranspiration_raw(table, cls, *raw, fpar, lai, math=math)
+        keep, NAMES = NAMES, RAW_NAMES
+        total += sum(report(name, got, want, which, values, tol, mixed=math == m16._lib.MATH_MIXED))
+        NAMES = keep
+    return total
+
+
+if __name__ == '__main__':
+    sys.exit(main())

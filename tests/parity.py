@@ -33,3 +33,27 @@ def assert_parity(got, want, rtol, what=''):
     err = rel_err(got, want)
     assert err <= rtol, '%s: max rel err %.3e > %.1e' % (what, err, rtol)
     return err
+
+
+def assert_mixed_parity(got, want, what='', rtol=1e-3, atol_of_max=1e-6):
+    """The float32 mixed-precision form against the float64 arithmetic rounded to float32: NaN
+    and inf masks identical; zero masks identical once float32 subnormals count as zero on both
+    sides (v_exp_f32 / v_rcp_f32 flush them: a result below 1.2e-38 is 0 or a subnormal at the
+    hardware's choice); every value within rtol OR within atol_of_max of the largest value (the
+    form bounds the absolute error: s A + rho Cp vpd / r_a cancels at night)."""
+    got = np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape and got.dtype == want.dtype == np.float32, (what, got.dtype, want.dtype)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), '%s: NaN masks differ' % what
+    assert np.array_equal(np.isinf(got), np.isinf(want)), '%s: inf masks differ' % what
+    tiny = np.finfo(np.float32).tiny
+    g = np.where(np.abs(got) < tiny, 0, got).astype(np.float64)
+    w = np.where(np.abs(want) < tiny, 0, want).astype(np.float64)
+    zg, zw = g == 0, w == 0
+    assert np.array_equal(zg, zw), '%s: zero masks differ at %d pixels' % (what, int((zg != zw).sum()))
+    ok = np.isfinite(w) & (w != 0)
+    if ok.any():
+        err = np.abs(g[ok] - w[ok])
+        bound = np.maximum(rtol * np.abs(w[ok]), atol_of_max * np.abs(w[ok]).max())
+        worst = float((err / bound).max())
+        assert worst <= 1, '%s: %.3g x the mixed form\'s tolerance' % (what, worst)

@@ -12,7 +12,7 @@ import pytest
 
 from oracle import mod16_oracle as oracle
 from oracle import synth
-from parity import assert_parity, rel_err
+from parity import assert_mixed_parity, assert_parity, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -491,27 +491,111 @@ def test_special_values_reference_order_kernel(m16, golden):
     assert_parity(got[1], want[1], 1e-10, 'night')
 
 
+SPECIAL_VALUES = [0.0, -0.0, np.nan, -9999.0, 65535.0, 1.0, -1.0, 1e-7, 273.15, 35.85, 34.15, 3.4e38,
+                  -3.4e38, 1e300, -1e300, 1e-300, np.inf, -np.inf, 1e15]
+
+
 def test_special_values_fast_kernel(m16, golden):
-    """The strength-reduced (default) arithmetic on the same construction, within its domain:
-    NaN anywhere, zeros, signed zeros, the usual fill values (-9999, 65535, +-3.4e38) and tiny
-    numbers in the radiation, albedo, VPD, fPAR and LAI fields, and NaN / 0 / -9999 / 1e-300 in
-    the temperatures and the pressure: masks identical, values to 1e-8. Outside it -- infinities,
-    magnitudes whose products overflow float64, a temperature above 1332 K (negative latent heat)
-    or exactly on the pole, a negative pressure -- the rearranged arithmetic computes other
-    garbage than the reference does (tests/fuzz_special_values.py lists the cases):
-    that is what MOD16_MATH_EXACT is for."""
-    values = [0.0, -0.0, np.nan, -9999.0, 65535.0, 1.0, 1e-7, 273.15, 34.15, 3.4e38, -3.4e38, 1e-300]
+    """The default (strength-reduced) arithmetic on the same construction, every value of the list
+    in every driver, nothing masked out: NaN, zero and inf masks identical to the oracle's, values
+    to 1e-8. Inside its domain the fast form computes them itself; a pixel outside it (an
+    infinity, a fill value left in a temperature or the pressure, the pole of the Tetens formula
+    -- mod16_physics.hpp, "domain guard") is computed again in the reference's operation order
+    inside the same kernel. MERRA-2's 1e15 fill is in the list as well."""
+    values = SPECIAL_VALUES
     cls, drv, which = _special_value_rasters(values)
     table = golden('f3_random64_f64')['table']
     bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
     with np.errstate(all='ignore'):
         want = oracle.evapotranspiration_raster(bplut, cls, *drv)
     got = m16.evapotranspiration_raster(table, cls, *drv, math=m16._lib.MATH_FAST)
-    driver, value = which // len(values), np.array(values)[which % len(values)]
-    temperature = (driver >= 5) & (driver <= 8)
-    outside = (temperature & (np.abs(value) > 1300)) | ((driver == 11) & (value < 0)) | \
-        ((driver == 11) & (np.abs(value) > 1e30)) | ((driver == 13) & (np.abs(value) > 1e30))
-    keep = ~outside
-    assert keep.sum() > 0.85 * keep.size
-    assert_parity(got[0][keep], want[0][keep], 1e-8, 'day')
-    assert_parity(got[1][keep], want[1][keep], 1e-8, 'night')
+    assert_parity(got[0], want[0], 1e-8, 'day')
+    assert_parity(got[1], want[1], 1e-8, 'night')
+    # the same pixels through the six components and the potential-ET outputs (other instances
+    # of the pipeline, same guard)
+    with np.errstate(all='ignore'):
+        want6 = oracle.evapotranspiration_raster(bplut, cls, *drv, separate=True)
+    got6 = m16.evapotranspiration_raster(table, cls, *drv, separate=True)
+    for g3, w3, period in zip(got6, want6, ('day', 'night')):
+        for g, w, part in zip(g3, w3, ('canopy', 'soil', 'transpiration')):
+            assert_parity(g, w, 1e-8, period + ' ' + part)
+    # one pixel per thread (ragged tail / unaligned) and per-pixel parameter arrays
+    n = cls.size - 3
+    params = {k: bplut[k][cls[1:n]] for k in oracle.PARAM_NAMES}
+    got1 = m16.MOD16(params).evapotranspiration(*[d[1:n] for d in drv])
+    assert_parity(got1[0], want[0][1:n], 1e-8, 'day, parameter arrays')
+    assert_parity(got1[1], want[1][1:n], 1e-8, 'night, parameter arrays')
+
+
+def test_special_values_float32_rasters(m16, golden):
+    """float32 rasters, FAST (float64 arithmetic, rounded once) and MIXED: every special value a
+    float32 can hold in every driver against the float64 oracle on the widened inputs. FAST: masks
+    identical, values to 1e-6. MIXED: masks identical; its values are held to the mixed form's
+    tolerance (1e-3 here; test_gpu_mixed.py has the distribution) -- outside its (tight) domain it
+    hands the pixel to the reference-order arithmetic like the FAST form does."""
+    values = [v for v in SPECIAL_VALUES if not np.isfinite(v) or v == 0 or 1e-37 < abs(v) < 3.41e38]
+    cls, drv, which = _special_value_rasters(values)
+    drv = [d.astype(np.float32) for d in drv]
+    table = golden('f3_random64_f64')['table']
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    with np.errstate(all='ignore'):
+        want = [w.astype(np.float32) for w in
+                oracle.evapotranspiration_raster(bplut, cls, *[d.astype(np.float64) for d in drv])]
+    got = m16.evapotranspiration_raster(table, cls, *drv, math=m16._lib.MATH_FAST)
+    assert_parity(got[0], want[0], 1e-6, 'day, fast')
+    assert_parity(got[1], want[1], 1e-6, 'night, fast')
+    got = m16.evapotranspiration_raster(table, cls, *drv, math=m16._lib.MATH_MIXED)
+    assert_mixed_parity(got[0], want[0], 'day, mixed')
+    assert_mixed_parity(got[1], want[1], 'night, mixed')
+
+
+def _raw_special_rasters(values, per=100, seed=321):
+    """Plausible raw drivers (mod16_raw_driver order) with one special value in one field per
+    pixel; uint8 fPAR / LAI with their fill codes sprinkled in."""
+    rng = np.random.default_rng(seed)
+    n = per * 14 * len(values)
+    t_d = rng.uniform(255, 305, n)
+    t_n = t_d - rng.uniform(0, 12, n)
+    raw = [rng.uniform(-100, 0, n), rng.uniform(-50, 0, n), rng.uniform(0, 360, n), np.zeros(n),
+           rng.uniform(0.1, 0.22, n), t_d, t_n, rng.uniform(265, 300, n), t_n - rng.uniform(0, 3, n),
+           rng.uniform(5e-4, 2e-2, n), rng.uniform(5e-4, 2e-2, n),
+           rng.uniform(70000, 101340, n), rng.uniform(70000, 101340, n), rng.uniform(-50, 4500, n)]
+    which = np.repeat(np.arange(14 * len(values)), per)
+    for j in range(14):
+        for s, v in enumerate(values):
+            raw[j][which == j * len(values) + s] = v
+    fpar = rng.integers(0, 101, n).astype(np.uint8)
+    lai = rng.integers(0, 70, n).astype(np.uint8)
+    fpar[rng.random(n) < 0.02] = 255
+    lai[rng.random(n) < 0.02] = 250
+    cls = rng.choice(np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12], np.uint8), n)
+    hours = rng.uniform(6, 18, n)
+    return cls, raw, fpar, lai, hours
+
+
+def test_special_values_raw_drivers(m16, golden):
+    """The raw-driver forms (pre-processing fused into the kernel) on special values in every raw
+    field -- specific humidity, surface pressure and elevation included -- against the oracle's
+    restatement of the reference's pre-processing + forward run: masks identical, values to 1e-8
+    (float64), 1e-6 (float32 rasters, float64 arithmetic), the mixed form's tolerance (parity.assert_mixed_parity)."""
+    values = SPECIAL_VALUES + [-1.7, 44330.0, 5e4, -5e4]
+    cls, raw, fpar, lai, hours = _raw_special_rasters(values)
+    table = golden('f3_random64_f64')['table']
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    with np.errstate(all='ignore'):
+        want = oracle.evapotranspiration_raw(bplut, cls, raw, fpar, lai, day_hours=hours)
+    got = m16.evapotranspiration_raw(table, cls, *raw, fpar, lai, day_hours=hours)
+    for g, w, what in zip(got, want, ('day', 'night', 'total8')):
+        assert_parity(g, w, 1e-8, what)
+    v32 = [v for v in values if not np.isfinite(v) or v == 0 or 1e-37 < abs(v) < 3.41e38]
+    cls, raw, fpar, lai, hours = _raw_special_rasters(v32)
+    raw32 = [a.astype(np.float32) for a in raw]
+    with np.errstate(all='ignore'):
+        want = [w.astype(np.float32) for w in oracle.evapotranspiration_raw(
+            bplut, cls, [a.astype(np.float64) for a in raw32], fpar, lai)]
+    got = m16.evapotranspiration_raw(table, cls, *raw32, fpar, lai, math=m16._lib.MATH_FAST)
+    for g, w, what in zip(got, want, ('day', 'night')):
+        assert_parity(g, w, 1e-6, what + ', float32 rasters')
+    got = m16.evapotranspiration_raw(table, cls, *raw32, fpar, lai, math=m16._lib.MATH_MIXED)
+    for g, w, what in zip(got, want, ('day', 'night')):
+        assert_mixed_parity(g, w, what + ', mixed')
