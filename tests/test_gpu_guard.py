@@ -1,0 +1,120 @@
+"""The domain guard on device-resident rasters (mod16_physics.hpp, "domain guard"): pixels
+outside the domain of the production arithmetic -- infinities, fill values in a temperature or the
+pressure, the pole of the Tetens formula -- sprinkled over a synthetic raster. The production
+kernel must give what the reference-order kernel gives on them (NaN / zero / inf masks identical,
+values to 1e-9; everywhere else it is the production arithmetic, bit for bit what it is without
+such pixels) and its in-kernel diagnostics must be those of its outputs -- on both schedules
+(small rasters revisit their flagged pieces inside the kernel, large ones in
+et_stream_redo_kernel), both layouts, float64 and float32 (FAST, MIXED), and through the oracle on
+windows."""
+import numpy as np
+import pytest
+
+from oracle import mod16_oracle as oracle
+from parity import assert_mixed_parity, assert_parity
+
+pytestmark = pytest.mark.gpu
+
+FILLS = [np.inf, -np.inf, -9999.0, 65535.0, 1e15, 3.4e38, -3.4e38, 35.85, 0.0, 1400.0]
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    from mod16_amd import _lib
+    from mod16_amd.raster import RasterEngine
+    from mod16_amd.utils import restore_bplut, bplut_table
+    from mod16_amd.models import COLLECTION61_BPLUT
+    table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
+    return torch, RasterEngine, table, _lib
+
+
+def sprinkle(torch, drv, n, every, seed):
+    """One fill value in one driver of every `every`-th pixel (and a block of 300 consecutive
+    pixels, so that whole waves are flagged too). Returns the number of touched pixels."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    idx = torch.arange(every // 2, n, every)
+    idx = torch.cat([idx, torch.arange(n // 3, min(n, n // 3 + 300))]).unique()
+    which = torch.randint(0, 14, (idx.numel(),), generator=g)
+    val = torch.tensor(FILLS, dtype=torch.float64)[torch.randint(0, len(FILLS), (idx.numel(),), generator=g)]
+    for k in range(14):
+        sel = which == k
+        drv[k][idx[sel].cuda()] = val[sel].to(drv[k].dtype).cuda()
+    return idx
+
+
+def host_diag(torch, day, night):
+    d = day.double()
+    g = night.double()
+    return [float(torch.nansum(d)), float(torch.nansum(g)), float((~torch.isnan(d)).sum()),
+            float((~torch.isnan(g)).sum()), float(torch.isnan(d).sum()), float(torch.isnan(g).sum()),
+            float(torch.where(torch.isnan(d), -np.inf, d).max()), float(torch.where(torch.isnan(g), -np.inf, g).max())]
+
+
+@pytest.mark.parametrize('n,every', [(1200 * 1200, 997), (1200 * 1200, 7), (40_000_000, 100_003), (40_000_000, 61),
+                                      (8192 * 40 + 4 * 777, 1)])
+@pytest.mark.parametrize('dtype,math', [('float64', 'fast'), ('float32', 'fast'), ('float32', 'mixed')])
+def test_flagged_pixels_on_device_rasters(env, n, every, dtype, math):
+    torch, RasterEngine, table, _lib = env
+    m = {'fast': _lib.MATH_FAST, 'mixed': _lib.MATH_MIXED}[math]
+    eng = RasterEngine(table, dtype=dtype, math=m)
+    ref = RasterEngine(table, dtype=dtype, math=_lib.MATH_EXACT if dtype == 'float64' else _lib.MATH_FAST)
+    cls, drv = eng.synth(n, seed=9, step=1)
+    clean_day, clean_night = eng.run(cls, drv)
+    clean_day, clean_night = clean_day.clone(), clean_night.clone()
+    idx = sprinkle(torch, drv, n, every, seed=n % 1000 + every).cuda()
+    diag = torch.zeros(8, dtype=torch.float64, device='cuda')
+    day, night = eng.run(cls, drv, diag=diag)
+    eng.check()
+    # untouched pixels: what they were without the flagged ones around them, bit for bit
+    keep = torch.ones(n, dtype=torch.bool, device='cuda')
+    keep[idx] = False
+    for got, was in ((day, clean_day), (night, clean_night)):
+        if math == 'mixed':
+            # (the mixed form redoes the radiation balance of a whole WAVE in float64 when one
+            # of its pixels sits next to a discontinuity -- mod16_mixed.hpp -- and a fill value
+            # does: the neighbours' float32 results move within the form's tolerance)
+            assert_mixed_parity(got[keep].cpu().numpy(), was[keep].cpu().numpy(), 'untouched pixels',
+                                rtol=1e-4, atol_of_max=1e-6)
+        else:
+            assert torch.equal(torch.nan_to_num(got[keep], nan=-7.0), torch.nan_to_num(was[keep], nan=-7.0))
+    # touched pixels: the reference-order arithmetic's results
+    sub_cls = cls[idx].contiguous()
+    sub_drv = [d[idx].contiguous() for d in drv]
+    want = ref.run(sub_cls, sub_drv)
+    ref.check()
+    for got, w, what in ((day[idx], want[0], 'day'), (night[idx], want[1], 'night')):
+        g_np, w_np = got.cpu().numpy(), w.cpu().numpy()
+        if math == 'mixed':
+            assert_mixed_parity(g_np, w_np, what)
+        else:
+            assert_parity(g_np, w_np, 1e-9 if dtype == 'float64' else 1e-6, what)
+    # ... and, on a window, the oracle's
+    if dtype == 'float64':
+        bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+        with np.errstate(all='ignore'):
+            o_day, o_night = oracle.evapotranspiration_raster(
+                bplut, cls[idx[:20000]].cpu().numpy(), *[d[idx[:20000]].cpu().numpy() for d in drv])
+        assert_parity(day[idx[:20000]].cpu().numpy(), o_day, 1e-8, 'day vs oracle')
+        assert_parity(night[idx[:20000]].cpu().numpy(), o_night, 1e-8, 'night vs oracle')
+    # the diagnostics are those of the outputs
+    got = diag.cpu().numpy()
+    want_d = host_diag(torch, day, night)
+    assert np.array_equal(got[2:6], want_d[2:6]), (got, want_d)
+    for k in (0, 1):
+        assert np.isclose(got[k], want_d[k], rtol=1e-11 if np.isfinite(want_d[k]) else 0, equal_nan=True) or \
+            (np.isinf(want_d[k]) and got[k] == want_d[k]), (k, got[k], want_d[k])
+    assert got[6] == want_d[6] and got[7] == want_d[7], (got, want_d)
+    # the tiled layout: same bits, outputs and diagnostics
+    r = eng.to_tiled(cls, drv)
+    d_tiled = torch.zeros(8, dtype=torch.float64, device='cuda')
+    eng.run_tiled(r, diag=d_tiled)
+    eng.check()
+    assert torch.equal(torch.nan_to_num(r.flat(r.day), nan=-7.0), torch.nan_to_num(day, nan=-7.0))
+    assert torch.equal(torch.nan_to_num(r.flat(r.night), nan=-7.0), torch.nan_to_num(night, nan=-7.0))
+    assert np.array_equal(d_tiled.cpu().numpy()[2:], got[2:])
+    assert np.allclose(d_tiled.cpu().numpy()[:2], got[:2], rtol=1e-12, equal_nan=True)
+    # repeated launches: same bits
+    d2 = torch.zeros(8, dtype=torch.float64, device='cuda')
+    eng.run(cls, drv, out_day=day, out_night=night, diag=d2)
+    assert torch.equal(torch.nan_to_num(d2, nan=-7.0), torch.nan_to_num(diag, nan=-7.0))
