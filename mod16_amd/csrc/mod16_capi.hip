@@ -464,12 +464,14 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     // pixels outside the domain of the production arithmetic (mod16_physics.hpp, "domain
     // guard"): a statically scheduled (small) raster has revisited them inside the kernel; a
     // large one left one flag per piece in its runs' partials for this kernel
+#ifndef MOD16_NO_REDO_LAUNCH
     if (!g.static_sched) {
         const int64_t groups = (nruns + 63) / 64;
         const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>((groups + kBlock / 64 - 1) / (kBlock / 64),
                                                                       (int64_t)ctx->cus * 4));
         hipLaunchKernelGGL((et_stream_redo_kernel<T, MODE>), dim3(rgrid), dim3(kBlock), 0, st, s);
     }
+#endif
     if (ddiag && !fused_final) {
         const double* fin = ws->partial;
         int64_t count = nruns;

@@ -751,7 +751,7 @@ __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const 
 //     negative where the merged clamp gives 0) or within 2e-4 K of 35.85 K (the pole of the
 //     Tetens formula: the table exp is not reduced for |x| > 2.3e7);
 // NaN anywhere, zeros, negative or huge values elsewhere are inside the domain. The guard
-// below is wider than that map (1e100, everything below 36 K) and costs 15 vector
+// below is wider than that map (1e100, everything below 36 K) and costs 13 vector
 // instructions per pixel; a pixel it flags is computed again by et_pixel_exact -- the
 // reference's own operation order -- in a branch that a wave enters only if one of its
 // lanes holds such a pixel (stream kernels: mod16_stream.hpp; plain kernels: et_kernel).
@@ -790,9 +790,12 @@ __device__ __forceinline__ bool fast_out_of_domain(const PixelIn<double>& x) {
 #ifdef MOD16_NO_GUARD      // measurement / mapping builds only (tests/fuzz_domain.py)
     return false;
 #else
-    double m = max_abs(x.lw_d, x.lw_n);
-    m = max_abs(m, x.sw_d);
-    m = max_abs(m, x.alb);
+    // lw_net_day, sw_rad_day and sw_albedo through the day's net radiation A = sw (1 - albedo) +
+    // lw, which the pixel function needs anyway: an infinite one of them makes A infinite -- or
+    // NaN (inf * 0, inf - inf), and then it is NaN in the reference as well and behaves like a
+    // NaN driver, which is inside the domain. (Finite huge values of these three are inside it.)
+    const double a_d = __builtin_fma(x.sw_d, 1.0 - x.alb, x.lw_d);
+    double m = max_abs(a_d, x.lw_n);
     m = max_abs(m, x.fpar);
     m = max_abs(m, x.lai);
     m = max_abs(m, x.pa);
@@ -876,9 +879,8 @@ __device__ __forceinline__ bool raw_out_of_domain(const RawIn<double>& r) {
 #ifdef MOD16_NO_GUARD
     return false;
 #else
-    double m = max_abs(r.lw_d, r.lw_n);
-    m = max_abs(m, r.sw_d);
-    m = max_abs(m, r.alb);
+    const double a_d = __builtin_fma(r.sw_d, 1.0 - r.alb, r.lw_d);      // see fast_out_of_domain
+    double m = max_abs(a_d, r.lw_n);
     m = max_abs(m, r.ps_d);
     m = max_abs(m, r.ps_n);
     m = max_abs(m, r.qv_d * in_vgpr(kGuardHuge));          // |qv| < 1

@@ -301,8 +301,11 @@ constexpr int kFlagBits = 52;        // ... as an exact integer in a double
 // PITCHED: the wide arrays are equally spaced (one slab, as
 // RasterEngine.alloc_raster lays them out): array k's address is wide[0] +
 // k * pitch by two scalar adds instead of a pointer load.
+// (no second __launch_bounds__ argument: asking for two waves per SIMD outright made hipcc pick a
+// schedule 1.2 % slower for the same 188 registers -- profiles/r03_ab_bisect.txt)
+#define MOD16_STREAM_BOUNDS __launch_bounds__(kBlock)
 template <typename T, int MODE, bool PITCHED = false>
-__global__ void __launch_bounds__(kBlock, 2) et_stream_kernel(const StreamArgs<T> a) {
+__global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     typedef StreamSpec<MODE> S;
     constexpr int V = 16 / (int)sizeof(T);
     constexpr int NW = S::NW, NB = S::NB, NOUT = S::NOUT;
