@@ -67,31 +67,64 @@ def free_port():
         return s.getsockname()[1]
 
 
-def spawn_command(argv, gpus, port):
-    """The command line of the child that runs the N ranks."""
-    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-            '--nproc-per-node', str(gpus), '--master-addr', '127.0.0.1',
-            '--master-port', str(port), os.path.join(ROOT, 'bench.py')] + list(argv)
+def rank_env(base, rank, gpus, port):
+    """Environment of rank `rank` of an N-rank run on this node (what
+    torch.distributed.run would export)."""
+    env = dict(base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return env
 
 
 def spawn(argv, gpus):
-    """Parent of a multi-GPU run: starts the ranks as a child process (never an
-    exec: this process must stay clear of the GPU and simply waits), relays the
-    one JSON line of rank 0 and returns the child's exit code."""
-    env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    env.setdefault('OMP_NUM_THREADS', '4')
-    cmd = spawn_command(argv, gpus, free_port())
-    proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
-    line = None
-    for out in proc.stdout:
-        text = out.strip()
-        if text.startswith('{') and '"metric"' in text:
-            line = text
-        else:
-            sys.stderr.write(out)
-    rc = proc.wait()
-    if line is not None:
+    """Parent of a multi-GPU run started as plain `python bench.py --gpus N`: starts the N
+    ranks itself as child processes (never an exec: this process must stay clear of the GPU
+    and simply waits), relays the one JSON line of rank 0 and returns non-zero if any rank
+    failed. The ranks are started directly, not through torch.distributed.run: its elastic
+    agent holds the GPU open as well (/dev/kfd, seen with MOD16_BENCH_CENSUS=1), which is one
+    GPU process more than the ranks -- on the one-GPU boxes, which allow six, that silently
+    ended the 6-rank rehearsal of round 2. Under torch.distributed.run
+    (the driver's launch line) this function is not involved: the process is a rank."""
+    port = free_port()
+    script = os.path.join(ROOT, 'bench.py')
+    procs = []
+    for r in range(gpus):
+        procs.append(subprocess.Popen(
+            [sys.executable, '-u', script] + list(argv), cwd=ROOT, env=rank_env(os.environ, r, gpus, port),
+            stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    import threading
+    lines = []
+
+    def relay():
+        for out in procs[0].stdout:
+            text = out.strip()
+            if text.startswith('{') and '"metric"' in text:
+                lines.append(text)
+            else:
+                sys.stderr.write(out)
+
+    reader = threading.Thread(target=relay, daemon=True)
+    reader.start()
+    # wait for all ranks; once one has failed the others cannot finish a collective: give them
+    # 30 s, then end them (these very children, by their handles)
+    deadline = None
+    while any(proc.poll() is None for proc in procs):
+        if deadline is None and any(proc.poll() not in (None, 0) for proc in procs):
+            deadline = time.monotonic() + 30
+        if deadline is not None and time.monotonic() > deadline:
+            for proc in procs:
+                if proc.poll() is None:
+                    proc.kill()
+        time.sleep(0.1)
+    codes = [proc.wait() for proc in procs]
+    reader.join(timeout=10)
+    line = lines[-1] if lines else None
+    rc = next((c for c in codes if c != 0), 0)
+    if rc != 0:
+        sys.stderr.write('bench.py: rank exit codes %s\n' % codes)
+    if line is not None and rc == 0:
         print(line, flush=True)
     elif rc == 0:
         sys.stderr.write('bench.py: the ranks exited without a result line\n')
@@ -213,12 +246,17 @@ def plumbing_rank(args, rank, world):
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group('gloo', rank=rank, world_size=world)
+    from mod16_amd import dist as tiles
     seen = torch.ones(1, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(seen)
+    # the product's reduction of the diagnostics vector (one gather, rank order)
+    diag = torch.tensor([rank, 1, 0, 0, 0, 0, rank, -rank], dtype=torch.float64)
+    tiles.allreduce_diag(diag)
     if rank == 0:
         print(json.dumps({'metric': 'plumbing rehearsal, no measurement', 'value': None,
                           'n_gpus': world, 'ranks_seen': int(seen.item()),
+                          'diag_reduced': diag.tolist(),
                           'steps': args.steps, 'warmup': args.warmup}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -275,6 +313,9 @@ def main():
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-plain', action='store_true',
                     help='skip timing the same kernel on 16 plain arrays (profiled runs: one layout per kernel symbol)')
+    ap.add_argument('--plain', action='store_true',
+                    help='N > 1: time the plain-array layout as well (default: N = 1 only -- its set-up tries '
+                         'seven slab spacings of up to 12 GiB of slack per rank, which a scaling run has no use for)')
     ap.add_argument('--no-configs', action='store_true',
                     help='skip the other BASELINE.json configurations (1200x1200 tile, series, float32)')
     ap.add_argument('--cpu-workers', type=int, default=16)
@@ -364,14 +405,18 @@ def main():
     reduced = [torch.cuda.Event() for _ in range(2)]
     counter = [0]
 
-    def step():
+    def step(events=None):
         k = counter[0] & 1
         counter[0] += 1
         if comm_stream is None:
             steps_bound[k]()
             return
-        main_stream.wait_event(reduced[k])          # the all-reduce that last used this vector
+        main_stream.wait_event(reduced[k])          # the reduction that last used this vector
+        if events is not None:
+            events[0].record(main_stream)
         steps_bound[k]()
+        if events is not None:
+            events[1].record(main_stream)
         produced[k].record(main_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(produced[k])
@@ -383,24 +428,41 @@ def main():
     fence()
     # MOD16_BENCH_CENSUS=1: who holds the GPU open while all ranks are up
     census = gpu_process_census() if rank == 0 and os.environ.get('MOD16_BENCH_CENSUS') == '1' else None
+    # the dominant kernel is timed INSIDE the timed steps: an event pair on the launch stream
+    # around every step's graph launch (counter reset + pipeline kernel + the kernel that revisits
+    # flagged pixels + the fixed-order sum), so kernel_ms <= ms_per_step by construction
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    bare_step = step if comm_stream is None else None
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for s_ in range(args.steps):
+        if bare_step is not None:
+            ev[s_][0].record(main_stream)
+            bare_step()
+            ev[s_][1].record(main_stream)
+        else:
+            step(ev[s_])
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = [a.elapsed_time(b) for a, b in ev]
     eng.check()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant kernel, HIP events on its own stream (replays of the captured step:
-    # counter reset + pipeline kernel + the two small kernels of the fixed-order sum)
-    kernel_ms = steps_bound[0].time(max(3, min(args.steps, 20)))
+    kernel_ms = sum(step_ms) / len(step_ms)
+    kernel_ms_min = min(step_ms)
     achieved = bpp * n / (kernel_ms * 1e-3) / 1e9
     torch.cuda.synchronize()
-    diag = diags[0]
-    tiles.allreduce_diag(diag)          # the timing launches left this rank's band in it
+    # load balance: every rank's kernel time (its band is 1/N of the grid)
+    rank_kernel_ms = [kernel_ms]
+    if world > 1:
+        kt = torch.zeros(world, dtype=torch.float64, device='cpu' if rehearsal else 'cuda')
+        kt[rank] = kernel_ms
+        dist.all_reduce(kt)
+        rank_kernel_ms = kt.tolist()
+    diag = diags[(counter[0] - 1) & 1]      # the last step's vector, already reduced over the ranks by that step
     diag_host = diag.cpu().numpy()
 
     def window(field_plain, field_tiled, lo, hi):
@@ -480,7 +542,7 @@ def main():
     # the same kernel on 16 plain arrays (the layout of the reference's arguments)
     plain = None
     copy_gbps = None
-    if args.layout == 'tiled' and not args.no_plain:
+    if args.layout == 'tiled' and not args.no_plain and (world == 1 or args.plain):
         steps_bound = ras = None
         torch.cuda.empty_cache()
         try:
@@ -525,8 +587,9 @@ def main():
                                args.rows // world, -(-args.rows // world)),
                 'pixels': total, 'pixels_per_gpu': n, 'parallelism': 'tile-dp%d' % world,
                 'math': args.math, 'bplut': os.path.basename(COLLECTION61_BPLUT),
-                'step': 'fused ET kernel with in-kernel diagnostics + fixed-order final sum (one HIP graph launch) + '
-                        'all-reduce(8 doubles) overlapped with the next step on a side stream',
+                'step': 'fused ET kernel with in-kernel diagnostics + the kernel that revisits pixels outside the fast '
+                        "arithmetic's domain + fixed-order final sum (one HIP graph launch) + one all-gather(8 doubles), "
+                        'reduced in rank order, overlapped with the next step on a side stream',
                 'raster_layout': layout_info,
             },
             'roofline': {
@@ -535,7 +598,11 @@ def main():
                 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
                 'traffic': traffic, 'traffic_source': traffic_source, 'traffic_unit': 'bytes per launch',
                 'bytes_per_pixel': bpp, 'pixels_per_launch': n,
-                'kernel_ms': kernel_ms, 'kernel_pixels_per_s': n / (kernel_ms * 1e-3),
+                'kernel_ms': kernel_ms, 'kernel_ms_min': kernel_ms_min,
+                'kernel_ms_note': 'mean / min over the timed steps themselves (an event pair around each '
+                                  "step's graph launch on the launch stream)",
+                'kernel_ms_by_rank': rank_kernel_ms,
+                'kernel_pixels_per_s': n / (kernel_ms * 1e-3),
                 'measured_copy_GBps': copy_gbps,
                 'frac_of_measured_copy': achieved / copy_gbps if copy_gbps else None,
                 'plain_arrays': plain,

@@ -38,13 +38,6 @@ template <> struct FastMath<double> {
 #ifndef MOD16_KK_M
 #define MOD16_KK_M "v"
 #endif
-    // a constant held in a vector register pair (see fma_kk) -- experiments: -DMOD16_TABK_VGPR
-    static __device__ __forceinline__ T kv(T k) {
-#ifdef MOD16_TABK_VGPR
-        asm("" : "+v"(k));
-#endif
-        return k;
-    }
     static __device__ __forceinline__ T fma_kk(T x, T m, T c) {
 #ifdef MOD16_NO_FMA_KK
         return __builtin_fma(x, m, c);
@@ -111,10 +104,10 @@ template <> struct FastMath<double> {
         // the shifted sum (no v_cvt_i32_f64). |x| beyond 2^31 ln2 / 64 = 2.3e7 is not reduced
         // properly any more (the callers' arguments are bounded: [-746, 0], or 17.3 tc / (tc + 237)
         // of a temperature)
-        T km = __builtin_fma(x, kv(92.33248261689366), kv(kRintShift));     // 64 / ln 2
-        T kf = km - kv(kRintShift);
-        T r = __builtin_fma(kf, kv(-0x1.62e42fee00000p-7), x);          // ln2/64, 32-bit head
-        r = __builtin_fma(kf, kv(-0x1.a39ef35793c76p-39), r);
+        T km = __builtin_fma(x, 92.33248261689366, kRintShift);     // 64 / ln 2
+        T kf = km - kRintShift;
+        T r = __builtin_fma(kf, -0x1.62e42fee00000p-7, x);          // ln2/64, 32-bit head
+        r = __builtin_fma(kf, -0x1.a39ef35793c76p-39, r);
         T p = fma_kk(r, 1.0 / 120.0, 1.0 / 24.0);                   // |r| <= ln2/128
         p = __builtin_fma(p, r, 1.0 / 6.0);
         p = __builtin_fma(p, r, 0.5);
@@ -127,10 +120,10 @@ template <> struct FastMath<double> {
     // the same with a quartic: the first term left out is r^5/120 <= 4e-14 relative -- for
     // results that are not differenced afterwards (rh^(vpd/beta))
     static __device__ __forceinline__ T exp_tab4(T x, const T* tb) {
-        T km = __builtin_fma(x, kv(92.33248261689366), kv(kRintShift));
-        T kf = km - kv(kRintShift);
-        T r = __builtin_fma(kf, kv(-0x1.62e42fee00000p-7), x);
-        r = __builtin_fma(kf, kv(-0x1.a39ef35793c76p-39), r);
+        T km = __builtin_fma(x, 92.33248261689366, kRintShift);
+        T kf = km - kRintShift;
+        T r = __builtin_fma(kf, -0x1.62e42fee00000p-7, x);
+        r = __builtin_fma(kf, -0x1.a39ef35793c76p-39, r);
         T p = fma_kk(r, 1.0 / 24.0, 1.0 / 6.0);
         p = __builtin_fma(p, r, 0.5);
         p = __builtin_fma(p, r, 1.0);
@@ -141,10 +134,10 @@ template <> struct FastMath<double> {
 
     // the same to 4e-11 (cubic): for results that end up in float32 (mod16_mixed.hpp)
     static __device__ __forceinline__ T exp_tab3(T x, const T* tb) {
-        T km = __builtin_fma(x, kv(92.33248261689366), kv(kRintShift));
-        T kf = km - kv(kRintShift);
-        T r = __builtin_fma(kf, kv(-0x1.62e42fee00000p-7), x);
-        r = __builtin_fma(kf, kv(-0x1.a39ef35793c76p-39), r);
+        T km = __builtin_fma(x, 92.33248261689366, kRintShift);
+        T kf = km - kRintShift;
+        T r = __builtin_fma(kf, -0x1.62e42fee00000p-7, x);
+        r = __builtin_fma(kf, -0x1.a39ef35793c76p-39, r);
         T p = fma_kk(r, 1.0 / 6.0, 0.5);
         p = __builtin_fma(p, r, 1.0);
         p = __builtin_fma(p, r, 1.0);

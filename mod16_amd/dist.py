@@ -3,8 +3,9 @@ Tile sharding of a global raster over the GPUs of one node.
 
 The ET computation is an independent map over pixels: no halo, no exchange.
 The row-major raster is cut into contiguous row bands, one per rank (one
-process per GPU); the only collective is an all-reduce of the 8-double
-diagnostics vector (RCCL over xGMI on GPUs, gloo in the CPU tests). Outputs
+process per GPU); the only collective is one all-gather of the 8-double
+diagnostics vector per step (RCCL over xGMI on GPUs, gloo in the CPU tests),
+reduced in rank order by every rank. Outputs
 stay sharded.
 '''
 
@@ -29,14 +30,34 @@ def pixel_range(rows, cols, rank, world):
     return r0 * cols, (r1 - r0) * cols
 
 
+_GATHER = {}
+
+
 def allreduce_diag(diag, group=None):
-    '''In-place all-reduce of a diagnostics vector (``raster.DIAG_FIELDS``):
-    sums and counts [0:6] with SUM, maxima [6:8] with MAX. ``diag`` is a
-    float64 tensor of 8 on the device the process group's backend serves.'''
+    '''In-place reduction of a diagnostics vector (``raster.DIAG_FIELDS``) over
+    the ranks: sums and counts [0:6] added, maxima [6:8] maximised. ``diag`` is
+    a float64 tensor of 8 on the device the process group's backend serves.
+
+    ONE collective per call -- an all-gather of the 8 doubles (64 bytes per
+    rank: latency-bound whatever the algorithm) -- and the reduction itself is
+    done by every rank on the gathered ``(world, 8)`` block in RANK ORDER, so
+    the global sums are the same bits on every rank and from run to run,
+    whatever order the collective library moves the pieces in.'''
+    import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or \
             dist.get_world_size(group) == 1:
         return diag
-    dist.all_reduce(diag[0:6], op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(diag[6:8], op=dist.ReduceOp.MAX, group=group)
+    world = dist.get_world_size(group)
+    key = (diag.device, world)
+    buf = _GATHER.get(key)
+    if buf is None:
+        buf = _GATHER[key] = torch.empty(world * 8, dtype=torch.float64, device=diag.device)
+    dist.all_gather_into_tensor(buf, diag, group=group)
+    buf = buf.view(world, 8)
+    acc = buf[0, 0:6].clone()
+    for r in range(1, world):          # fixed order: rank 0 + rank 1 + ...
+        acc += buf[r, 0:6]
+    diag[0:6] = acc
+    diag[6:8] = buf[:, 6:8].max(dim=0).values
     return diag

@@ -60,38 +60,58 @@ def test_two_rank_gloo_bands_and_allreduce(tmp_path):
     assert res['bands_identical_to_global']
 
 
-def test_bench_spawn_command():
-    """`python bench.py --gpus N` starts its own ranks: the command of the child."""
+def test_bench_rank_environment():
+    """`python bench.py --gpus N` starts its own ranks: what each child finds in its environment
+    (the names torch.distributed.run exports, 127.0.0.1 for the rendezvous)."""
     sys.path.insert(0, ROOT)
     import bench
-    cmd = bench.spawn_command(['--gpus', '8', '--steps', '5', '--warmup', '1'], 8, 29511)
-    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
-    assert '--nnodes=1' in cmd
-    assert cmd[cmd.index('--nproc-per-node') + 1] == '8'
-    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
-    assert cmd[cmd.index('--master-port') + 1] == '29511'
-    k = cmd.index(os.path.join(ROOT, 'bench.py'))
-    assert cmd[k + 1:] == ['--gpus', '8', '--steps', '5', '--warmup', '1']
+    env = bench.rank_env({'PATH': '/bin'}, 5, 8, 29511)
+    assert env['RANK'] == '5' and env['LOCAL_RANK'] == '5' and env['WORLD_SIZE'] == '8'
+    assert env['MASTER_ADDR'] == '127.0.0.1' and env['MASTER_PORT'] == '29511'
+    assert env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and env['PATH'] == '/bin'
 
 
-def test_bench_gpus_2_spawns_its_own_ranks():
-    """`python bench.py --gpus 2` typed as is (no torch.distributed.run around it):
-    the parent launches two ranks, the ranks count each other with an all-reduce and
-    rank 0's line comes back through the parent, whose exit code is the child's.
-    MOD16_BENCH_PLUMBING=1 replaces the GPU work of a rank by nothing (no GPU in
-    this container); launcher, rendezvous and relay are the real ones."""
+@pytest.mark.parametrize('ranks', [2, 8])
+def test_bench_gpus_n_spawns_its_own_ranks(ranks):
+    """`python bench.py --gpus N` typed as is (no torch.distributed.run around it), N = 2 and
+    the 8 of a full node: the parent launches the ranks, the ranks count each other with a
+    collective, reduce a diagnostics vector with the product's one-gather reduction and rank
+    0's line comes back through the parent, whose exit code is the ranks'.
+    MOD16_BENCH_PLUMBING=1 replaces the GPU work of a rank by nothing (no GPU in this
+    container); launcher, rendezvous, collective and relay are the real ones."""
     env = dict(os.environ, MOD16_BENCH_PLUMBING='1', OMP_NUM_THREADS='1')
     for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(key, None)
-    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks),
                            '--steps', '3', '--warmup', '1'],
                           env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
     lines = [l for l in proc.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, proc.stdout
     res = json.loads(lines[0])
-    assert res['n_gpus'] == 2 and res['ranks_seen'] == 2 and res['steps'] == 3
-    # a failing rank makes the parent fail too
+    assert res['n_gpus'] == ranks and res['ranks_seen'] == ranks and res['steps'] == 3
+    # rank r contributed [r, 1, ..., r]: sums in rank order, maxima over ranks
+    assert res['diag_reduced'][0] == sum(range(ranks)) and res['diag_reduced'][1] == ranks
+    assert res['diag_reduced'][6] == ranks - 1
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's launch line (python -m torch.distributed.run ... bench.py --gpus 2): the
+    process is one of the ranks and does not spawn."""
+    env = dict(os.environ, MOD16_BENCH_PLUMBING='1', OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1']
+    proc = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and json.loads(lines[0])['ranks_seen'] == 2
+
+
+def test_bench_failing_rank_fails_the_parent():
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(key, None)
     env['MOD16_BENCH_PLUMBING'] = '0'
     env['CUDA_VISIBLE_DEVICES'] = env['HIP_VISIBLE_DEVICES'] = ''
     proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
