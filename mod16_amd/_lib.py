@@ -353,15 +353,23 @@ class _PinnedPool(object):
     ``hipHostMalloc`` blocks. A block goes back to the pool when its array is
     garbage-collected and is handed out again for the next result of that size
     (a time loop allocates once); the pool keeps at most ``MAX_CACHED`` bytes of
-    idle blocks, the rest is freed. Everything else about the arrays is ordinary
-    (writeable, C-contiguous, own their memory through ``.base``).'''
+    idle blocks and hands out at most ``MAX_LIVE`` bytes in total -- beyond that
+    ``empty`` returns plain numpy arrays. ``trim()`` frees the idle blocks.
+    Everything else about the arrays is ordinary (writeable, C-contiguous, own
+    their memory through ``.base``).'''
     MIN_BYTES = 1 << 20
-    MAX_CACHED = 8 << 30
+    # Bounds (bytes; MOD16_PINNED_CACHE / MOD16_PINNED_LIVE override them): idle blocks kept
+    # for re-use, and page-locked memory handed out in total -- results beyond the second
+    # bound are ordinary numpy arrays (slower to fill, but swappable: a caller that keeps a year
+    # of day/night rasters must not pin tens of GB of RAM).
+    MAX_CACHED = int(os.environ.get('MOD16_PINNED_CACHE', 1 << 30))
+    MAX_LIVE = int(os.environ.get('MOD16_PINNED_LIVE', 8 << 30))
 
     def __init__(self):
         self.lock = threading.Lock()
         self.free = {}          # nbytes -> [address, ...]
-        self.cached = 0
+        self.cached = 0         # idle bytes in `free`
+        self.live = 0           # bytes allocated (handed out + idle)
 
     def take(self, nbytes):
         with self.lock:
@@ -369,10 +377,38 @@ class _PinnedPool(object):
             if blocks:
                 self.cached -= nbytes
                 return blocks.pop()
+            if self.live + nbytes > self.MAX_LIVE:
+                self._trim_locked(self.live + nbytes - self.MAX_LIVE)
+                if self.live + nbytes > self.MAX_LIVE:
+                    return None
+            self.live += nbytes
         p = C.c_void_p()
         if load().mod16_host_alloc(nbytes, C.byref(p)) != OK or not p.value:
+            with self.lock:
+                self.live -= nbytes
             return None
         return p.value
+
+    def _release(self, addr, nbytes):
+        self.live -= nbytes
+        try:
+            load().mod16_host_free(addr)
+        except Exception:       # interpreter shutdown
+            pass
+
+    def _trim_locked(self, want):
+        for size in sorted(self.free, reverse=True):
+            blocks = self.free[size]
+            while blocks and want > 0:
+                self._release(blocks.pop(), size)
+                self.cached -= size
+                want -= size
+        return want
+
+    def trim(self, keep=0):
+        '''Free idle blocks until at most ``keep`` bytes of them remain.'''
+        with self.lock:
+            self._trim_locked(self.cached - keep)
 
     def give(self, addr, nbytes):
         with self.lock:
@@ -380,10 +416,7 @@ class _PinnedPool(object):
                 self.free.setdefault(nbytes, []).append(addr)
                 self.cached += nbytes
                 return
-        try:
-            load().mod16_host_free(addr)
-        except Exception:       # interpreter shutdown
-            pass
+            self._release(addr, nbytes)
 
     def empty(self, shape, dtype):
         '''``numpy.empty(shape, dtype)``, page-locked when large enough.'''
@@ -408,8 +441,10 @@ def context(device=0):
 
     One context per host thread and GPU: the reference's functions are pure and
     may be called from several threads at once; a context
-    owns staging slabs, streams, a BPLUT copy and a workspace, so threads that
-    shared one would take turns (the library serialises calls on a ctx) and
+    owns staging slabs (HOST mode: up to ``MOD16_HOST_THREADS`` = 8 of them, ~0.6 GB
+    each for float64, allocated on the first numpy call of the thread and freed
+    with it -- N threads on the numpy path hold N x 4.7 GB of HBM), streams, a
+    BPLUT copy and a workspace, so threads that shared one would take turns (the library serialises calls on a ctx) and
     would see each other's ``set_bplut``. Contexts of finished threads are
     destroyed with the thread's locals.'''
     table = getattr(_local, 'contexts', None)

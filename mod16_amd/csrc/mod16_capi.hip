@@ -66,6 +66,7 @@ struct mod16_ctx {
     unsigned* status_host = nullptr; // pinned mirror
     unsigned* static_flag = nullptr; // device word of mod16_et_static_*
     DiagWs ws;                       // diagnostics partials of launches outside a graph
+    std::vector<void*> retired;      // outgrown workspaces (freed with the context)
     DiagWs* force_ws = nullptr;      // workspace to use instead (graph capture)
     hipEvent_t ws_event = nullptr;   // recorded behind the last launch that produced diagnostics in `ws`
     hipStream_t ws_stream = nullptr; // ... and the stream it ran on
@@ -152,6 +153,7 @@ extern "C" int mod16_destroy(mod16_ctx* ctx) {
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     if (ctx->static_flag) (void)hipFree(ctx->static_flag);
     if (ctx->ws.partial) (void)hipFree(ctx->ws.partial);
+    for (void* p : ctx->retired) (void)hipFree(p);
     if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
     if (ctx->diag_dev) (void)hipFree(ctx->diag_dev);
     if (ctx->diag_host) (void)hipHostFree(ctx->diag_host);
@@ -346,12 +348,17 @@ static int reserve_diag(mod16_ctx* ctx, int64_t blocks, DiagWs** out = nullptr) 
     }
     if (out) *out = &ctx->ws;
     if (blocks <= ctx->ws.capacity) return MOD16_OK;
-    HIPCHK(ctx, hipDeviceSynchronize());   // growing only: earlier launches may still use it
-    HIPCHK(ctx, hipFree(ctx->ws.partial));
+    // Growing: earlier launches may still use the old block. No device-wide wait (other
+    // contexts of the process -- the workers of mod16_amd.io -- would stall with this one) and
+    // no hipFree (which synchronises the device): the old block is retired and freed with the
+    // context; sizes at least double, so the retired blocks add up to less than the live one.
+    // Launches that follow use the new block and are ordered behind the old one's by the
+    // workspace event as before.
+    ctx->retired.push_back(ctx->ws.partial);
     ctx->ws.partial = nullptr;
+    const int64_t want = std::max<int64_t>(blocks, 2 * ctx->ws.capacity);
     ctx->ws.capacity = 0;
-    ctx->ws_pending = false;
-    HIPCHK(ctx, ws_alloc(ctx->ws, blocks));
+    HIPCHK(ctx, ws_alloc(ctx->ws, want));
     return MOD16_OK;
 }
 
@@ -362,6 +369,13 @@ static int reserve_diag(mod16_ctx* ctx, int64_t blocks, DiagWs** out = nullptr) 
 // Inside a graph capture the graph's own workspace is used instead.
 static int ws_acquire(mod16_ctx* ctx, hipStream_t st) {
     if (ctx->force_ws) return MOD16_OK;
+    // A caller capturing its own stream into a graph would bake the context's workspace (which
+    // may be replaced later) and this event bookkeeping into it: refused -- mod16_graph_* builds
+    // graphs that own their workspace.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(ctx, MOD16_ERR_ARG, "the stream is being captured into a graph: use mod16_graph_et_diag_* / "
+                                        "mod16_graph_et_tiled_* (they capture the step with a workspace of its own)");
     if (ctx->ws_pending && st != ctx->ws_stream)
         HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ws_event, 0));
     return MOD16_OK;
@@ -959,10 +973,10 @@ static int graph_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drive
     g->ctx = ctx;
     g->device = ctx->device;
     int rc = [&]() -> int {
-        // the run below (outside the capture: it validates the arguments) reads the raster
-        // on the library's own stream: whatever the caller enqueued on other streams to
-        // fill it must have finished (set-up time only; replays are ordered by their stream)
-        HIPCHK(ctx, hipDeviceSynchronize());
+        // (nothing runs here: the step is only recorded -- argument errors come back from the
+        // recording call, launch errors from the instantiation -- so no wait for whatever the
+        // caller's streams are still doing to the raster is needed; replays are ordered by
+        // the stream they are launched on)
         HIPCHK(ctx, hipMalloc(&g->counter, 128));
         ctx->force_counter = g->counter;
         // the graph's kernel nodes keep pointing at this workspace for as long as
@@ -970,11 +984,8 @@ static int graph_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drive
         HIPCHK(ctx, ws_alloc(g->ws, std::max<int64_t>(kDiagBlocks, stream_geom(ctx, std::max<int64_t>(n, 0), VecOf<T>::v).nruns + kStage)));
         ctx->force_ws = &g->ws;
         // once outside a capture: validates the arguments and brings the workspace to size
-        int r = et_diag_entry<T>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, st);
-        if (r != MOD16_OK) return r;
-        HIPCHK(ctx, hipStreamSynchronize(st));
         HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        r = et_diag_entry<T>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, st);
+        int r = et_diag_entry<T>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, st);
         hipError_t e = hipStreamEndCapture(st, &g->graph);
         if (r != MOD16_OK) return r;
         HIPCHK(ctx, e);
@@ -1007,7 +1018,12 @@ extern "C" int mod16_graph_et_diag_f32(mod16_ctx* ctx, const uint8_t* cls, const
 }
 extern "C" int mod16_graph_launch(mod16_graph* g, void* stream) {
     if (!g || !g->exec) return MOD16_ERR_ARG;
-    HIPCHK(g->ctx, hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream)));
+    // (a graph may outlive the context it was built with: no error text through g->ctx)
+    const hipError_t e = hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        fprintf(stderr, "mod16_graph_launch: %s\n", hipGetErrorString(e));
+        return MOD16_ERR_HIP;
+    }
     return MOD16_OK;
 }
 
@@ -1992,10 +2008,10 @@ static int graph_tiled_entry(mod16_ctx* ctx, const mod16_layout* lay, const uint
     g->ctx = ctx;
     g->device = ctx->device;
     int rc = [&]() -> int {
-        // the run below (outside the capture: it validates the arguments) reads the raster
-        // on the library's own stream: whatever the caller enqueued on other streams to
-        // fill it must have finished (set-up time only; replays are ordered by their stream)
-        HIPCHK(ctx, hipDeviceSynchronize());
+        // (nothing runs here: the step is only recorded -- argument errors come back from the
+        // recording call, launch errors from the instantiation -- so no wait for whatever the
+        // caller's streams are still doing to the raster is needed; replays are ordered by
+        // the stream they are launched on)
         HIPCHK(ctx, hipMalloc(&g->counter, 128));
         ctx->force_counter = g->counter;
         int pv = 0, tsh = lay->tile > 0 ? tile_log2(lay->tile, 1) : -1;
@@ -2003,11 +2019,8 @@ static int graph_tiled_entry(mod16_ctx* ctx, const mod16_layout* lay, const uint
         if (tsh < pv) return fail(ctx, MOD16_ERR_ARG, "mod16_graph_et_tiled: bad tile");
         HIPCHK(ctx, ws_alloc(g->ws, std::max<int64_t>(kDiagBlocks, stream_geom(ctx, std::max<int64_t>(n, 0), VecOf<T>::v, tsh - pv).nruns + kStage)));
         ctx->force_ws = &g->ws;
-        int r = tiled_entry<T>(ctx, lay, cls, drivers, n, out_day, out_night, flags, ddiag, st);
-        if (r != MOD16_OK) return r;
-        HIPCHK(ctx, hipStreamSynchronize(st));
         HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        r = tiled_entry<T>(ctx, lay, cls, drivers, n, out_day, out_night, flags, ddiag, st);
+        int r = tiled_entry<T>(ctx, lay, cls, drivers, n, out_day, out_night, flags, ddiag, st);
         hipError_t e = hipStreamEndCapture(st, &g->graph);
         if (r != MOD16_OK) return r;
         HIPCHK(ctx, e);

@@ -94,11 +94,16 @@ class TiledRaster(object):
 
     def flat(self, field, lo=0, hi=None):
         '''Pixels [lo, hi) of one array of the raster as a contiguous 1-D
-        tensor (a copy; only the tiles it touches are read).'''
+        tensor -- always a COPY (only the tiles it touches are read): inside one
+        tile the strided view is contiguous and reshape would hand back an alias
+        of live raster memory, which the next launch overwrites.'''
         hi = self.n if hi is None else hi
         P = self.tile
         t0, t1 = lo // P, -(-hi // P)
-        return field[t0:t1].reshape(-1)[lo - t0 * P:hi - t0 * P]
+        out = field[t0:t1].reshape(-1)[lo - t0 * P:hi - t0 * P]
+        if out.data_ptr() == field[t0:t1].data_ptr() + (lo - t0 * P) * field.element_size():
+            out = out.clone()
+        return out
 
     def put(self, field, src, lo=0):
         '''Write the 1-D tensor ``src`` into pixels [lo, lo + len(src)) of one

@@ -718,3 +718,43 @@ def test_global_grid_float64(env):
         want = oracle.evapotranspiration_raster(bplut, h_cls, *h_drv)
         assert_parity(day[s0:s0 + m].cpu().numpy(), want[0], 1e-8, 'day @%d' % s0)
         assert_parity(night[s0:s0 + m].cpu().numpy(), want[1], 1e-8, 'night @%d' % s0)
+
+
+def test_pinned_pool_is_bounded(env):
+    """The page-locked memory behind result arrays is bounded: beyond MAX_LIVE bytes handed out the
+    results are plain numpy arrays (a caller keeping many rasters must not pin RAM without limit),
+    idle blocks beyond MAX_CACHED are freed, trim() frees the rest."""
+    import gc
+    from mod16_amd import _lib
+    pool = _lib._PinnedPool()
+    pool.MAX_LIVE, pool.MAX_CACHED = 5 << 20, 2 << 20
+    held = [pool.empty((1 << 20,), np.uint8) for _ in range(5)]        # 5 MiB: all page-locked
+    assert all(a.base is not None for a in held) and pool.live == 5 << 20
+    extra = pool.empty((1 << 20,), np.uint8)                           # over the bound: ordinary
+    assert extra.base is None and pool.live == 5 << 20
+    del held
+    gc.collect()
+    assert pool.cached == 2 << 20 and pool.live == 2 << 20             # two kept idle, three freed
+    again = pool.empty((1 << 20,), np.uint8)
+    assert again.base is not None and pool.cached == 1 << 20           # an idle block came back
+    pool.trim()
+    assert pool.cached == 0 and pool.live == 1 << 20
+    # an idle block of another size makes room when the bound is reached
+    del again
+    gc.collect()
+    big = pool.empty((4 << 20,), np.uint8)
+    big2 = pool.empty((1 << 20,), np.uint8)
+    assert big.base is not None and big2.base is not None and pool.live <= 5 << 20
+
+
+def test_flat_always_copies(env):
+    """TiledRaster.flat() hands back a copy whether the window lies inside one tile (where the
+    strided view happens to be contiguous) or spans several."""
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table)
+    r = eng.synth_tiled(eng.alloc_tiled(4096 * 3), seed=3)
+    inside = r.flat(r.drivers[5], 10, 500)
+    across = r.flat(r.drivers[5], 4000, 4200)
+    was = inside.clone(), across.clone()
+    r.drivers[5].fill_(-1.0)
+    assert torch.equal(inside, was[0]) and torch.equal(across, was[1])
