@@ -643,7 +643,38 @@ def test_more_than_two_to_the_31_pixels(env):
     assert torch.equal(c2, cls[n - m:])
     assert torch.equal(torch.nan_to_num(d2[5]), torch.nan_to_num(drv[5][n - m:]))
     eng.check()
+    # the same raster in the tiled layout (float32: 8192 pixels per tile, 262146 tiles; a tiled
+    # raster holds whole 16-byte vectors: the first nt = n - 1 pixels), mixed precision as
+    # well: the plain inputs make room first
+    nt = n // 4 * 4
+    keep = {off: (day[off:off + m].clone(), night[off:off + m].clone())
+            for off in (0, 2 ** 31 - 2048, 2 ** 31 + 4, nt - m)}
+    last = (float(day[nt:].double().nan_to_num().sum()), float(night[nt:].double().nan_to_num().sum()),
+            int(torch.isnan(day[nt:]).sum()), int(torch.isnan(night[nt:]).sum()))
     del cls, drv, day, night
+    torch.cuda.empty_cache()
+    r = eng.synth_tiled(eng.alloc_tiled(nt), seed=81)
+    d_tiled = torch.zeros(8, dtype=torch.float64, device='cuda')
+    eng.run_tiled(r, diag=d_tiled)
+    eng.check()
+    t = d_tiled.cpu().numpy()
+    assert t[2] + t[4] == nt and t[3] + t[5] == nt
+    assert t[4] == d[4] - last[2] and t[5] == d[5] - last[3]
+    assert np.isclose(t[0], d[0] - last[0], rtol=1e-12) and np.isclose(t[1], d[1] - last[1], rtol=1e-12)
+    for off, (kd, kn) in keep.items():
+        assert torch.equal(torch.nan_to_num(r.flat(r.day, off, off + m)), torch.nan_to_num(kd)), off
+        assert torch.equal(torch.nan_to_num(r.flat(r.night, off, off + m)), torch.nan_to_num(kn)), off
+    from mod16_amd import _lib
+    mixed = RasterEngine(table, dtype='float32', math=_lib.MATH_MIXED)
+    d_mixed = torch.zeros(8, dtype=torch.float64, device='cuda')
+    mixed.run_tiled(r, diag=d_mixed)
+    mixed.check()
+    x = d_mixed.cpu().numpy()
+    assert np.array_equal(x[2:6], t[2:6]) and np.allclose(x[:2], t[:2], rtol=1e-5)
+    for off, (kd, kn) in keep.items():
+        got = r.flat(r.day, off, off + m)
+        assert torch.equal(torch.isnan(got), torch.isnan(kd)) and torch.equal(got == 0, kd == 0), off
+    del r
     torch.cuda.empty_cache()
 
 
@@ -718,6 +749,30 @@ def test_global_grid_float64(env):
         want = oracle.evapotranspiration_raster(bplut, h_cls, *h_drv)
         assert_parity(day[s0:s0 + m].cpu().numpy(), want[0], 1e-8, 'day @%d' % s0)
         assert_parity(night[s0:s0 + m].cpu().numpy(), want[1], 1e-8, 'night @%d' % s0)
+    # the same grid in the engine's TILED layout (the layout bench.py times): the plain inputs
+    # make room, the generator writes the identical field into the tiled raster, and every pixel
+    # of its outputs must equal the plain run's bit for bit (the full-size tile / row address
+    # arithmetic: 227813 tiles, offsets beyond 2^36 bytes); diagnostics to 1e-12
+    del cls, drv, h_cls, h_drv
+    torch.cuda.empty_cache()
+    r = eng.synth_tiled(eng.alloc_tiled(n), seed=16)
+    d_tiled = torch.zeros(8, dtype=torch.float64, device='cuda')
+    eng.run_tiled(r, diag=d_tiled)
+    eng.check()
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        assert torch.equal(torch.nan_to_num(r.flat(r.day, lo, hi), nan=-7.0), torch.nan_to_num(day[lo:hi], nan=-7.0)), lo
+        assert torch.equal(torch.nan_to_num(r.flat(r.night, lo, hi), nan=-7.0), torch.nan_to_num(night[lo:hi], nan=-7.0)), lo
+    t = d_tiled.cpu().numpy()
+    assert np.array_equal(t[2:], g[2:]) and np.allclose(t[:2], g[:2], rtol=1e-12, atol=0)
+    # a window of the tiled INPUTS against the oracle too (what the kernel read is what was written)
+    s0 = (n // 2) // 4 * 4
+    want = oracle.evapotranspiration_raster(
+        bplut, r.flat(r.cls, s0, s0 + m).cpu().numpy(), *[r.flat(d, s0, s0 + m).cpu().numpy() for d in r.drivers])
+    assert_parity(r.flat(r.day, s0, s0 + m).cpu().numpy(), want[0], 1e-8, 'tiled day')
+    assert_parity(r.flat(r.night, s0, s0 + m).cpu().numpy(), want[1], 1e-8, 'tiled night')
+    del r, day, night
+    torch.cuda.empty_cache()
 
 
 def test_pinned_pool_is_bounded(env):
