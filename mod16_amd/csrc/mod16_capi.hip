@@ -453,8 +453,8 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     s.run_shift = g.run_shift;
     s.static_sched = g.static_sched;
     const int grid = g.grid;
-    // partials: one per run, or (static schedule) one per wave that has a run
-    const int64_t nruns = g.static_sched ? std::min<int64_t>(g.nruns, (int64_t)grid * (kBlock / 64)) : g.nruns;
+    // partials: one per run, or (static schedule) one per block
+    const int64_t nruns = g.static_sched ? grid : g.nruns;
     DiagWs* ws = nullptr;
     int rc = reserve_diag(ctx, nruns + kStage, &ws);
     if (rc != MOD16_OK) return rc;

@@ -315,15 +315,11 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     __shared__ double lut[MOD16_LUT_ROWS * kLutCols];
     __shared__ __attribute__((aligned(16))) double tab[kTab];
     __shared__ __attribute__((aligned(16))) char stage[(kBlock / 64) * kSlot];
-    for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) lut[i] = a.lut64[i];
+    // (the tables are filled further down, BEHIND the issue of the first piece's DMA: the two
+    // round trips to memory overlap -- a 1200 x 1200 launch is only six iterations long)
     const float* lutf = nullptr;       // mixed-precision forms: the table in float32 as well
-    if constexpr (stream_is_mixed(MODE)) {
-        __shared__ float lut32[MOD16_LUT_ROWS * kLutCols];
-        for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) lut32[i] = (float)a.lut64[i];
-        lutf = lut32;
-    }
-    for (int i = threadIdx.x; i < kTab; i += kBlock) tab[i] = a.tab[i];
-    __syncthreads();
+    __shared__ float lut32[stream_is_mixed(MODE) ? MOD16_LUT_ROWS * kLutCols : 1];
+    if constexpr (stream_is_mixed(MODE)) lutf = lut32;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char* const ws = stage + wave * kSlot;
@@ -445,6 +441,13 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         load_ptrs(p);
         if (v < nvec) issue(offs_of(cbase, run), p);
     }
+    for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) {
+        const double x = a.lut64[i];
+        lut[i] = x;
+        if constexpr (stream_is_mixed(MODE)) lut32[i] = (float)x;
+    }
+    for (int i = threadIdx.x; i < kTab; i += kBlock) tab[i] = a.tab[i];
+    __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     bool flushed = false;
 #pragma nounroll
@@ -695,24 +698,41 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     // operation order, then its one partial. Iteration i of wave w was piece
     // ((w + (i >> rs) nwaves) << rs) + (i & (rl - 1)); the last flag bit stands for every
     // iteration from there on.
-    if (a.static_sched && first_cbase < npiece) {
-        const unsigned long long mine = flags;     // (diag_fields() stores and clears them)
-        double f = diag_fields();
-        if (__builtin_expect(mine != 0ull, 0)) {
-            RedoAcc acc;
-            const int64_t w0 = first_cbase >> rs;
+    if (a.static_sched) {
+        // ONE partial per BLOCK: the block's four waves add theirs up in LDS (fixed order:
+        // wave 0 + wave 1 + ...), so the block that sums the partials of the whole launch
+        // afterwards reads a quarter of them -- one round trip to memory instead of two on
+        // the path behind the last block's last store (1200 x 1200: 512 partials)
+        __shared__ double wave_part[kBlock / 64][kDiag];
+        double f = lane < 6 ? 0.0 : -__builtin_huge_val();        // a wave without work adds nothing
+        if (first_cbase < npiece) {
+            const unsigned long long mine = flags;     // (diag_fields() stores and clears them)
+            f = diag_fields();
+            if (__builtin_expect(mine != 0ull, 0)) {
+                RedoAcc acc;
+                const int64_t w0 = first_cbase >> rs;
 #pragma nounroll
-            for (int i = 0; i < iters; ++i) {
-                const int bit = i < kFlagBits - 1 ? i : kFlagBits - 1;
-                if (!((mine >> bit) & 1ull)) continue;
-                const int64_t piece = ((w0 + (int64_t)(i >> rs) * nwaves) << rs) + (i & (rl - 1));
-                redo_piece<T, MODE>(a, lut, piece, lane, acc);
+                for (int i = 0; i < iters; ++i) {
+                    const int bit = i < kFlagBits - 1 ? i : kFlagBits - 1;
+                    if (!((mine >> bit) & 1ull)) continue;
+                    const int64_t piece = ((w0 + (int64_t)(i >> rs) * nwaves) << rs) + (i & (rl - 1));
+                    redo_piece<T, MODE>(a, lut, piece, lane, acc);
+                }
+                f = redo_fold(acc, lane, f);
             }
-            f = redo_fold(acc, lane, f);
         }
-        if (lane < kDiag)
-            __hip_atomic_store(a.diag_partial + ((int64_t)blockIdx.x * (kBlock / 64) + wave) * kDiag + lane, f,
+        if (lane < kDiag) wave_part[wave][lane] = lane == kFlagField ? 0.0 : f;
+        __syncthreads();
+        if (wave == 0 && lane < kDiag) {
+            double g = wave_part[0][lane];
+#pragma unroll
+            for (int w = 1; w < kBlock / 64; ++w) {
+                const double o = wave_part[w][lane];
+                g = lane < 6 ? g + o : (o > g ? o : g);
+            }
+            __hip_atomic_store(a.diag_partial + (int64_t)blockIdx.x * kDiag + lane, g,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     // -- diagnostics of a small raster, finished in this launch: every block counts itself
     // done once its partials are in memory; the block that counts last adds all of them up in
