@@ -676,7 +676,7 @@ def other_configs(args, torch, np, _lib, RasterEngine, table, bplut):
                           r.flat(r.day, lo, hi), r.flat(r.night, lo, hi))
 
     t0 = time.perf_counter()
-    sdiag, _ = eng.run_series_tiled(n, args.series_steps, seed=SEED, on_step=grab, ring=ring)
+    sdiag = eng.run_series_tiled(n, args.series_steps, seed=SEED, on_step=grab, ring=ring)[0]   # ([1]: a ring slot)
     torch.cuda.synchronize()
     t_series = time.perf_counter() - t0
     eng.check()
@@ -731,7 +731,161 @@ def other_configs(args, torch, np, _lib, RasterEngine, table, bplut):
                   'the float64 arithmetic and bounds the ABSOLUTE error; relative error exceeds 1e-5 on the '
                   'counted share of (small) values')
     out['c5_global_grid_float32'] = c5
+    del r, ref, e_mixed, e_fast, e, ras, got, want, res      # (loop variables hold the rasters too)
+    import gc
+    gc.collect()                 # bound steps and their launch closures are reference cycles
+    torch.cuda.empty_cache()
+    if torch.cuda.memory_allocated() > n * 40:
+        raise RuntimeError('a raster of an earlier configuration is still alive (%.1f GB allocated)'
+                           % (torch.cuda.memory_allocated() / 1e9))
+    # ---- the other forms of the forward run (N1, N3, separate=True) and the calibration path (N2)
+    out['forms_float64'] = forms_config(torch, np, _lib, RasterEngine, table, bplut, 'float64', _lib.MATH_FAST, 10800)
+    out['forms_float32_mixed'] = forms_config(torch, np, _lib, RasterEngine, table, bplut, 'float32', _lib.MATH_MIXED, 10800)
+    out['n2_calibration'] = n2_config(np, _lib)
     return out
+
+
+def forms_config(torch, np, _lib, RasterEngine, table, bplut, dtype, math, rows):
+    """The other forms of the forward run on the tiled layout (SURVEY.md 8f N1 / N3 and
+    separate=True): potential ET, six components, totals + components, raw drivers without /
+    with the 8-day total. Per form: ms per launch (events on the launch stream), share of the
+    HBM peak at the form's algorithmic bytes per pixel, and the numpy oracle on a window of
+    320 k pixels (inputs and outputs copied back)."""
+    from oracle import mod16_oracle as oracle
+    n = rows * 43200
+    eng = RasterEngine(table, dtype=dtype, math=math)
+    esz = eng.np_dtype.itemsize
+    cls, drv = eng.synth(n, seed=SEED)
+    g = torch.Generator(device='cuda').manual_seed(1)
+    u = lambda lo, hi: torch.empty(n, dtype=eng.dtype, device='cuda').uniform_(lo, hi, generator=g)
+    raw = drv[:9] + [u(0.001, 0.02), u(0.001, 0.02), u(7e4, 1.0134e5), u(7e4, 1.0134e5), u(0, 3500)]
+    fpar = torch.randint(0, 101, (n,), dtype=torch.uint8, device='cuda', generator=g)
+    lai = torch.randint(0, 71, (n,), dtype=torch.uint8, device='cuda', generator=g)
+    fill = torch.rand(n, device='cuda', generator=g) < 0.01
+    fpar[fill] = 255
+    lai[fill] = 250
+    hours = u(8, 16)
+    lo = (n // 2) // 8192 * 8192
+    hi = lo + 320000
+    mixed = math == _lib.MATH_MIXED
+    rtol = 1e-3 if mixed else (1e-8 if dtype == 'float64' else 1e-6)
+    cases = [('potential_et', _lib.FORM_PET, 14 * esz + 1 + 4 * esz),
+             ('components', _lib.FORM_COMPONENTS, 14 * esz + 1 + 6 * esz),
+             ('totals_and_components', _lib.FORM_TOTALS_COMPONENTS, 14 * esz + 1 + 8 * esz),
+             ('raw_drivers', _lib.FORM_RAW, 14 * esz + 3 + 2 * esz),
+             ('raw_drivers_total8', _lib.FORM_RAW_TOTAL8_HOURS, 15 * esz + 3 + 3 * esz)]
+    out = {'pixels': n, 'layout': 'tiled', 'parity_rtol': rtol,
+           'parity_note': 'largest relative error against the numpy oracle on 320 k pixels; masks = NaN and '
+                          'exact-zero masks identical' + (' (float32 subnormals count as zero)' if mixed else '')}
+
+    def f64(ts):
+        return [t.cpu().numpy().astype(np.float64) for t in ts]
+
+    for name, form, bpp in cases:
+        r = eng.alloc_tiled(n, form=form)
+        is_raw = form >= _lib.FORM_RAW
+        wide = (raw + [hours])[:len(r.wide)] if is_raw else drv
+        for dst, src in zip(r.wide, wide):
+            r.put(dst, src)
+        for dst, src in zip(r.bytes, [cls, fpar, lai]):
+            r.put(dst, src)
+        eng.run_form_tiled(r)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            eng.run_form_tiled(r)
+        e1.record()
+        torch.cuda.synchronize()
+        eng.check()
+        ms = e0.elapsed_time(e1) / 5
+        h_cls = cls[lo:hi].cpu().numpy()
+        with np.errstate(all='ignore'):
+            if is_raw:
+                want = oracle.evapotranspiration_raw(
+                    bplut, h_cls, f64([x[lo:hi] for x in raw]), fpar[lo:hi].cpu().numpy(), lai[lo:hi].cpu().numpy(),
+                    day_hours=hours[lo:hi].cpu().numpy().astype(np.float64) if form == _lib.FORM_RAW_TOTAL8_HOURS else None)
+            else:
+                h_drv = f64([x[lo:hi] for x in drv])
+                params = oracle.gather_params(bplut, h_cls)
+                sep = oracle.evapotranspiration(params, *h_drv, separate=True)
+                tot = oracle.evapotranspiration(params, *h_drv)
+                if form == _lib.FORM_PET:
+                    want = list(tot) + list(oracle.potential_et(params, *h_drv))
+                elif form == _lib.FORM_COMPONENTS:
+                    want = list(sep[0]) + list(sep[1])
+                else:
+                    want = list(tot) + list(sep[0]) + list(sep[1])
+        worst, masks = 0.0, True
+        tiny = float(np.finfo(np.float32).tiny)
+        for o, w in zip(r.outs, want):
+            got = r.flat(o, lo, hi).cpu().numpy().astype(np.float64)
+            w = w.astype(eng.np_dtype).astype(np.float64)
+            if mixed:
+                got = np.where(np.abs(got) < tiny, 0, got)
+                w = np.where(np.abs(w) < tiny, 0, w)
+            masks = masks and bool(np.array_equal(np.isnan(got), np.isnan(w)) and np.array_equal(got == 0, w == 0))
+            ok = np.isfinite(w) & (w != 0)
+            err = np.abs(got[ok] - w[ok])
+            if mixed:       # the mixed form bounds the absolute error (DESIGN.md 5.1)
+                err = np.where(err <= 1e-6 * np.abs(w[ok]).max(), 0, err)
+            worst = max(worst, float(np.max(err / np.abs(w[ok]))))
+        out[name] = {'ms': ms, 'bytes_per_pixel': bpp, 'GBps': bpp * n / ms / 1e6,
+                     'frac': bpp * n / ms / 1e6 / HBM_PEAK_GBPS,
+                     'parity': {'max_rel_err_vs_oracle': worst, 'masks_equal': masks, 'within_rtol': worst <= rtol}}
+        del r
+        torch.cuda.empty_cache()
+    return out
+
+
+def n2_config(np, _lib):
+    """the calibration path MOD16._et evaluated for 2048 parameter vectors
+    (the sampler's loop, reference calibration.py:907, sensitivity.py:95) over 100 k pixels in
+    one launch, reference-order and FAST arithmetic; numpy in, the objective (sse, count) out.
+    Bound: the float64 vector pipe -- instructions per pixel-draw from the listing
+    (profiles/r03_isa_mix_calibration_kernels.txt) against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz."""
+    import mod16_amd
+    from oracle import mod16_oracle as oracle
+    from oracle import synth
+    n, ndraw = 100000, 2048
+    rng = np.random.default_rng(0)
+    _, drv = synth.drivers((n,), seed=1)
+    lo = np.array([-10, 5, 400, 2000, 0.01, 0.01, 1e-6, 0.001, 20, 60, 50.0])
+    hi = np.array([-6, 15, 1000, 5000, 0.12, 0.12, 1e-4, 0.01, 70, 120, 800.0])
+    params = rng.uniform(lo, hi, (ndraw, 11))
+    M = mod16_amd.MOD16
+    with np.errstate(all='ignore'):
+        want = [oracle.et_static(list(params[d]), *drv) for d in (0, 1, ndraw - 1)]
+    obs = want[0] + rng.normal(0, 5, n)
+    res = {'pixels': n, 'draws': ndraw, 'valu_peak_lane_instructions_per_s': 256 * 4 * 16 * 2.4e9}
+    for name, math, per_draw in (('reference_order', _lib.MATH_EXACT, N2_INSTR['reference_order']),
+                                 ('fast', _lib.MATH_FAST, N2_INSTR['fast'])):
+        M._et_batch(params[:4], *drv, observed=obs, math=math)
+        best = 1e30
+        for _ in range(3):
+            t0 = time.perf_counter()
+            sse, cnt = M._et_batch(params, *drv, observed=obs, math=math)
+            best = min(best, time.perf_counter() - t0)
+        rows = M._et_batch(params[[0, 1, ndraw - 1]], *drv, math=math)
+        worst, masks = 0.0, True
+        for got, w in zip(rows, want):
+            masks = masks and bool(np.array_equal(np.isnan(got), np.isnan(w)) and np.array_equal(got == 0, w == 0))
+            ok = np.isfinite(w) & (w != 0)
+            worst = max(worst, float(np.max(np.abs(got[ok] - w[ok]) / np.abs(w[ok]))))
+        rate = n * ndraw / best
+        res[name] = {'seconds': best, 'pixel_draws_per_s': rate,
+                     'valu_instructions_per_pixel_draw': per_draw,
+                     'frac_of_valu_issue_peak': rate * per_draw / res['valu_peak_lane_instructions_per_s'] if per_draw else None,
+                     'parity': {'max_rel_err_vs_oracle': worst, 'masks_equal': masks, 'draws_checked': 3},
+                     'objective_first_draw': float(sse[0] / cnt[0])}
+    res['note'] = ('numpy in -> (sse, count) out: the 11 MB of drivers go up once per call, 32 KB come back; '
+                   'bound = the float64 vector pipe, not HBM (each pixel is read once for 2048 draws)')
+    return res
+
+
+# VALU instructions per pixel-draw of the batched calibration kernels' inner loop (static count of
+# the gfx950 listing, tools/isa_count.py; profiles/r03_isa_mix_calibration_kernels.txt)
+N2_INSTR = {'reference_order': 2325, 'fast': 180}
 
 
 if __name__ == '__main__':
