@@ -188,13 +188,16 @@ class RasterStore(object):
 
 
 def run_store(bplut, root, tile_pixels=1 << 22, workers=4, beta=None, math=_lib.MATH_FAST,
-              device=0):
+              device=0, readers=3):
     '''
     Forward run over every step and pixel of the store at ``root``: reads the raw
     fields, writes ``out/ET_daytime`` and ``out/ET_nighttime`` [kg m-2 s-1], tile
     by tile through ``workers`` concurrent pipelines (each: page-locked buffers,
-    device buffers, a stream and a context of its own). Short-wave radiation at
-    night is zero, as in the reference (calibration.py:383).
+    device buffers, a stream and a context of its own; ``readers`` threads per
+    pipeline share the positional reads and writes of a step -- one thread copies
+    13-17 GB/s out of the page cache, which was the bound of the single-reader
+    pipeline of round 2). Short-wave radiation at night is zero, as in the
+    reference (calibration.py:383).
 
     Returns a report: per stage (``read``, ``h2d``, ``kernel``, ``d2h``,
     ``write``) the bytes moved, the busy seconds summed over the workers and the
@@ -243,15 +246,16 @@ def run_store(bplut, root, tile_pixels=1 << 22, workers=4, beta=None, math=_lib.
             h_pft, d_pft = pin((tile,), torch.uint8), dev((tile,), torch.uint8)
             zero = torch.zeros(1, dtype=tdt, device='cuda:%d' % device)
             local = {k: [0, 0.0] for k in stats}
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max(1, int(readers)))
             ready.wait()
 
             def read_step(b, t, p0, m):
                 t0 = time.perf_counter()
-                nb = 0
-                for k, (_, name) in enumerate(DYNAMIC_FIELDS):
-                    nb += files[name].read_into(b['h_dyn'][k, :m].numpy(), t, p0)
-                nb += files[FPAR].read_into(b['h_u8'][0, :m].numpy(), t, p0)
-                nb += files[LAI].read_into(b['h_u8'][1, :m].numpy(), t, p0)
+                todo = [(files[name], b['h_dyn'][k, :m].numpy()) for k, (_, name) in enumerate(DYNAMIC_FIELDS)]
+                todo += [(files[FPAR], b['h_u8'][0, :m].numpy()), (files[LAI], b['h_u8'][1, :m].numpy())]
+                # (preadv releases the GIL: the fields of a step are read side by side)
+                nb = sum(pool.map(lambda fa: fa[0].read_into(fa[1], t, p0), todo))
                 local['read'][0] += nb
                 local['read'][1] += time.perf_counter() - t0
                 b['nbytes'] = nb
@@ -284,8 +288,9 @@ def run_store(bplut, root, tile_pixels=1 << 22, workers=4, beta=None, math=_lib.
                     local[key][0] += bytes_
                     local[key][1] += ev[i].elapsed_time(ev[j]) * 1e-3
                 t0 = time.perf_counter()
-                nb = outs[OUT_DAY].write_from(b['h_out'][0, :m].numpy(), t, p0)
-                nb += outs[OUT_NIGHT].write_from(b['h_out'][1, :m].numpy(), t, p0)
+                nb = sum(pool.map(lambda fa: fa[0].write_from(fa[1], t, p0),
+                                  [(outs[OUT_DAY], b['h_out'][0, :m].numpy()),
+                                   (outs[OUT_NIGHT], b['h_out'][1, :m].numpy())]))
                 local['write'][0] += nb
                 local['write'][1] += time.perf_counter() - t0
 
@@ -315,6 +320,7 @@ def run_store(bplut, root, tile_pixels=1 << 22, workers=4, beta=None, math=_lib.
                         read_step(nxt_set, t + 1, p0, m)    # while step t is on the GPU
                     finish(cur, t, p0, m)
                 eng.check()
+            pool.shutdown()
             for f in list(files.values()) + list(outs.values()):
                 f.close()
             with lock:
@@ -345,7 +351,7 @@ def run_store(bplut, root, tile_pixels=1 << 22, workers=4, beta=None, math=_lib.
         raise errors[0]
     total_bytes = stats['read'][0] + stats['write'][0]
     report = {'steps': T, 'pixels': N, 'dtype': dt.name, 'tile_pixels': tile,
-              'workers': len(threads), 'setup_s': setup, 'wall_s': wall,
+              'workers': len(threads), 'readers_per_worker': max(1, int(readers)), 'setup_s': setup, 'wall_s': wall,
               'pixels_per_s': T * N / wall, 'file_GBps': total_bytes / wall / 1e9,
               'stages': {k: {'bytes': v[0], 'busy_s_sum_over_workers': v[1],
                              'GBps_while_busy': (v[0] / v[1] / 1e9) if v[1] else None}

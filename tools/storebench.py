@@ -63,6 +63,7 @@ def main():
     ap.add_argument('--dtype', default='float32')
     ap.add_argument('--workers', default='1,4,8')
     ap.add_argument('--tile', type=int, default=1 << 22)
+    ap.add_argument('--readers', default='1,3', help='reader threads per worker, comma-separated')
     args = ap.parse_args()
     table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
     root = tempfile.mkdtemp(prefix='mod16_store_', dir=args.dir)
@@ -74,8 +75,9 @@ def main():
         size = args.steps * args.pixels * (11 * esz + 2 + 2 * esz) + args.pixels * (2 * esz + 1)
         print(json.dumps({'store': root, 'bytes_in_and_out': size, 'fill_seconds': time.perf_counter() - t0}), flush=True)
         for w in [int(x) for x in args.workers.split(',')]:
-            rep = io.run_store(table, root, tile_pixels=args.tile, workers=w)
-            print(json.dumps(rep), flush=True)
+            for rd in [int(x) for x in args.readers.split(',')]:
+                rep = io.run_store(table, root, tile_pixels=args.tile, workers=w, readers=rd)
+                print(json.dumps(rep), flush=True)
         # spot check: the last tile of the last step against a direct HOST-mode call
         import mod16_amd
         p0 = max(0, args.pixels - 100000)
