@@ -52,7 +52,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md)
 PMC_TRAFFIC = [os.path.join(ROOT, 'profiles', f) for f in
-               ('r02_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic_float32.json',
+               ('r03_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic_float32.json',
+                'r02_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic_float32.json',
                 'r01j_pmc_hbm_traffic.json', 'r01i_pmc_hbm_traffic_float32.json')]
 TILE = (1200, 1200)           # BASELINE.json configs[1], the CPU sample unit
 SEED = 16

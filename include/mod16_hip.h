@@ -83,21 +83,25 @@ enum mod16_where { MOD16_HOST = 0, MOD16_DEVICE = 1 };
  *
  * MOD16_MATH_FAST rearranges the smooth arithmetic (conductances instead of resistances,
  * shared per-period terms, table exp / log) and keeps every comparison of the reference:
- * within 1e-9 of the reference-order kernel, NaN and exact-zero masks identical, on finite
- * drivers of physical magnitude -- NaN anywhere, zeros, the usual fill values in the
- * radiation / albedo / VPD / fPAR / LAI fields included. Outside that domain (an infinite
- * driver, magnitudes whose products overflow float64, a temperature above 1332 K where the
- * latent heat of vaporization turns negative or exactly on the pole of the saturation
- * formula at 35.85 K, a negative pressure) the reference computes garbage from garbage and
- * FAST computes other garbage; MOD16_MATH_EXACT reproduces the reference's there as well
- * (tests/test_gpu_parity.py::test_special_values_*, tests/fuzz_special_values.py). */
+ * within 1e-9 of the reference-order kernel, NaN and exact-zero masks identical. Its own
+ * domain is finite drivers of physical sign and magnitude (NaN anywhere, zeros and the usual
+ * fill values in the radiation / albedo / VPD / fPAR / LAI fields included); a pixel outside
+ * it -- an infinite driver, |LAI| or |pressure| beyond 1e100, a negative pressure, a
+ * temperature outside (36 K, 1332 K): the pole of the saturation formula, a negative latent
+ * heat -- is detected in the kernel and computed in the reference's operation order
+ * instead, so that the DEFAULT arithmetic returns what the reference returns for every
+ * input, NaN / zero / inf masks included (csrc/mod16_physics.hpp "domain guard";
+ * tests/test_gpu_parity.py::test_special_values_*, tests/test_gpu_guard.py,
+ * tests/fuzz_domain.py). MOD16_MATH_EXACT is the reference's operation order throughout. */
 #define MOD16_MATH_FAST   0u  /* strength-reduced arithmetic (default)          */
 #define MOD16_MATH_EXACT  1u  /* reference operation order, IEEE divide/pow     */
 #define MOD16_MATH_MIXED  2u  /* float32 rasters: float64 where it decides a mask or
                                  feeds the humidity terms, packed float32 elsewhere
-                                 (dense class rasters; other shapes run FAST). Domain:
-                                 FAST's, less what overflows or underflows float32
-                                 products (a +-3.4e38 fill, a temperature near 0 K) */
+                                 (dense class rasters; other shapes run FAST). Its domain
+                                 is physical drivers (|lw|, |sw|, |albedo|, |vpd|, |fpar|,
+                                 |lai| < 1e5, 1e3 <= pressure < 1e7 Pa, 90 K < T < 1332 K);
+                                 pixels outside it are computed in the reference's order,
+                                 float64, like FAST's */
 
 typedef struct mod16_ctx mod16_ctx;
 
