@@ -746,12 +746,14 @@ __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const 
 //   - an infinite lw_net_day / lw_net_night / sw_rad_day / sw_albedo / fpar / vpd (inf * 0 or
 //     inf - inf where the reference has separate operations; vpd = -inf shows in the components
 //     only), |lai| or |pressure| >= 1e200 (products overflow),
-//   - a negative pressure (the merged clamps assume rho, r_corr > 0),
+//   - a negative pressure (the merged clamps assume rho, r_corr > 0); pairs of special values
+//     add: a pressure of 1e-300 next to a large value (underflow), sw_rad_night = 1e300 next to
+//     a large LAI / pressure (overflow),
 //   - a temperature above 1332.4 K (latent heat <= 0: the reference's soil evaporation turns
 //     negative where the merged clamp gives 0) or within 2e-4 K of 35.85 K (the pole of the
 //     Tetens formula: the table exp is not reduced for |x| > 2.3e7);
 // NaN anywhere, zeros, negative or huge values elsewhere are inside the domain. The guard
-// below is wider than that map (1e100, everything below 36 K) and costs 13 vector
+// below is wider than that map (1e50, everything below 36 K, pressures below 1 Pa) and costs 14 vector
 // instructions per pixel; a pixel it flags is computed again by et_pixel_exact -- the
 // reference's own operation order -- in a branch that a wave enters only if one of its
 // lanes holds such a pixel (stream kernels: mod16_stream.hpp; plain kernels: et_kernel).
@@ -766,8 +768,10 @@ __device__ __forceinline__ double max_abs_signed(double a, double b) {   // maxN
     asm("v_max_f64 %0, |%1|, %2" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
-constexpr double kGuardHuge = 1e100;          // |x| at or beyond this (or infinite): reference order
-                                              // (the products of the fast form hold up to the square of 1e150)
+constexpr double kGuardHuge = 1e50;           // |x| at or beyond this (or infinite): reference order. Single
+                                              // drivers pass the fast form up to 1e100 and beyond, but its
+                                              // products take up to four of them: 1e50 keeps every product of
+                                              // guarded values inside float64 (tests/fuzz_domain.py, pairs)
 constexpr double kGuardTmin = 36.0;           // K; 35.85 K is the pole of the Tetens formula
 constexpr double kGuardTmax = 1332.0;         // K; latent heat of vaporization <= 0 from 1332.4 K
 
@@ -794,8 +798,12 @@ __device__ __forceinline__ bool fast_out_of_domain(const PixelIn<double>& x) {
     // lw, which the pixel function needs anyway: an infinite one of them makes A infinite -- or
     // NaN (inf * 0, inf - inf), and then it is NaN in the reference as well and behaves like a
     // NaN driver, which is inside the domain. (Finite huge values of these three are inside it.)
-    const double a_d = __builtin_fma(x.sw_d, 1.0 - x.alb, x.lw_d);
+    // sw_rad_night likewise through the night's net radiation (next to lw_net_night itself,
+    // which also enters the soil's balance on its own).
+    const double oma = 1.0 - x.alb;
+    const double a_d = __builtin_fma(x.sw_d, oma, x.lw_d), rn_n = __builtin_fma(x.sw_n, oma, x.lw_n);
     double m = max_abs(a_d, x.lw_n);
+    m = max_abs(m, rn_n);
     m = max_abs(m, x.fpar);
     m = max_abs(m, x.lai);
     m = max_abs(m, x.pa);
@@ -803,7 +811,9 @@ __device__ __forceinline__ bool fast_out_of_domain(const PixelIn<double>& x) {
     m = max_abs(m, x.vpd_n);
     m = max_abs(m, guard_temperature(x.t_d));
     m = max_abs(m, guard_temperature(x.t_n));
-    return (m >= in_vgpr(kGuardHuge)) | (x.pa < 0.0);
+    // (a pressure below 1 Pa -- zero, negative, 1e-300 -- as well: its products with the other
+    // drivers underflow where the reference's do not)
+    return (m >= in_vgpr(kGuardHuge)) | (x.pa < 1.0);
 #endif
 }
 
@@ -879,8 +889,10 @@ __device__ __forceinline__ bool raw_out_of_domain(const RawIn<double>& r) {
 #ifdef MOD16_NO_GUARD
     return false;
 #else
-    const double a_d = __builtin_fma(r.sw_d, 1.0 - r.alb, r.lw_d);      // see fast_out_of_domain
+    const double oma = 1.0 - r.alb;                                     // see fast_out_of_domain
+    const double a_d = __builtin_fma(r.sw_d, oma, r.lw_d), rn_n = __builtin_fma(r.sw_n, oma, r.lw_n);
     double m = max_abs(a_d, r.lw_n);
+    m = max_abs(m, rn_n);
     m = max_abs(m, r.ps_d);
     m = max_abs(m, r.ps_n);
     m = max_abs(m, r.qv_d * in_vgpr(kGuardHuge));          // |qv| < 1

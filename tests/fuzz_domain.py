@@ -7,6 +7,7 @@ domain guard in place (mod16_physics.hpp: fast_out_of_domain) every list must be
 MOD16_NO_GUARD=1 in the environment of the BUILD (-DMOD16_NO_GUARD) the lists are the map the
 guard was drawn from. Uses oracle/ as the checker, so it lives under tests/
 (`python tests/fuzz_domain.py`)."""
+import collections
 import os
 import sys
 
@@ -101,7 +102,56 @@ def main():
     got = m16.evapotranspiration_raster(table, cls, *d32, math=m16._lib.MATH_MIXED)
     total += sum(report('mixed float32', got, want, which, lad32, 1e-3, mixed=True))
     total += raw_forms(table, bplut)
+    total += pairs(table, bplut)
     return 0 if total == 0 else 1
+
+
+PAIR_VALUES = [0.0, -0.0, np.nan, np.inf, -np.inf, -9999.0, 65535.0, 1e15, 3.4e38, -3.4e38, 1e300, -1e300,
+               1e-300, -1e-300, 1e-7, 1.0, -1.0, 35.85, 34.15, 1400.0, 1e40, -1e40, 1e49, 1e60, 1e100, 1e150, 1e200]
+
+
+def pairs(table, bplut, n=1200000, seed=5):
+    """TWO special values in two different drivers of every pixel (random pairs: an infinity next
+    to a NaN, to a zero, to the albedo 1 that turns inf * (1 - albedo) into NaN ...): the guard
+    has to hold for combinations, not only for the single values it was drawn from."""
+    rng = np.random.default_rng(seed)
+    cls, drv, _ = rasters([1.0], per=1)             # shapes only
+    t_d = rng.uniform(255, 305, n)
+    t_n = t_d - rng.uniform(0, 12, n)
+    es = lambda t: 610.8 * np.exp(17.27 * (t - 273.15) / (t - 273.15 + 237.3))
+    drv = [rng.uniform(-100, 0, n), rng.uniform(-50, 0, n), rng.uniform(0, 360, n), np.zeros(n),
+           rng.uniform(0.1, 0.22, n), t_d, t_n, rng.uniform(265, 300, n), t_n - rng.uniform(0, 3, n),
+           es(t_d) * (1 - rng.uniform(0.05, 1, n)), es(t_n) * (1 - rng.uniform(0.05, 1, n)),
+           rng.uniform(7e4, 101340, n), rng.uniform(0.02, 0.89, n), rng.uniform(0.13, 5.34, n)]
+    a = rng.integers(0, 14, n)
+    b = (a + rng.integers(1, 14, n)) % 14
+    va = np.array(PAIR_VALUES)[rng.integers(0, len(PAIR_VALUES), n)]
+    vb = np.array(PAIR_VALUES)[rng.integers(0, len(PAIR_VALUES), n)]
+    for k in range(14):
+        drv[k][a == k] = va[a == k]
+        drv[k][b == k] = vb[b == k]
+    cls = rng.choice(np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12], np.uint8), n)
+    with np.errstate(all='ignore'):
+        want = oracle.evapotranspiration_raster(bplut, cls, *drv, separate=True)
+    got = m16.evapotranspiration_raster(table, cls, *drv, separate=True, math=m16._lib.MATH_FAST)
+    bad = np.zeros(n, bool)
+    off = np.zeros(n, bool)
+    for g3, w3 in zip(got, want):
+        for g, w in zip(g3, w3):
+            bad |= (np.isnan(g) != np.isnan(w)) | ((g == 0) != (w == 0)) | (np.isinf(g) != np.isinf(w))
+            ok = np.isfinite(w) & (w != 0) & np.isfinite(g)
+            rel = np.zeros(n)
+            rel[ok] = np.abs(g[ok] - w[ok]) / np.abs(w[ok])
+            off |= rel > 1e-8
+    off &= ~bad
+    print('pairs, fast float64 (six components): %d of %d pixels with a mask that differs from the oracle, '
+          '%d more off by > 1e-08' % (int(bad.sum()), n, int(off.sum())))
+    tally = collections.Counter()
+    for i in np.nonzero(bad | off)[0][:100000]:
+        tally[(NAMES[a[i]], '%g' % va[i], NAMES[b[i]], '%g' % vb[i])] += 1
+    for key, cnt in tally.most_common(40):
+        print('   %-13s = %-9s with %-13s = %-9s : %d' % (key + (cnt,)))
+    return int(bad.sum()) + int(off.sum())
 
 
 RAW_NAMES = NAMES[:9] + ['qv10m_day', 'qv10m_night', 'ps_day', 'ps_night', 'elevation']
