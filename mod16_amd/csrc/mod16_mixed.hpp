@@ -292,7 +292,12 @@ __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], co
     sh.k_p = pa * splat((float)(1013.0 / 0.622));
     sh.p_mbar_k = pa * splat((float)(0.348444 / 100.0));
     const f2 l_wet = sel(lai.x == 0.f, lai.y == 0.f, splat(1e-7f), lai);              // :935
-    sh.lai_tiny[0] = l_wet.x <= 1e-7f; sh.lai_tiny[1] = l_wet.y <= 1e-7f;
+    // lai <= tiny (:961) is asked in float64 of the float32 value: float32(1e-7) is ABOVE 1e-7,
+    // so a LAI of exactly that float is not masked by the reference (pair fuzz, round 3):
+    // x <= 1e-7  <=>  x <= 0x1.ad7f28p-24f, the largest float32 below; LAI = 0 became tiny above
+    constexpr float kTinyBelow = 0x1.ad7f28p-24f;
+    sh.lai_tiny[0] = (lai.x == 0.f) | (lai.x <= kTinyBelow);
+    sh.lai_tiny[1] = (lai.y == 0.f) | (lai.y <= kTinyBelow);
     sh.lai_pos[0] = lai.x > 0.f; sh.lai_pos[1] = lai.y > 0.f;
     sh.glsh_l = p.gl_sh * l_wet;
     sh.glwv_l = p.gl_wv * l_wet;

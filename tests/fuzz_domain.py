@@ -151,7 +151,35 @@ def pairs(table, bplut, n=1200000, seed=5):
         tally[(NAMES[a[i]], '%g' % va[i], NAMES[b[i]], '%g' % vb[i])] += 1
     for key, cnt in tally.most_common(40):
         print('   %-13s = %-9s with %-13s = %-9s : %d' % (key + (cnt,)))
-    return int(bad.sum()) + int(off.sum())
+    total = int(bad.sum()) + int(off.sum())
+    # float32 rasters, FAST and MIXED (totals): the values a float32 holds
+    keep = np.array([not np.isfinite(v) or v == 0 or 1e-37 < abs(v) < 3.41e38 for v in PAIR_VALUES])
+    ok_pix = np.isin(va, np.array(PAIR_VALUES)[keep]) | np.isnan(va)
+    ok_pix &= np.isin(vb, np.array(PAIR_VALUES)[keep]) | np.isnan(vb)
+    d32 = [d[ok_pix].astype(np.float32) for d in drv]
+    c32 = cls[ok_pix]
+    with np.errstate(all='ignore'):
+        want = [w.astype(np.float32).astype(np.float64) for w in
+                oracle.evapotranspiration_raster(bplut, c32, *[d.astype(np.float64) for d in d32])]
+    which = np.zeros(c32.size, np.int64)
+    for name, math, tol, mixed in (('pairs, fast float32', m16._lib.MATH_FAST, 1e-6, False),
+                                   ('pairs, mixed float32', m16._lib.MATH_MIXED, 1e-3, True)):
+        got = m16.evapotranspiration_raster(table, c32, *d32, math=math)
+        total += sum(report(name, got, want, which, [0.0], tol, mixed=mixed))
+        tiny = float(np.finfo(np.float32).tiny)
+        badp = np.zeros(c32.size, bool)
+        for g, w in zip(got, want):
+            g = g.astype(np.float64)
+            if mixed:
+                g, w = np.where(np.abs(g) < tiny, 0, g), np.where(np.abs(w) < tiny, 0, w)
+            badp |= (np.isnan(g) != np.isnan(w)) | ((g == 0) != (w == 0)) | (np.isinf(g) != np.isinf(w))
+        tally = collections.Counter()
+        ia, ib, xa, xb = a[ok_pix], b[ok_pix], va[ok_pix], vb[ok_pix]
+        for i in np.nonzero(badp)[0][:2000]:
+            tally[(NAMES[ia[i]], '%g' % xa[i], NAMES[ib[i]], '%g' % xb[i])] += 1
+        for key, cnt in tally.most_common(25):
+            print('   %-13s = %-9s with %-13s = %-9s : %d' % (key + (cnt,)))
+    return total
 
 
 RAW_NAMES = NAMES[:9] + ['qv10m_day', 'qv10m_night', 'ps_day', 'ps_night', 'elevation']
