@@ -103,6 +103,7 @@ def main():
     total += sum(report('mixed float32', got, want, which, lad32, 1e-3, mixed=True))
     total += raw_forms(table, bplut)
     total += pairs(table, bplut)
+    total += raw_pairs(table, bplut)
     return 0 if total == 0 else 1
 
 
@@ -218,6 +219,65 @@ def raw_forms(table, bplut):
         got = m16.evapotranspiration_raw(table, cls, *raw, fpar, lai, math=math)
         keep, NAMES = NAMES, RAW_NAMES
         total += sum(report(name, got, want, which, values, tol, mixed=math == m16._lib.MATH_MIXED))
+        NAMES = keep
+    return total
+
+
+
+def raw_pairs(table, bplut, n=600000, seed=6):
+    """Pairs of special values in the RAW fields (specific humidity, surface pressure, elevation
+    included), float64 and float32 (FAST, MIXED)."""
+    rng = np.random.default_rng(seed)
+    values = np.array(PAIR_VALUES + [0.5, 0.99, 1.5, -1.65, 8848.0, 4e4, 44330.0, -5e4])
+    t_d = rng.uniform(255, 305, n)
+    t_n = t_d - rng.uniform(0, 12, n)
+    raw = [rng.uniform(-100, 0, n), rng.uniform(-50, 0, n), rng.uniform(0, 360, n), np.zeros(n),
+           rng.uniform(0.1, 0.22, n), t_d, t_n, rng.uniform(265, 300, n), t_n - rng.uniform(0, 3, n),
+           rng.uniform(5e-4, 2e-2, n), rng.uniform(5e-4, 2e-2, n),
+           rng.uniform(70000, 101340, n), rng.uniform(70000, 101340, n), rng.uniform(-50, 4500, n)]
+    a = rng.integers(0, 14, n)
+    b = (a + rng.integers(1, 14, n)) % 14
+    va, vb = values[rng.integers(0, len(values), n)], values[rng.integers(0, len(values), n)]
+    for k in range(14):
+        raw[k][a == k] = va[a == k]
+        raw[k][b == k] = vb[b == k]
+    fpar = rng.integers(0, 101, n).astype(np.uint8)
+    lai = rng.integers(0, 70, n).astype(np.uint8)
+    cls = rng.choice(np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12], np.uint8), n)
+    total = 0
+    f32ok = np.array([not np.isfinite(v) or v == 0 or 1e-37 < abs(v) < 3.41e38 for v in values])
+    pix32 = (np.isin(va, values[f32ok]) | np.isnan(va)) & (np.isin(vb, values[f32ok]) | np.isnan(vb))
+    for name, dtype, math, tol, mixed in (('raw pairs, fast float64', np.float64, m16._lib.MATH_FAST, 1e-8, False),
+                                          ('raw pairs, fast float32', np.float32, m16._lib.MATH_FAST, 1e-6, False),
+                                          ('raw pairs, mixed float32', np.float32, m16._lib.MATH_MIXED, 1e-3, True)):
+        sel = np.ones(n, bool) if dtype == np.float64 else pix32
+        r = [x[sel].astype(dtype) for x in raw]
+        with np.errstate(all='ignore'):
+            want = [w.astype(dtype).astype(np.float64) for w in oracle.evapotranspiration_raw(
+                bplut, cls[sel], [x.astype(np.float64) for x in r], fpar[sel], lai[sel])]
+        got = m16.evapotranspiration_raw(table, cls[sel], *r, fpar[sel], lai[sel], math=math)
+        global NAMES
+        keep, NAMES = NAMES, RAW_NAMES
+        total += sum(report(name, got, want, np.zeros(int(sel.sum()), np.int64), [0.0], tol, mixed=mixed))
+        tiny = float(np.finfo(np.float32).tiny)
+        badp = np.zeros(int(sel.sum()), bool)
+        for g, w in zip(got, want):
+            g = g.astype(np.float64)
+            if mixed:
+                g, w = np.where(np.abs(g) < tiny, 0, g), np.where(np.abs(w) < tiny, 0, w)
+            badp |= (np.isnan(g) != np.isnan(w)) | ((g == 0) != (w == 0)) | (np.isinf(g) != np.isinf(w))
+            ok = np.isfinite(w) & (w != 0) & np.isfinite(g)
+            rel = np.zeros(badp.size)
+            rel[ok] = np.abs(g[ok] - w[ok]) / np.abs(w[ok])
+            if mixed and ok.any():
+                rel[ok] = np.where(np.abs(g[ok] - w[ok]) <= 1e-6 * np.abs(w[ok]).max(), 0, rel[ok])
+            badp |= rel > tol
+        tally = collections.Counter()
+        ia, ib, xa, xb = a[sel], b[sel], va[sel], vb[sel]
+        for i in np.nonzero(badp)[0][:3000]:
+            tally[(RAW_NAMES[ia[i]], '%g' % xa[i], RAW_NAMES[ib[i]], '%g' % xb[i])] += 1
+        for key, cnt in tally.most_common(25):
+            print('   %-13s = %-9s with %-13s = %-9s : %d' % (key + (cnt,)))
         NAMES = keep
     return total
 
