@@ -118,3 +118,65 @@ def test_flagged_pixels_on_device_rasters(env, n, every, dtype, math):
     d2 = torch.zeros(8, dtype=torch.float64, device='cuda')
     eng.run(cls, drv, out_day=day, out_night=night, diag=d2)
     assert torch.equal(torch.nan_to_num(d2, nan=-7.0), torch.nan_to_num(diag, nan=-7.0))
+
+
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_flagged_pixels_in_the_other_forms_at_size(env, dtype):
+    """Potential ET, the six components and the raw-driver form on rasters large enough for the
+    dynamic schedule (flagged pieces revisited by et_stream_redo_kernel<T, form>), fill values
+    sprinkled in: every output equals the plain kernels' (MOD16_NO_DMA context: same pixel functions,
+    flagged pixels redone inline) bit for bit; and a step captured into a HIP graph replays the
+    revisit as well."""
+    import os
+    torch, RasterEngine, table, _lib = env
+    n = 24_000_000 if dtype == 'float64' else 40_000_000
+    eng = RasterEngine(table, dtype=dtype)
+    os.environ['MOD16_NO_DMA'] = '1'
+    try:
+        plain = RasterEngine(table, dtype=dtype)
+        plain.ctx = _lib.Context(0)
+        plain.ctx.set_bplut(np.ascontiguousarray(table, np.float64))
+    finally:
+        del os.environ['MOD16_NO_DMA']
+    cls, drv = eng.synth(n, seed=4, step=3)
+    idx = sprinkle(torch, drv, n, 9973, seed=11).cuda()
+
+    def same(a, b):
+        return torch.equal(torch.nan_to_num(a, nan=-7.0, posinf=1e300, neginf=-1e300),
+                           torch.nan_to_num(b, nan=-7.0, posinf=1e300, neginf=-1e300))
+
+    got, want = eng.run_pet(cls, drv), plain.run_pet(cls, drv)
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert same(g, w), ('potential ET', k)
+    a, b = eng.empty(n, 6), plain.empty(n, 6)
+    eng.run(cls, drv, None, None, out_sep=a)
+    plain.run(cls, drv, None, None, out_sep=b)
+    for k in range(6):
+        assert same(a[k], b[k]), ('components', k)
+    del a, b, got, want
+    # raw drivers: the first nine fields pass through; humidity, surface pressure, elevation
+    g = torch.Generator(device='cuda').manual_seed(2)
+    u = lambda lo, hi: torch.empty(n, dtype=eng.dtype, device='cuda').uniform_(lo, hi, generator=g)
+    raw = drv[:9] + [u(0.001, 0.02), u(0.001, 0.02), u(7e4, 1.0134e5), u(7e4, 1.0134e5), u(0, 3500)]
+    raw[13][idx[::3]] = 5e4                     # above the guard's 40 km
+    raw[9][idx[1::3]] = 1.5                     # a specific humidity above 1 kg/kg
+    fpar = torch.randint(0, 101, (n,), dtype=torch.uint8, device='cuda', generator=g)
+    lai = torch.randint(0, 71, (n,), dtype=torch.uint8, device='cuda', generator=g)
+    hours = u(8, 16)
+    got = eng.run_raw(cls, raw, fpar, lai, day_hours=hours)
+    want = plain.run_raw(cls, raw, fpar, lai, day_hours=hours)
+    eng.check()
+    plain.check()
+    for k, (g_, w_) in enumerate(zip(got, want)):
+        assert same(g_, w_), ('raw drivers', k)
+    # a captured step: the graph holds the revisit
+    day, night = eng.empty(n, 2)
+    diag = torch.zeros(8, dtype=torch.float64, device='cuda')
+    step = eng.bind(cls, drv, day, night, diag, graph=True)
+    step()
+    torch.cuda.synchronize()
+    d2 = torch.zeros(8, dtype=torch.float64, device='cuda')
+    rd, rn = eng.run(cls, drv, diag=d2)
+    assert same(day, rd) and same(night, rn) and same(diag, d2)
+    pd, pn = plain.run(cls, drv)
+    assert same(day, pd) and same(night, pn)
