@@ -462,7 +462,9 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     if (rc != MOD16_OK) return rc;
     s.diag_partial = ws->partial;
     // few partials: the kernel's last block adds them up itself (two dispatches less)
-    const bool fused_final = ddiag && nruns <= kFuseFinalBelow;
+    // (only under the static schedule: a dynamically scheduled raster's flagged pieces are
+    // revisited by the kernel BEHIND this one, which corrects the partials before they are summed)
+    const bool fused_final = ddiag && g.static_sched && nruns <= kFuseFinalBelow;
     s.diag_out = fused_final ? ddiag : nullptr;
     s.done_counter = ws->done();
     s.nruns = nruns;

@@ -52,7 +52,8 @@ def host_diag(torch, day, night):
 
 
 @pytest.mark.parametrize('n,every', [(1200 * 1200, 997), (1200 * 1200, 7), (40_000_000, 100_003), (40_000_000, 61),
-                                      (8192 * 40 + 4 * 777, 1)])
+                                      (8192 * 40 + 4 * 777, 1),
+                                      (1 << 24, 4099)])      # float64: exactly 16384 runs, the first dynamic size
 @pytest.mark.parametrize('dtype,math', [('float64', 'fast'), ('float32', 'fast'), ('float32', 'mixed')])
 def test_flagged_pixels_on_device_rasters(env, n, every, dtype, math):
     torch, RasterEngine, table, _lib = env
@@ -180,3 +181,39 @@ def test_flagged_pixels_in_the_other_forms_at_size(env, dtype):
     assert same(day, rd) and same(night, rn) and same(diag, d2)
     pd, pn = plain.run(cls, drv)
     assert same(day, pd) and same(night, pn)
+
+
+@pytest.mark.parametrize('switches', [{'MOD16_STATIC_BELOW': '0'}, {'MOD16_STATIC_BELOW': '0', 'MOD16_RUN_SHIFT': '6'},
+                                      {'MOD16_RUN_SHIFT': '6'}, {'MOD16_STATIC_BELOW': '64'}])
+def test_flags_under_other_schedules(env, switches):
+    """The flag record under the schedules the experiment switches select: a small raster on the
+    DYNAMIC schedule (et_stream_redo_kernel on few runs), runs of 64 pieces (more pieces per run than
+    the 52 flag bits: the last bit stands for the rest), the static schedule on a larger raster (more
+    than 52 iterations per wave likewise). Same outputs and diagnostics as the default context."""
+    import os
+    torch, RasterEngine, table, _lib = env
+    n = 3_000_000 if switches.get('MOD16_STATIC_BELOW') != '64' else 20_000_000
+    base = RasterEngine(table)
+    for k, v in switches.items():
+        os.environ[k] = v
+    try:
+        eng = RasterEngine(table)
+        eng.ctx = _lib.Context(0)
+        eng.ctx.set_bplut(np.ascontiguousarray(table, np.float64))
+    finally:
+        for k in switches:
+            del os.environ[k]
+    cls, drv = base.synth(n, seed=12)
+    sprinkle(torch, drv, n, 501, seed=3)
+    drv[5][n // 2: n // 2 + 40000] = 65535.0            # whole runs of flagged pixels
+    d0 = torch.zeros(8, dtype=torch.float64, device='cuda')
+    d1 = torch.zeros(8, dtype=torch.float64, device='cuda')
+    want = base.run(cls, drv, diag=d0)
+    got = eng.run(cls, drv, diag=d1)
+    eng.check()
+    for g, w in zip(got, want):
+        assert torch.equal(torch.nan_to_num(g, nan=-7.0, posinf=1e300, neginf=-1e300),
+                           torch.nan_to_num(w, nan=-7.0, posinf=1e300, neginf=-1e300))
+    a, b = d1.cpu().numpy(), d0.cpu().numpy()
+    assert np.array_equal(a[2:6], b[2:6]) and a[6] == b[6] and a[7] == b[7]
+    assert np.allclose(a[:2], b[:2], rtol=1e-11, equal_nan=True) or (np.isinf(b[:2]).any() and np.array_equal(a[:2], b[:2]))
