@@ -374,7 +374,9 @@ MOD16_API int mod16_et_static_f32(mod16_ctx* ctx, const float* const* drivers,
  * flags = MOD16_MATH_EXACT row d is bit-identical to mod16_et_static_* called
  * with the scalars params[d] (r_corr computed, `rcorr` = NULL); MOD16_MATH_FAST
  * uses the strength-reduced arithmetic of the forward run (float64 throughout,
- * within 1e-9 of EXACT, same NaN and zero masks, several times faster). With `observed` [n] (and optional
+ * within 1e-9 of EXACT, same NaN and zero masks, several times faster -- on finite
+ * drivers of physical sign and magnitude, NaN included: this opt-in form has no domain guard;
+ * towers' drivers are quality-controlled, the default is EXACT). With `observed` [n] (and optional
  * `weights` [n]) the call also reduces each draw to
  *     sse[d]   = sum_i (weights[i] * (out_total[d][i] - observed[i]))^2
  *     count[d] = number of pairs used (NaN pairs are skipped),

@@ -428,7 +428,8 @@ class MOD16(object):
         equals ``MOD16._et(params[d], *drivers)`` bit for bit -- or, with
         ``separate=True``, ``[day, night]``. ``math=_lib.MATH_FAST`` trades the
         bit-identity for speed: the strength-reduced float64 arithmetic of the
-        forward run, within 1e-9 of the default with the same NaN / zero masks. With ``observed`` (and optional
+        forward run, within 1e-9 of the default with the same NaN / zero masks on finite
+        drivers of physical sign and magnitude (this opt-in form has no domain guard). With ``observed`` (and optional
         ``weights``, both of the drivers' shape) nothing of that size comes
         back: the result is ``(sse, count)``, two float64 arrays (D,) with
         ``sse[d] = sum((weights * (_et_d - observed))**2)`` over the non-NaN
