@@ -217,3 +217,40 @@ def test_flags_under_other_schedules(env, switches):
     a, b = d1.cpu().numpy(), d0.cpu().numpy()
     assert np.array_equal(a[2:6], b[2:6]) and a[6] == b[6] and a[7] == b[7]
     assert np.allclose(a[:2], b[:2], rtol=1e-11, equal_nan=True) or (np.isinf(b[:2]).any() and np.array_equal(a[:2], b[:2]))
+
+
+def test_flagged_pixels_through_the_numpy_path_over_many_tiles(env):
+    """numpy in -> numpy out (HOST mode: 2 Mi-pixel tiles staged by eight threads through one
+    context's workspace) with fill values sprinkled in, float64 and float32: what the
+    reference-order arithmetic gives, masks identical."""
+    import mod16_amd as m16
+    from oracle import synth
+    torch, RasterEngine, table, _lib = env
+    n = 5 * (1 << 21) + 12345
+    cls, drv = synth.drivers((n,), seed=8)
+    rng = np.random.default_rng(1)
+    idx = rng.choice(n, 60000, replace=False)
+    which = rng.integers(0, 14, idx.size)
+    val = np.array(FILLS)[rng.integers(0, len(FILLS), idx.size)]
+    for k in range(14):
+        drv[k] = drv[k].copy()
+        drv[k][idx[which == k]] = val[which == k]
+    got = m16.evapotranspiration_raster(table, cls, *drv)
+    with np.errstate(all='ignore'):
+        want = m16.evapotranspiration_raster(table, cls, *drv, math=_lib.MATH_EXACT)
+    assert_parity(got[0], want[0], 1e-9, 'day')
+    assert_parity(got[1], want[1], 1e-9, 'night')
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    sub = idx[:30000]
+    with np.errstate(all='ignore'):
+        o = oracle.evapotranspiration_raster(bplut, cls[sub], *[d[sub] for d in drv])
+    assert_parity(got[0][sub], o[0], 1e-8, 'day vs oracle')
+    assert_parity(got[1][sub], o[1], 1e-8, 'night vs oracle')
+    d32 = [d.astype(np.float32) for d in drv]
+    got32 = m16.evapotranspiration_raster(table, cls, *d32)
+    with np.errstate(all='ignore'):
+        o32 = oracle.evapotranspiration_raster(bplut, cls[sub], *[d[sub].astype(np.float64) for d in d32])
+    with np.errstate(over='ignore'):          # a float64 result beyond float32's range rounds to inf, as the kernel's does
+        w32 = [w.astype(np.float32) for w in o32]
+    assert_parity(got32[0][sub], w32[0], 1e-6, 'day, float32')
+    assert_parity(got32[1][sub], w32[1], 1e-6, 'night, float32')
