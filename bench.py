@@ -220,6 +220,72 @@ def cpu_baseline(max_workers):
     return out
 
 
+def device_sensors(torch):
+    """Directory of the hwmon files (power1_input in uW, power1_cap, freq1_input = shader clock
+    in Hz; read-only) of the card THIS process computes on, found by its PCI address -- a box
+    shows the sensors of all the GPUs of its host."""
+    import ctypes
+    import glob
+    try:
+        hip = ctypes.CDLL('libamdhip64.so')
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, torch.cuda.current_device()) != 0:
+            return None
+        bus = buf.value.decode().lower()
+    except (OSError, AttributeError):
+        return None
+    for path in glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*/power1_input'):
+        if bus in os.path.realpath(path.split('/hwmon')[0]).lower():
+            return os.path.dirname(path)
+    return None
+
+
+def device_under_load(torch, step, nsteps, sample):
+    """Shader clock and package power while the timed step runs, OUTSIDE the timed region:
+    `nsteps` more steps are enqueued and the sensors read until they are done (the first 40 %
+    skipped: the power figure is an average). Every rank runs the steps (they hold the
+    collective); `sample` says whether this rank reads the sensors. Why it is in the line: the
+    float64 step runs the chip into its package power cap and the shader clock comes down to
+    ~1.7 GHz (profiles/r03_power_probe.jsonl) -- the step time follows
+    that clock, and it differs from device to device."""
+    hw = device_sensors(torch) if sample else None
+    done = torch.cuda.Event()
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        step()
+    done.record()
+    if hw is None:
+        done.synchronize()
+        return None
+
+    def read(name):
+        try:
+            with open(os.path.join(hw, name)) as f:
+                return float(f.read().split()[0])
+        except (OSError, ValueError, IndexError):
+            return None
+    first = None
+    clocks, watts = [], []
+    while not done.query():
+        if first is None:
+            first = time.perf_counter()
+        c, w = read('freq1_input'), read('power1_input')
+        if c is not None and w is not None:
+            clocks.append((time.perf_counter() - t0, c * 1e-6, w * 1e-6))
+        time.sleep(0.02)
+    total = time.perf_counter() - t0
+    kept = [x for x in clocks if x[0] >= 0.4 * total]
+    if not kept:
+        return None
+    cap = read('power1_cap')
+    return {'sclk_mhz': sum(x[1] for x in kept) / len(kept), 'sclk_mhz_min': min(x[1] for x in kept),
+            'sclk_mhz_max': max(x[1] for x in kept), 'power_w': sum(x[2] for x in kept) / len(kept),
+            'power_cap_w': cap * 1e-6 if cap else None, 'samples': len(kept), 'seconds': total,
+            'source': hw,
+            'note': 'hwmon sensors of this device read while %d more steps run behind the timed region; '
+                    'a float64 step at the power cap runs at the clock the cap leaves' % nsteps}
+
+
 def pmc_traffic(pixels_per_launch, dtype, layout):
     """(HBM bytes per launch, source file) of the dominant kernel from the committed
     rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected separately, see the
@@ -317,6 +383,8 @@ def main():
     ap.add_argument('--plain', action='store_true',
                     help='N > 1: time the plain-array layout as well (default: N = 1 only -- its set-up tries '
                          'seven slab spacings of up to 12 GiB of slack per rank, which a scaling run has no use for)')
+    ap.add_argument('--no-sensors', action='store_true',
+                    help="skip the 2 s of extra steps behind the timed region during which the device's clock and power are read")
     ap.add_argument('--no-configs', action='store_true',
                     help='skip the other BASELINE.json configurations (1200x1200 tile, series, float32)')
     ap.add_argument('--cpu-workers', type=int, default=16)
@@ -456,6 +524,11 @@ def main():
     kernel_ms_min = min(step_ms)
     achieved = bpp * n / (kernel_ms * 1e-3) / 1e9
     torch.cuda.synchronize()
+    # clock and power under this load (same count of extra steps on every rank: `elapsed` is the maximum over them)
+    under_load = None
+    if not args.no_sensors:
+        under_load = device_under_load(torch, step, max(20, int(2.0 / max(elapsed / args.steps, 1e-4))), rank == 0)
+        fence()
     # load balance: every rank's kernel time (its band is 1/N of the grid)
     rank_kernel_ms = [kernel_ms]
     if world > 1:
@@ -606,6 +679,7 @@ def main():
                 'kernel_pixels_per_s': n / (kernel_ms * 1e-3),
                 'measured_copy_GBps': copy_gbps,
                 'frac_of_measured_copy': achieved / copy_gbps if copy_gbps else None,
+                'device_under_load': under_load,
                 'plain_arrays': plain,
             },
             'cpu_baseline': cpu,

@@ -323,8 +323,12 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char* const ws = stage + wave * kSlot;
-    const int64_t nvec = a.n / V;
-    const int64_t npiece = (nvec + 63) / 64;
+    const int64_t nvec_s = a.n / V;
+    const int64_t npiece = (nvec_s + 63) / 64;
+    // (the loop compares it with a per-lane index twice per iteration: in a vector register
+    // pair it is an operand; as a scalar pair hipcc spills it and reads it back lane by lane)
+    int64_t nvec = nvec_s;
+    asm("" : "+v"(nvec));
     const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
     const int rs = a.run_shift, rl = 1 << rs;
     int64_t cbase = ((int64_t)blockIdx.x * (kBlock / 64) + wave) << rs;
@@ -348,7 +352,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     };
     const unsigned lane_elem = (unsigned)lane * (unsigned)V;
     auto advance = [&](int64_t& cb, int& r) {
-        if (++r == rl) { r = 0; cb = next_base; }
+        if (((++r) >> rs) != 0) { r = 0; cb = next_base; }
     };
     int64_t v = vec_of(cbase, run);
     double dsum_d = 0, dsum_n = 0, dmax_d = -__builtin_huge_val(), dmax_n = -__builtin_huge_val();
@@ -360,9 +364,13 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         return d;
     };
 
-    unsigned long long flags = 0;      // pieces of the current run (static schedule: of this wave) with a flagged pixel
+    // pieces of the current run (static schedule: of this wave) with a flagged pixel. Wave-uniform,
+    // but kept in a VECTOR register pair (the asm hides the uniformity): it is written in a cold
+    // branch and read at a flush only -- no reason to hold a scalar pair across the loop body,
+    // where scalar registers are what hipcc runs out of
+    unsigned long long flags = 0;
+    asm volatile("" : "+v"(flags));
     int iters = 0;                     // iterations this wave has done
-    const int64_t first_cbase = cbase;
     // the 8 fields of a diagnostics partial, one per lane (lane k < 8: field k), from the
     // accumulators, which are reset: butterfly sums in a fixed order; field kFlagField = `flags`
     auto diag_fields = [&]() -> double {
@@ -390,11 +398,16 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     };
     struct Ptrs { const char* w[NW]; const char* b[NB]; };
     // scalar loads from the kernel-argument segment, ahead of the wait for the DMA
+    typedef const __attribute__((address_space(4))) char* kptr_t;
     auto load_ptrs = [&](Ptrs& p) {
-        typedef const __attribute__((address_space(4))) char* kptr_t;
         kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ka));
-        if constexpr (!PITCHED) {
+        if constexpr (PITCHED) {
+            p.w[0] = *reinterpret_cast<const char* const __attribute__((address_space(4)))*>(ka);
+            p.w[1] = reinterpret_cast<const char*>(
+                *reinterpret_cast<const int64_t __attribute__((address_space(4)))*>(
+                    ka + __builtin_offsetof(StreamArgs<T>, wide_pitch)) * (int64_t)sizeof(T));
+        } else {
 #pragma unroll
             for (int k = 0; k < NW; ++k)
                 p.w[k] = *reinterpret_cast<const char* const __attribute__((address_space(4)))*>(ka + 8 * k);
@@ -411,9 +424,10 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         const int64_t first_b = of.w * (int64_t)sizeof(T);
         const int64_t first = of.b;
         if constexpr (PITCHED) {
-            int64_t pitch_b = a.wide_pitch * (int64_t)sizeof(T);
-            asm volatile("" : "+s"(pitch_b));     // opaque: keeps 14 addresses from being hoisted
-            const char* pk = reinterpret_cast<const char*>(a.wide[0]) + first_b;
+            // (base and pitch: read again in this iteration, load_ptrs -- which also keeps
+            // the 14 addresses from being hoisted)
+            const int64_t pitch_b = (int64_t)(uintptr_t)p.w[1];
+            const char* pk = p.w[0] + first_b;
 #pragma unroll
             for (int k = 0; k < NW; ++k) {
                 __builtin_amdgcn_global_load_lds((gptr_t)(pk + lb), (lptr_t)(uintptr_t)(wl + k * 1024),
@@ -694,11 +708,25 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         run = run_n;
         v = vn;
     }
+    // What runs behind the loop reads the kernel arguments again (through a pointer the compiler
+    // cannot see through): the pointers redo_piece needs would otherwise be live -- in scalar
+    // registers, i.e. spilled to vector-register lanes -- all through the loop, and the loop's own
+    // scalars with them (float64 totals instance: 45 -> 21 v_readlane_b32 per iteration, raw
+    // drivers 76 -> 52; 0.7-0.9 % on the raw-driver and mixed instances, nothing on the float64
+    // totals instance, whose time follows the package power -- DESIGN.md section 6)
+    StreamArgs<T> late;
+    {
+        typedef const __attribute__((address_space(4))) char* kptr_t;
+        kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        __builtin_memcpy(&late, (const void*)ka, sizeof(late));
+    }
     // -- static schedule (small rasters): the wave's flagged pieces again in the reference's
     // operation order, then its one partial. Iteration i of wave w was piece
     // ((w + (i >> rs) nwaves) << rs) + (i & (rl - 1)); the last flag bit stands for every
     // iteration from there on.
-    if (a.static_sched) {
+    if (late.static_sched) {
+        const int64_t first_cbase = ((int64_t)blockIdx.x * (kBlock / 64) + wave) << rs;
         // ONE partial per BLOCK: the block's four waves add theirs up in LDS (fixed order:
         // wave 0 + wave 1 + ...), so the block that sums the partials of the whole launch
         // afterwards reads a quarter of them -- one round trip to memory instead of two on
@@ -706,7 +734,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         __shared__ double wave_part[kBlock / 64][kDiag];
         double f = lane < 6 ? 0.0 : -__builtin_huge_val();        // a wave without work adds nothing
         if (first_cbase < npiece) {
-            const unsigned long long mine = flags;     // (diag_fields() stores and clears them)
+            const unsigned long long mine = (unsigned long long)uniform64((int64_t)flags);     // (diag_fields() stores and clears them)
             f = diag_fields();
             if (__builtin_expect(mine != 0ull, 0)) {
                 RedoAcc acc;
@@ -730,7 +758,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                 const double o = wave_part[w][lane];
                 g = lane < 6 ? g + o : (o > g ? o : g);
             }
-            __hip_atomic_store(a.diag_partial + (int64_t)blockIdx.x * kDiag + lane, g,
+            __hip_atomic_store(late.diag_partial + (int64_t)blockIdx.x * kDiag + lane, g,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -744,25 +772,25 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     // measured 19 us on a 1200 x 1200 raster -- more than the two dispatches it replaces.
     // (MOD16_NO_FUSED_FINAL: compiled out, for instruction counts of the loop -- tools/isa_count.py)
 #ifndef MOD16_NO_FUSED_FINAL
-    if (a.diag_out) {
+    if (late.diag_out) {
         __shared__ int last_block;
         __shared__ double fin[kBlock / 64][kDiag];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0)
-            last_block = __hip_atomic_fetch_add(a.done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+            last_block = __hip_atomic_fetch_add(late.done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
         __syncthreads();
         if (last_block) {
             double acc[kDiag] = {0, 0, 0, 0, 0, 0, -__builtin_huge_val(), -__builtin_huge_val()};
             // four partials in flight per thread
-            for (int64_t b0 = threadIdx.x; b0 < a.nruns; b0 += 4 * kBlock) {
+            for (int64_t b0 = threadIdx.x; b0 < late.nruns; b0 += 4 * kBlock) {
                 double o[4][kDiag];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int64_t b = b0 + j * kBlock;
 #pragma unroll
                     for (int k = 0; k < kDiag; ++k)
-                        o[j][k] = b < a.nruns ? __hip_atomic_load(a.diag_partial + b * kDiag + k, __ATOMIC_RELAXED,
+                        o[j][k] = b < late.nruns ? __hip_atomic_load(late.diag_partial + b * kDiag + k, __ATOMIC_RELAXED,
                                                                   __HIP_MEMORY_SCOPE_AGENT)
                                               : (k < 6 ? 0.0 : -__builtin_huge_val());
                 }
@@ -785,15 +813,15 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                     for (int k = 0; k < kDiag; ++k) o[k] = fin[w][k];
                     diag_merge(acc, o);
                 }
-                a.diag_out[0] = acc[0];
-                a.diag_out[1] = acc[1];
-                a.diag_out[2] = (double)a.n - acc[4];
-                a.diag_out[3] = (double)a.n - acc[5];
-                a.diag_out[4] = acc[4];
-                a.diag_out[5] = acc[5];
-                a.diag_out[6] = acc[6];
-                a.diag_out[7] = acc[7];
-                __hip_atomic_store(a.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                late.diag_out[0] = acc[0];
+                late.diag_out[1] = acc[1];
+                late.diag_out[2] = (double)late.n - acc[4];
+                late.diag_out[3] = (double)late.n - acc[5];
+                late.diag_out[4] = acc[4];
+                late.diag_out[5] = acc[5];
+                late.diag_out[6] = acc[6];
+                late.diag_out[7] = acc[7];
+                __hip_atomic_store(late.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
