@@ -63,6 +63,56 @@ __global__ void __launch_bounds__(256) k_copy(const f4* __restrict__ src, f4* __
             __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
+// variants of the stream: cache policy, read only / write only, and the production kernel's
+// path (LDS-DMA into the wave's slot, ds_read_b128, store) -- what does a byte cost on each?
+__global__ void __launch_bounds__(256) k_copy_plain(const f4* __restrict__ src, f4* __restrict__ dst, long n, int reps) {
+    for (int r = 0; r < reps; ++r)
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) k_read_nt(const f4* __restrict__ src, f4* __restrict__ dst, long n, int reps) {
+    f4 acc = {0, 0, 0, 0};
+    for (int r = 0; r < reps; ++r)
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+            acc += __builtin_nontemporal_load(src + i);
+    if (acc.x == 1.2345f) dst[threadIdx.x] = acc;
+}
+__global__ void __launch_bounds__(256) k_write_nt(const f4* __restrict__ src, f4* __restrict__ dst, long n, int reps) {
+    const f4 v = {1.f, 2.f, 3.f, (float)threadIdx.x};
+    for (int r = 0; r < reps; ++r)
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+            __builtin_nontemporal_store(v, dst + i);
+}
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+template <bool DMA>
+__global__ void __launch_bounds__(256) k_copy_8(const f4* __restrict__ src, f4* __restrict__ dst, long n, int reps) {
+    // a wave moves 8 KB per turn: 8 x (64 lanes x 16 B), like the 14 + 2 of the production kernel
+    __shared__ __attribute__((aligned(16))) char stage[4 * 8192];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* ws = stage + wave * 8192;
+    const long nchunk = n / 512;                      // chunks of 8 KB
+    const long nw = (long)gridDim.x * 4;
+    for (int r = 0; r < reps; ++r)
+        for (long c = blockIdx.x * 4L + wave; c < nchunk; c += nw) {
+            const f4* s0 = src + c * 512 + lane;
+            f4 v[8];
+            if constexpr (DMA) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(s0 + k * 64), (lptr_t)(ws + k * 1024), 16, 0, 2);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f4*>(ws + k * 1024 + lane * 16);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(s0 + k * 64);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(v[k], dst + c * 512 + k * 64 + lane);
+        }
+}
+
 static double g_seconds = 1.2;
 struct Sampler {
     std::string power, freq;
@@ -144,19 +194,33 @@ int main(int argc, char** argv) {
     RUN(s_nop); RUN(s_mov); RUN(mov_b32); RUN(add_u32); RUN(cndmask); RUN(min3_u32); RUN(lshl_add_u32); RUN(max3_f32);
     RUN(readlane); RUN(fma_f32); RUN(pk_fma_f32); RUN(cmp_f64); RUN(max_f64); RUN(add_f64); RUN(mul_f64); RUN(fma_f64);
     RUN(rcp_f64); if (!only || strstr(only, "mix_f64")) bench("mix_f64", k_mix_f64, out, smp, 8);
-    {   // streaming copy, 2 x 4 GiB
+    {   // streaming variants, 2 x 4 GiB
         const long n = (4L << 30) / 16;
         f4 *a, *b; hipMalloc(&a, n * 16); hipMalloc(&b, n * 16);
         hipMemset(a, 1, n * 16); hipMemset(b, 0, n * 16);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        hipLaunchKernelGGL(k_copy, dim3(4096), dim3(256), 0, 0, a, b, n, 1); hipDeviceSynchronize();
-        smp.start();
-        hipEventRecord(e0); hipLaunchKernelGGL(k_copy, dim3(4096), dim3(256), 0, 0, a, b, n, (int)(700 * g_seconds)); hipEventRecord(e1);
-        hipEventSynchronize(e1);
-        smp.stop();
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("{\"kernel\": \"copy\", \"ms\": %.1f, \"sclk_mhz\": %.0f, \"power_w\": %.0f, \"GBps\": %.0f, \"samples\": %zu}\n",
-               ms, Sampler::mean(smp.fq), Sampler::mean(smp.pw), (double)(int)(700 * g_seconds) * 2 * n * 16 / (ms * 1e-3) * 1e-9, smp.fq.size());
+        auto stream = [&](const char* name, auto k, int blocks, double bytes_per_rep) {
+            if (only && !strstr(only, name)) return;
+            hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, a, b, n, 2); hipDeviceSynchronize();
+            hipEventRecord(e0); hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, a, b, n, 20); hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            const int reps = (int)(20 * g_seconds * 1000.0 / ms) + 1;
+            smp.start();
+            hipEventRecord(e0); hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, a, b, n, reps); hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            smp.stop();
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("{\"kernel\": \"%s\", \"ms\": %.1f, \"sclk_mhz\": %.0f, \"power_w\": %.0f, \"GBps\": %.0f, \"samples\": %zu}\n",
+                   name, ms, Sampler::mean(smp.fq), Sampler::mean(smp.pw), reps * bytes_per_rep / (ms * 1e-3) * 1e-9, smp.fq.size());
+            fflush(stdout);
+        };
+        stream("copy_nt", k_copy, 4096, 2.0 * n * 16);
+        stream("copy_plain", k_copy_plain, 4096, 2.0 * n * 16);
+        stream("read_nt", k_read_nt, 4096, 1.0 * n * 16);
+        stream("write_nt", k_write_nt, 4096, 1.0 * n * 16);
+        stream("copy8_direct", k_copy_8<false>, 512, 2.0 * n * 16);
+        stream("copy8_ldsdma", k_copy_8<true>, 512, 2.0 * n * 16);
     }
     return 0;
 }
