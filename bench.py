@@ -44,6 +44,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -249,14 +250,6 @@ def device_under_load(torch, step, nsteps, sample):
     ~1.7 GHz (profiles/r03_power_probe.jsonl) -- the step time follows
     that clock, and it differs from device to device."""
     hw = device_sensors(torch) if sample else None
-    done = torch.cuda.Event()
-    t0 = time.perf_counter()
-    for _ in range(nsteps):
-        step()
-    done.record()
-    if hw is None:
-        done.synchronize()
-        return None
 
     def read(name):
         try:
@@ -264,15 +257,25 @@ def device_under_load(torch, step, nsteps, sample):
                 return float(f.read().split()[0])
         except (OSError, ValueError, IndexError):
             return None
-    first = None
-    clocks, watts = [], []
-    while not done.query():
-        if first is None:
-            first = time.perf_counter()
-        c, w = read('freq1_input'), read('power1_input')
-        if c is not None and w is not None:
-            clocks.append((time.perf_counter() - t0, c * 1e-6, w * 1e-6))
-        time.sleep(0.02)
+    clocks, stop = [], threading.Event()
+    t0 = time.perf_counter()
+
+    def watch():        # a thread: with N > 1 a step may block in its collective
+        while not stop.is_set():
+            c, w = read('freq1_input'), read('power1_input')
+            if c is not None and w is not None:
+                clocks.append((time.perf_counter() - t0, c * 1e-6, w * 1e-6))
+            time.sleep(0.02)
+    watcher = threading.Thread(target=watch, daemon=True) if hw is not None else None
+    if watcher is not None:
+        watcher.start()
+    for _ in range(nsteps):
+        step()
+    torch.cuda.synchronize()
+    stop.set()
+    if watcher is None:
+        return None
+    watcher.join()
     total = time.perf_counter() - t0
     kept = [x for x in clocks if x[0] >= 0.4 * total]
     if not kept:
@@ -894,7 +897,7 @@ def forms_config(torch, np, _lib, RasterEngine, table, bplut, dtype, math, rows)
     lo = (n // 2) // 8192 * 8192
     hi = lo + 320000
     mixed = math == _lib.MATH_MIXED
-    rtol = 1e-3 if mixed else (1e-8 if dtype == 'float64' else 1e-6)
+    rtol = None if mixed else (1e-8 if dtype == 'float64' else 1e-6)
     cases = [('potential_et', _lib.FORM_PET, 14 * esz + 1 + 4 * esz),
              ('components', _lib.FORM_COMPONENTS, 14 * esz + 1 + 6 * esz),
              ('totals_and_components', _lib.FORM_TOTALS_COMPONENTS, 14 * esz + 1 + 8 * esz),
@@ -902,7 +905,9 @@ def forms_config(torch, np, _lib, RasterEngine, table, bplut, dtype, math, rows)
              ('raw_drivers_total8', _lib.FORM_RAW_TOTAL8_HOURS, 15 * esz + 3 + 3 * esz)]
     out = {'pixels': n, 'layout': 'tiled', 'parity_rtol': rtol,
            'parity_note': 'largest relative error against the numpy oracle on 320 k pixels; masks = NaN and '
-                          'exact-zero masks identical' + (' (float32 subnormals count as zero)' if mixed else '')}
+                          'exact-zero masks identical' + (' (float32 subnormals count as zero); the mixed form is held to an '
+                                                          'absolute bound, 1e-6 of the largest value, and the share of values '
+                                                          'off by more than 1e-5 relative is reported' if mixed else '')}
 
     def f64(ts):
         return [t.cpu().numpy().astype(np.float64) for t in ts]
@@ -943,6 +948,7 @@ def forms_config(torch, np, _lib, RasterEngine, table, bplut, dtype, math, rows)
                 else:
                     want = list(tot) + list(sep[0]) + list(sep[1])
         worst, masks = 0.0, True
+        worst_abs, n_gt, n_all = 0.0, 0, 0
         tiny = float(np.finfo(np.float32).tiny)
         for o, w in zip(r.outs, want):
             got = r.flat(o, lo, hi).cpu().numpy().astype(np.float64)
@@ -953,12 +959,19 @@ def forms_config(torch, np, _lib, RasterEngine, table, bplut, dtype, math, rows)
             masks = masks and bool(np.array_equal(np.isnan(got), np.isnan(w)) and np.array_equal(got == 0, w == 0))
             ok = np.isfinite(w) & (w != 0)
             err = np.abs(got[ok] - w[ok])
-            if mixed:       # the mixed form bounds the absolute error
-                err = np.where(err <= 1e-6 * np.abs(w[ok]).max(), 0, err)
-            worst = max(worst, float(np.max(err / np.abs(w[ok]))))
+            rel = err / np.abs(w[ok])
+            worst = max(worst, float(np.max(rel)))
+            worst_abs = max(worst_abs, float(np.max(err) / np.abs(w[ok]).max()))
+            n_gt += int(np.count_nonzero(rel > 1e-5))
+            n_all += int(rel.size)
+        parity = {'max_rel_err_vs_oracle': worst, 'masks_equal': masks}
+        if mixed:       # the mixed form bounds the ABSOLUTE error: a tolerance check
+            parity.update({'max_abs_err_over_max_value': worst_abs, 'within_abs_bound_1e-6': worst_abs <= 1e-6,
+                           'fraction_rel_err_gt_1e-5': n_gt / max(n_all, 1)})
+        else:
+            parity['within_rtol'] = worst <= rtol
         out[name] = {'ms': ms, 'bytes_per_pixel': bpp, 'GBps': bpp * n / ms / 1e6,
-                     'frac': bpp * n / ms / 1e6 / HBM_PEAK_GBPS,
-                     'parity': {'max_rel_err_vs_oracle': worst, 'masks_equal': masks, 'within_rtol': worst <= rtol}}
+                     'frac': bpp * n / ms / 1e6 / HBM_PEAK_GBPS, 'parity': parity}
         del r
         torch.cuda.empty_cache()
     return out
