@@ -233,7 +233,7 @@ def device_sensors(torch):
         if hip.hipDeviceGetPCIBusId(buf, 64, torch.cuda.current_device()) != 0:
             return None
         bus = buf.value.decode().lower()
-    except (OSError, AttributeError):
+    except (OSError, AttributeError, RuntimeError):       # no HIP runtime / no device: no sensors
         return None
     for path in glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*/power1_input'):
         if bus in os.path.realpath(path.split('/hwmon')[0]).lower():

@@ -118,3 +118,13 @@ def test_bench_failing_rank_fails_the_parent():
                            '--no-cpu-baseline'], env=env, cwd=ROOT, capture_output=True,
                           text=True, timeout=300)
     assert proc.returncode != 0
+
+
+def test_bench_sensors_are_optional():
+    """The clock / power leg of the bench line reads hwmon files of the process's own card; a
+    box without a device (this one) or without the files gets None, not an exception."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import torch
+    if not torch.cuda.is_available():
+        assert bench.device_sensors(torch) is None
