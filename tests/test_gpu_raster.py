@@ -813,3 +813,29 @@ def test_flat_always_copies(env):
     was = inside.clone(), across.clone()
     r.drivers[5].fill_(-1.0)
     assert torch.equal(inside, was[0]) and torch.equal(across, was[1])
+
+
+def test_bench_reads_the_sensors_of_its_own_device(env):
+    """The bench line's clock / power figures come from the hwmon files of the card the process
+    computes on (a box shows all the cards of its host): found by PCI address, plausible while a
+    kernel runs. No such files on a box (a different kernel driver layout): nothing to check."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table)
+    hw = bench.device_sensors(torch)
+    if hw is None:
+        pytest.skip('no hwmon sensors for this device on this box')
+    cap = float(open(os.path.join(hw, 'power1_cap')).read()) * 1e-6
+    assert 100 < cap < 5000
+    n = 1 << 24
+    ras = eng.synth_tiled(eng.alloc_tiled(n), seed=3)
+    diag = torch.zeros(8, dtype=torch.float64, device='cuda')
+    step = eng.bind_tiled(ras, diag)
+    res = bench.device_under_load(torch, step, 600, True)      # ~0.25 s of launches
+    assert res is not None and res['samples'] >= 1
+    assert 90 <= res['sclk_mhz'] <= 3000 and 0 < res['power_w'] <= 1.2 * cap
+    assert res['power_cap_w'] == cap
