@@ -75,6 +75,18 @@ template <> struct FastMath<double> {
         return __builtin_fma(r, e, r);
     }
 
+    // (measurement builds only, -DMOD16_EXPERIMENT_SEED_RCP: the reciprocals of the three
+    // Penman-Monteith quotients without their Newton step -- how the step time answers to
+    // 12 float64 fma fewer per pixel; DESIGN.md section 6. Not the product: the step also makes
+    // 1/0 and 1/inf NaN, as the reference's 0/0 and inf/inf are.)
+    static __device__ __forceinline__ T rcp_quotient(T x) {
+#ifdef MOD16_EXPERIMENT_SEED_RCP
+        return __builtin_amdgcn_rcp(x);
+#else
+        return rcp(x);
+#endif
+    }
+
     // x^(-7/4) for the r_corr term (mod16/__init__.py:771). Seed y = x^(-1/4)
     // from v_rsq_f64 + v_sqrt_f64 (relative error <= 5.3e-8, measured seeds
     // 2^-24.2 and 2^-25.3), one Newton step on y^-4 = x (error 2.5 e^2 = 7e-15),

@@ -627,7 +627,7 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
         T g_a = __builtin_fma(sh.glsh_l, fw, g_rr);                // g_h + 1/r_r
         T numer = fw * __builtin_fma(rcfv * x.fpar, g_a, s * (x.fpar * rad_net));
         T den = __builtin_fma(slhv, g_e, sh.k_p * g_a);
-        T evap = (numer * g_e) * M::rcp(den);
+        T evap = (numer * g_e) * M::rcp_quotient(den);
         // numer < 0 -> 0 (:959), then fw <= tiny or lai <= tiny -> 0 (:961): one select
         canopy = ((numer < T(0)) | dry | sh.lai_tiny) ? T(0) : evap;
     }
@@ -640,7 +640,7 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
         T w = __builtin_fma(r_tot, g_rr, T(1));                    // r_tot / r_as
         T num = __builtin_fma((s * rad_soil), r_tot, (rcfv * sh.omf) * w);
         T den = r_tot * __builtin_fma(sh.k_p, w, slhv);
-        T q = num * M::rcp(den);                                   // numer/denom/lhv
+        T q = num * M::rcp_quotient(den);                                   // numer/denom/lhv
         T pw = M::pow01_tab(rh, vpd * p.inv_beta, tb);             // :861
         // sat = q fwet and unsat = q (1 - fwet) with 0 <= fwet <= 1: both
         // clamps of :858-861 fire exactly when q < 0 (NaN falls through)
@@ -677,7 +677,7 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
         rad_c = (rad_c < T(0)) ? T(0) : rad_c;                     // :1251
         T num = (omw * __builtin_fma(rcfv * x.fpar, g_d, s * rad_c)) * p1;
         T den = __builtin_fma(slhv, p1, sh.k_p * __builtin_fma(g_d, s1, p1));
-        T tr = num * M::rcp(den);
+        T tr = num * M::rcp_quotient(den);
         trans = shut ? T(0) : tr;
     }
 }
