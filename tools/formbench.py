@@ -60,9 +60,15 @@ def main():
     nw, nb, no = _lib.FORM_SHAPE[form]
     bpp = nw * esz + nb + no * esz
     ms = e0.elapsed_time(e1) / launches
-    print(json.dumps({'form': sys.argv[1], 'dtype': dtype, 'math': 'mixed' if math == _lib.MATH_MIXED else 'fast',
-                      'pixels': n, 'bytes_per_pixel': bpp, 'ms': round(ms, 3),
-                      'GBps': round(bpp * n / ms / 1e6, 1), 'frac_8TBs': round(bpp * n / ms / 1e6 / 8000, 4)}))
+    line = {'form': sys.argv[1], 'dtype': dtype, 'math': 'mixed' if math == _lib.MATH_MIXED else 'fast',
+            'pixels': n, 'bytes_per_pixel': bpp, 'ms': round(ms, 3),
+            'GBps': round(bpp * n / ms / 1e6, 1), 'frac_8TBs': round(bpp * n / ms / 1e6 / 8000, 4)}
+    if os.environ.get('FORMBENCH_SENSORS') == '1':      # shader clock and package power under this form (bench.py's reader)
+        import bench
+        u = bench.device_under_load(torch, lambda: eng.run_form_tiled(r, day_hours=hours), max(20, int(2000 / ms)), True)
+        if u:
+            line.update(sclk_mhz=round(u['sclk_mhz']), power_w=round(u['power_w'], 1), power_cap_w=u['power_cap_w'])
+    print(json.dumps(line))
 
 
 if __name__ == '__main__':
