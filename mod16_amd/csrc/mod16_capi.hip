@@ -54,6 +54,7 @@ struct mod16_ctx {
     bool use_dma = true;             // production pipeline (mod16_stream.hpp); MOD16_NO_DMA=1: plain kernels only
     int host_threads = 8;            // MOD16_HOST_THREADS: staging threads of the HOST mode (1..kSlots)
     int run_shift = -1;              // MOD16_RUN_SHIFT: force 2^k pieces per run (experiments)
+    int stream_blocks = 2;           // MOD16_STREAM_BLOCKS: blocks of the pipeline kernel per CU (measurements: 1 = one wave per SIMD)
     int static_below = 8;            // MOD16_STATIC_BELOW: runs per wave below which runs are dealt out statically (0: never)
     int use_pitch = 1;               // scalar base + pitch addressing for slab layouts (MOD16_PITCH=0: off)
     unsigned long long* dyn_counters = nullptr;   // ring of ticket counters, 128 B apart
@@ -185,6 +186,7 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
         if (const char* g = getenv("MOD16_HOST_THREADS")) ctx->host_threads = std::max(1, std::min(kSlots, atoi(g)));
         if (const char* g = getenv("MOD16_RUN_SHIFT")) ctx->run_shift = std::max(1, std::min(6, atoi(g)));
         if (const char* g = getenv("MOD16_STATIC_BELOW")) ctx->static_below = std::max(0, std::min(64, atoi(g)));
+        if (const char* g = getenv("MOD16_STREAM_BLOCKS")) ctx->stream_blocks = std::max(1, std::min(2, atoi(g)));
         HIPCHK(ctx, hipMalloc(&ctx->dyn_counters, 64 * 128));
         const size_t nlut = MOD16_LUT_ROWS * kLutCols;
         HIPCHK(ctx, hipMalloc(&ctx->lut64, nlut * sizeof(double)));
@@ -423,7 +425,7 @@ static StreamGeom stream_geom(const mod16_ctx* ctx, int64_t n, int V, int tile_s
     g.nruns = (g.npiece + (int64_t(1) << run_shift) - 1) >> run_shift;
     // persistent waves: 2 blocks per CU is what the LDS slots allow
     g.grid = (int)std::max<int64_t>(1, std::min<int64_t>(
-        (g.nruns + (kBlock / 64) - 1) / (kBlock / 64), (int64_t)ctx->cus * 2));
+        (g.nruns + (kBlock / 64) - 1) / (kBlock / 64), (int64_t)ctx->cus * ctx->stream_blocks));
     return g;
 }
 constexpr int kStage = 1024;     // slices of the two-level sum of the per-run partials
