@@ -184,12 +184,14 @@ def test_flagged_pixels_in_the_other_forms_at_size(env, dtype):
 
 
 @pytest.mark.parametrize('switches', [{'MOD16_STATIC_BELOW': '0'}, {'MOD16_STATIC_BELOW': '0', 'MOD16_RUN_SHIFT': '6'},
-                                      {'MOD16_RUN_SHIFT': '6'}, {'MOD16_STATIC_BELOW': '64'}])
+                                      {'MOD16_RUN_SHIFT': '6'}, {'MOD16_STATIC_BELOW': '64'},
+                                      {'MOD16_STREAM_BLOCKS': '1'}, {'MOD16_STREAM_BLOCKS': '1', 'MOD16_STATIC_BELOW': '64'}])
 def test_flags_under_other_schedules(env, switches):
     """The flag record under the schedules the experiment switches select: a small raster on the
     DYNAMIC schedule (et_stream_redo_kernel on few runs), runs of 64 pieces (more pieces per run than
     the 52 flag bits: the last bit stands for the rest), the static schedule on a larger raster (more
-    than 52 iterations per wave likewise). Same outputs and diagnostics as the default context."""
+    than 52 iterations per wave likewise), half the waves (one block per CU: twice the iterations per
+    wave). Same outputs and diagnostics as the default context."""
     import os
     torch, RasterEngine, table, _lib = env
     n = 3_000_000 if switches.get('MOD16_STATIC_BELOW') != '64' else 20_000_000
