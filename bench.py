@@ -228,7 +228,10 @@ def device_sensors(torch):
     import ctypes
     import glob
     try:
-        hip = ctypes.CDLL('libamdhip64.so')
+        # the HIP runtime this process already uses (PyTorch-ROCm wheels bundle their own copy:
+        # a second runtime in the process could not open the GPU)
+        own = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+        hip = ctypes.CDLL(own if os.path.exists(own) else 'libamdhip64.so')
         buf = ctypes.create_string_buffer(64)
         if hip.hipDeviceGetPCIBusId(buf, 64, torch.cuda.current_device()) != 0:
             return None
