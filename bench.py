@@ -686,6 +686,10 @@ def main():
                 'measured_copy_GBps': copy_gbps,
                 'frac_of_measured_copy': achieved / copy_gbps if copy_gbps else None,
                 'device_under_load': under_load,
+                'limited_by': ('package power cap: %.0f of %.0f W while the step runs, shader clock %.0f MHz'
+                               % (under_load['power_w'], under_load['power_cap_w'], under_load['sclk_mhz'])
+                               if under_load and under_load.get('power_cap_w')
+                               and under_load['power_w'] >= 0.97 * under_load['power_cap_w'] else None),
                 'plain_arrays': plain,
             },
             'cpu_baseline': cpu,
