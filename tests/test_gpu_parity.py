@@ -12,7 +12,7 @@ import pytest
 
 from oracle import mod16_oracle as oracle
 from oracle import synth
-from parity import assert_mixed_parity, assert_parity, rel_err
+from parity import assert_mixed_parity, assert_parity
 
 pytestmark = pytest.mark.gpu
 
