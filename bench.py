@@ -6,11 +6,16 @@ achieved HBM GB/s on the 43200 x 21600 global ET grid, float64).
     python bench.py --gpus N --steps K --warmup W
 
 With N > 1 and no torch.distributed environment the command starts its own
-ranks: the parent -- which never touches a GPU -- runs
-`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
-127.0.0.1 --master-port P bench.py ...` as a child process, relays rank 0's JSON
-line and exits with the child's return code. Launched under
-torch.distributed.run directly (RANK / WORLD_SIZE set) it is one of the ranks.
+ranks: the parent -- which never touches a GPU -- starts the N ranks directly as
+child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
+MASTER_PORT in their environment; not through torch.distributed.run, whose
+elastic agent holds the GPU open as one process more), relays rank 0's JSON
+line and returns non-zero if any rank failed. Launched under
+torch.distributed.run (RANK / WORLD_SIZE set: the driver's line) it is one of
+the ranks. MOD16_BENCH_FORCE_GROUP=1 makes a --gpus 1 run take the N > 1 code
+path unchanged -- an RCCL process group of one rank, the side stream, the event
+hand-off and the all-gather of the diagnostics vector -- so that the collective
+path runs on a one-GPU box (tests/test_a_gpu_group.py).
 
 One "step" is one pass of the hot path over the (synthetic, already
 HBM-resident) drivers of one time step: the fused ET kernel over this rank's row
@@ -52,10 +57,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md)
-PMC_TRAFFIC = [os.path.join(ROOT, 'profiles', f) for f in
-               ('r03_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic_float32.json',
-                'r02_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic_float32.json',
-                'r01j_pmc_hbm_traffic.json', 'r01i_pmc_hbm_traffic_float32.json')]
 TILE = (1200, 1200)           # BASELINE.json configs[1], the CPU sample unit
 SEED = 16
 DIAG_NAMES = ('sum_day', 'sum_night', 'n_valid_day', 'n_valid_night',
@@ -292,12 +293,18 @@ def device_under_load(torch, step, nsteps, sample):
                     'a float64 step at the power cap runs at the clock the cap leaves' % nsteps}
 
 
-def pmc_traffic(pixels_per_launch, dtype, layout):
-    """(HBM bytes per launch, source file) of the dominant kernel from the committed
-    rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected separately, see the
-    files); counters cannot be read from inside this process, so a figure applies
-    only when this run launches the same kernel on the same pixel count and layout."""
-    for path in PMC_TRAFFIC:
+def pmc_traffic(pixels_per_launch, dtype, layout, build_id, profiles_dir=None):
+    """(HBM bytes per launch, source file, note) of the dominant kernel from the committed
+    rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected separately by
+    tools/run_profiles.sh, see the files). Counters cannot be read from inside this process,
+    so a record applies only when it was measured on THIS build of the library (its
+    `build_id`, the digest of sources and flags that mod16_build_id() returns) launching the
+    same kernel on the same pixel count and layout; otherwise the figure is None and the note
+    says why -- a kernel change without fresh PMC passes never prints a stale number."""
+    import glob
+    profiles_dir = profiles_dir or os.path.join(ROOT, 'profiles')
+    shape_only = None
+    for path in sorted(glob.glob(os.path.join(profiles_dir, '*pmc_hbm_traffic*.json')), reverse=True):
         try:
             with open(path) as f:
                 rec = json.load(f)
@@ -305,8 +312,14 @@ def pmc_traffic(pixels_per_launch, dtype, layout):
             continue
         if rec.get('pixels_per_launch') == pixels_per_launch and rec.get('dtype') == dtype \
                 and rec.get('layout', 'plain') == layout:
-            return rec['traffic_bytes_per_launch'], os.path.relpath(path, ROOT)
-    return None, None
+            if rec.get('build_id') == build_id:
+                return rec['traffic_bytes_per_launch'], os.path.relpath(path, ROOT), \
+                    'PMC passes of build %s (git %s)' % (build_id, rec.get('git_commit'))
+            shape_only = shape_only or (os.path.relpath(path, ROOT), rec.get('build_id'))
+    if shape_only:
+        return None, None, ('no PMC record of this build (%s): the newest record of this shape, %s, was measured '
+                            'on build %s -- run tools/run_profiles.sh' % (build_id, shape_only[0], shape_only[1]))
+    return None, None, 'no PMC record for this pixel count / dtype / layout'
 
 
 # ------------------------------------------------------------------ the rank
@@ -398,6 +411,12 @@ def main():
     args = ap.parse_args()
 
     in_group = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+    # MOD16_BENCH_FORCE_GROUP=1: the N > 1 step (process group, side stream, collective) also
+    # for ONE rank -- this process becomes rank 0 of a group of one (it has not touched the GPU)
+    force_group = os.environ.get('MOD16_BENCH_FORCE_GROUP') == '1'
+    if force_group and not in_group and args.gpus == 1:
+        os.environ.update(rank_env({}, 0, 1, free_port()))
+        in_group = True
     if not in_group and args.gpus > 1:
         # the parent of a multi-GPU run: no torch.cuda, no mod16_amd, no GPU
         return spawn(sys.argv[1:], args.gpus)
@@ -427,7 +446,10 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    grouped = world > 1 or force_group
+    backend = None
+    if grouped:
+        backend = 'gloo' if rehearsal else 'nccl'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if rehearsal:
             dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -436,7 +458,7 @@ def main():
                                     device_id=torch.device('cuda', local_rank))
     # how many ranks the collective layer really has (RCCL for N > 1)
     seen = torch.ones(1, dtype=torch.float64, device='cpu' if rehearsal else 'cuda')
-    if world > 1:
+    if grouped:
         dist.all_reduce(seen)
     ranks_seen = int(seen.item())
 
@@ -449,7 +471,7 @@ def main():
     bpp = eng.bytes_per_pixel
 
     def fence():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -475,7 +497,7 @@ def main():
     else:
         steps_bound = [eng.bind(cls, drv, day, night, d, graph=True) for d in diags]
     main_stream = torch.cuda.current_stream()
-    comm_stream = torch.cuda.Stream() if world > 1 else None
+    comm_stream = torch.cuda.Stream() if grouped else None
     produced = [torch.cuda.Event() for _ in range(2)]
     reduced = [torch.cuda.Event() for _ in range(2)]
     counter = [0]
@@ -495,7 +517,7 @@ def main():
         produced[k].record(main_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(produced[k])
-            tiles.allreduce_diag(diags[k])
+            tiles.allreduce_diag(diags[k], engine=eng)
             reduced[k].record(comm_stream)
 
     for _ in range(args.warmup):
@@ -521,7 +543,7 @@ def main():
     elapsed = time.perf_counter() - t0
     step_ms = [a.elapsed_time(b) for a, b in ev]
     eng.check()
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -537,7 +559,7 @@ def main():
         fence()
     # load balance: every rank's kernel time (its band is 1/N of the grid)
     rank_kernel_ms = [kernel_ms]
-    if world > 1:
+    if grouped:
         kt = torch.zeros(world, dtype=torch.float64, device='cpu' if rehearsal else 'cuda')
         kt[rank] = kernel_ms
         dist.all_reduce(kt)
@@ -603,7 +625,7 @@ def main():
                     merge_compare(full, res)
             del c_cls, c_drv, rday, rnight
         full['pixels'] = int(n)
-        if world > 1:       # every rank's band counts
+        if grouped:         # every rank's band counts
             mx = torch.tensor([full['max_rel_err'], full['max_abs_err_over_max_value'],
                                -float(full['nan_masks_equal'])], dtype=torch.float64, device='cuda')
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -653,11 +675,12 @@ def main():
         configs = other_configs(args, torch, np, _lib, RasterEngine, table, bplut)
 
     if rank == 0:
-        traffic, traffic_source = pmc_traffic(n, args.dtype, args.layout)
+        traffic, traffic_source, traffic_note = pmc_traffic(n, args.dtype, args.layout, _lib.build_id())
         value = total * args.steps / elapsed
         line = {
             'metric': 'pixels/sec, fused Penman-Monteith ET forward run (day+night), 43200x21600 global grid',
             'value': value, 'unit': 'pixels/s', 'n_gpus': world, 'ranks_seen': ranks_seen,
+            'process_group': {'backend': backend, 'world_size': world, 'forced_for_one_rank': bool(force_group and world == 1)},
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64' if args.dtype == 'float64' else 'f32', 'data': 'synthetic',
@@ -676,7 +699,8 @@ def main():
                 'bound': 'hbm', 'kernel': 'et_stream_kernel<%s, %s> (LDS-DMA, dynamic runs, in-kernel diagnostics)'
                                           % (args.dtype, 'totals, mixed precision' if args.math == 'mixed' else 'totals'),
                 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
-                'traffic': traffic, 'traffic_source': traffic_source, 'traffic_unit': 'bytes per launch',
+                'traffic': traffic, 'traffic_source': traffic_source, 'traffic_note': traffic_note,
+                'traffic_unit': 'bytes per launch', 'library_build_id': _lib.build_id(),
                 'bytes_per_pixel': bpp, 'pixels_per_launch': n,
                 'kernel_ms': kernel_ms, 'kernel_ms_min': kernel_ms_min,
                 'kernel_ms_note': 'mean / min over the timed steps themselves (an event pair around each '
@@ -700,7 +724,7 @@ def main():
         if census is not None:
             line['gpu_process_census'] = census
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
     return 0
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MOD16_ABI_VERSION 2
+#define MOD16_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define MOD16_API __attribute__((visibility("default")))
@@ -85,14 +85,22 @@ enum mod16_where { MOD16_HOST = 0, MOD16_DEVICE = 1 };
  * shared per-period terms, table exp / log) and keeps every comparison of the reference:
  * within 1e-9 of the reference-order kernel, NaN and exact-zero masks identical. Its own
  * domain is finite drivers of physical sign and magnitude (NaN anywhere, zeros and the usual
- * fill values in the radiation / albedo / VPD / fPAR / LAI fields included); a pixel outside
- * it -- an infinite driver, |LAI| or |pressure| beyond 1e100, a negative pressure, a
- * temperature outside (36 K, 1332 K): the pole of the saturation formula, a negative latent
- * heat -- is detected in the kernel and computed in the reference's operation order
- * instead, so that the DEFAULT arithmetic returns what the reference returns for every
- * input, NaN / zero / inf masks included (csrc/mod16_physics.hpp "domain guard";
- * tests/test_gpu_parity.py::test_special_values_*, tests/test_gpu_guard.py,
- * tests/fuzz_domain.py). MOD16_MATH_EXACT is the reference's operation order throughout. */
+ * fill values in the radiation / albedo / VPD / fPAR / LAI fields included). A pixel outside
+ * it is detected in the kernel (csrc/mod16_physics.hpp, fast_out_of_domain) and computed in the
+ * reference's operation order instead. The test, exactly:
+ *     |A_day| = |sw_rad_day (1 - albedo) + lw_net_day|, |lw_net_night|,
+ *     |sw_rad_night (1 - albedo) + lw_net_night|, |fPAR|, |LAI|, |pressure|, |VPD day|,
+ *     |VPD night| at or above 1e50 (or infinite);  pressure below 1 Pa (zero, negative);
+ *     a day or night temperature at or outside 36 K .. 1332 K (35.85 K is the pole of the
+ *     saturation formula, from 1332.4 K the latent heat is negative).
+ * NaN operands never flag a pixel. With this the DEFAULT arithmetic returned what the
+ * reference returns on every input class tested: a ladder of 56 magnitudes in each driver,
+ * 1.2 M random pairs and a storm of independently special drivers (tests/fuzz_domain.py),
+ * signalling-NaN patterns next to an infinity (tests/test_gpu_guard.py), NaN / zero / inf
+ * masks included. The raw-driver forms test the raw fields instead: |specific humidity| < 1
+ * kg/kg, |surface pressure| < 1e50 Pa, |elevation| < 39 km (the air pressure computed from it is
+ * then above the 1 Pa bound: 1.5 Pa at 39 km), the temperatures and radiation terms as above.
+ * MOD16_MATH_EXACT is the reference's operation order throughout. */
 #define MOD16_MATH_FAST   0u  /* strength-reduced arithmetic (default)          */
 #define MOD16_MATH_EXACT  1u  /* reference operation order, IEEE divide/pow     */
 #define MOD16_MATH_MIXED  2u  /* float32 rasters: float64 where it decides a mask or
@@ -102,6 +110,13 @@ enum mod16_where { MOD16_HOST = 0, MOD16_DEVICE = 1 };
                                  |lai| < 1e5, 1e3 <= pressure < 1e7 Pa, 90 K < T < 1332 K);
                                  pixels outside it are computed in the reference's order,
                                  float64, like FAST's */
+/* The caller vouches that every driver lies inside the domain above (quality-controlled or
+ * NaN-masked rasters): the totals form of the production pipeline (dense class raster,
+ * outputs day + night; mod16_et_*, mod16_et_diag_*, mod16_et_tiled_*, their graphs) then runs
+ * the instance without the domain test and without the dispatch that revisits flagged pixels
+ * (-2.6 % kernel time on the float64 global grid, -3 % MIXED). A pixel outside the domain then
+ * gets whatever the rearranged arithmetic gives. Other forms and shapes ignore the flag. */
+#define MOD16_DOMAIN_TRUSTED 4u
 
 typedef struct mod16_ctx mod16_ctx;
 
@@ -562,6 +577,22 @@ MOD16_API int mod16_host_free(void* p);
  * best rate, (bytes read + bytes written) / time, in GB/s. Synchronous.
  */
 MOD16_API int mod16_measure_copy(mod16_ctx* ctx, int64_t bytes, int reps, float* gbps);
+
+/*
+ * Identity of this build: a hex digest of the library's sources and compiler flags, put in
+ * by mod16_amd/csrc/build.py. profiles/ records of a kernel (HBM traffic from the PMC passes)
+ * carry it, and bench.py reports such a record only for the build it was measured on.
+ */
+MOD16_API const char* mod16_build_id(void);
+
+/*
+ * The rank-order fold behind the all-gather of the diagnostics vectors: `gathered`
+ * is [world][8] float64 on the device (rank r's vector at row r), `diag` [8] receives sums and
+ * counts [0..5] added in rank order (rank 0 + rank 1 + ...: the same bits on every rank and
+ * from run to run) and the maxima [6..7]. One small kernel, asynchronous on `stream`.
+ */
+MOD16_API int mod16_fold_diag(mod16_ctx* ctx, const double* gathered, int world, double* diag,
+                              void* stream);
 
 #ifdef __cplusplus
 }

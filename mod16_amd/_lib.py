@@ -18,6 +18,7 @@ N_COMPONENTS = 6
 HOST, DEVICE = 0, 1
 BC_SCALAR, BC_DENSE, BC_ROW, BC_COL = 0, 1, 2, 3      # enum mod16_broadcast
 MATH_FAST, MATH_EXACT, MATH_MIXED = 0, 1, 2
+DOMAIN_TRUSTED = 4        # flag bit MOD16_DOMAIN_TRUSTED: or it into a math value (include/mod16_hip.h)
 # enum mod16_form: (wide arrays, byte rasters, outputs) of each form of the forward run
 (FORM_TOTALS, FORM_PET, FORM_COMPONENTS, FORM_TOTALS_COMPONENTS, FORM_RAW, FORM_RAW_TOTAL8,
  FORM_RAW_TOTAL8_HOURS) = range(7)
@@ -35,11 +36,14 @@ OK = 0
 ERR_ARG, ERR_HIP, ERR_CLASS_RANGE, ERR_NOMEM, ERR_NO_DEVICE, ERR_NO_BPLUT = \
     -1, -2, -3, -4, -5, -6
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 LIB_NAME = 'libmod16hip.so'
 # MOD16_LIB: alternative build of the same library (kernel experiments only)
 LIB_PATH = os.environ.get('MOD16_LIB') or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# the same sources built with -DMOD16_EXPERIMENTS (launch-geometry overrides read from the
+# environment at context creation): tests and tools only, see load_experiments()
+EXP_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libmod16hip_exp.so')
 
 
 class Mod16Error(RuntimeError):
@@ -175,6 +179,8 @@ PROTOTYPES = {
     'mod16_host_alloc': (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
     'mod16_host_free': (C.c_int, [C.c_void_p]),
     'mod16_measure_copy': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
+    'mod16_build_id': (C.c_char_p, []),
+    'mod16_fold_diag': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'mod16_time_et': (C.c_int, [
         C.c_void_p, C.c_int, C.c_void_p, _PP, _I64P, _PP, _I64P, C.c_int64,
         C.c_void_p, C.c_void_p, _PP, C.c_uint, C.c_void_p, C.c_int, C.c_void_p,
@@ -203,6 +209,24 @@ def _preload_torch_hip_runtime():
         C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
+def _declare(lib, tolerate_missing):
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            # an older experimental build given through MOD16_LIB (tools/kbench.py
+            # A/B runs) may predate an entry point; the in-tree library may not
+            if tolerate_missing:
+                continue
+            raise
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mod16_version() != ABI_VERSION:
+        raise ImportError('libmod16hip ABI version %d, expected %d'
+                          % (lib.mod16_version(), ABI_VERSION))
+    return lib
+
+
 def load():
     '''Load libmod16hip.so (once) and declare its prototypes.'''
     global _lib
@@ -214,23 +238,31 @@ def load():
             'g.build()"` (or mod16_amd/csrc/build.py) at the repo root. '
             'mod16_amd has no CPU fallback.' % LIB_PATH)
     _preload_torch_hip_runtime()
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in PROTOTYPES.items():
-        try:
-            fn = getattr(lib, name)
-        except AttributeError:
-            # an older experimental build given through MOD16_LIB (tools/kbench.py
-            # A/B runs) may predate an entry point; the in-tree library may not
-            if 'MOD16_LIB' in os.environ:
-                continue
-            raise
-        fn.restype = res
-        fn.argtypes = args
-    if lib.mod16_version() != ABI_VERSION:
-        raise ImportError('libmod16hip ABI version %d, expected %d'
-                          % (lib.mod16_version(), ABI_VERSION))
-    _lib = lib
-    return lib
+    _lib = _declare(C.CDLL(LIB_PATH), 'MOD16_LIB' in os.environ)
+    return _lib
+
+
+_exp_lib = None
+
+
+def load_experiments():
+    '''The experiments build of the library (``libmod16hip_exp.so``: the same sources with
+    ``-DMOD16_EXPERIMENTS``), whose contexts read the launch-geometry overrides ``MOD16_NO_DMA``,
+    ``MOD16_RUN_SHIFT``, ``MOD16_STATIC_BELOW``, ``MOD16_STREAM_BLOCKS``, ``MOD16_PITCH``,
+    ``MOD16_GRID_MULT`` from the environment when they are created. For tests and tools: the
+    product never calls this (``Context(device, experiments=True)`` is how a test asks for it).'''
+    global _exp_lib
+    if _exp_lib is None:
+        if not os.path.exists(EXP_LIB_PATH):
+            raise ImportError('%s is not built (mod16_amd/csrc/build.py builds it)' % EXP_LIB_PATH)
+        load()          # the HIP runtime both resolve to
+        _exp_lib = _declare(C.CDLL(EXP_LIB_PATH), False)
+    return _exp_lib
+
+
+def build_id():
+    '''Digest of the sources and flags the loaded library was built from (``mod16_build_id``).'''
+    return load().mod16_build_id().decode()
 
 
 def device_count():
@@ -254,8 +286,8 @@ def i64_array(vals):
 class Context:
     '''One device context (``mod16_ctx``): BPLUT, staging tiles, workspace.'''
 
-    def __init__(self, device=0):
-        self.lib = load()
+    def __init__(self, device=0, experiments=False):
+        self.lib = load_experiments() if experiments else load()
         self.handle = C.c_void_p()
         self.device = device
         rc = self.lib.mod16_create(int(device), C.byref(self.handle))
@@ -344,6 +376,13 @@ class Context:
         self.check(self.lib.mod16_check_status(self.handle, stream))
 
 
+def _host_ram_bytes():
+    try:
+        return os.sysconf('SC_PAGE_SIZE') * os.sysconf('SC_PHYS_PAGES')
+    except (ValueError, OSError, AttributeError):
+        return 0
+
+
 class _PinnedPool(object):
     '''Page-locked host blocks behind the result arrays of the numpy entry points.
 
@@ -352,71 +391,109 @@ class _PinnedPool(object):
     moves 57 GB/s, so result arrays of ``MIN_BYTES`` or more are numpy views of
     ``hipHostMalloc`` blocks. A block goes back to the pool when its array is
     garbage-collected and is handed out again for the next result of that size
-    (a time loop allocates once); the pool keeps at most ``MAX_CACHED`` bytes of
-    idle blocks and hands out at most ``MAX_LIVE`` bytes in total -- beyond that
-    ``empty`` returns plain numpy arrays. ``trim()`` frees the idle blocks.
-    Everything else about the arrays is ordinary (writeable, C-contiguous, own
-    their memory through ``.base``).'''
+    (a time loop allocates once). Two bounds: at most ``MAX_LIVE`` bytes are
+    page-locked in total (default: a quarter of the host's RAM, between 8 and 64 GiB;
+    ``MOD16_PINNED_LIVE``) -- beyond that ``empty`` returns plain numpy arrays and says
+    so once (``warnings``; ``fallbacks`` counts them) -- and idle blocks are kept up to the
+    larger of ``MAX_CACHED`` (1 GiB; ``MOD16_PINNED_CACHE``) and the sizes of the last eight
+    results handed out, so the results of one step of a time loop always find their
+    blocks again. ``trim()`` frees the idle blocks. Everything else about the arrays is
+    ordinary (writeable, C-contiguous, own their memory through ``.base``).
+
+    Locking: ``give`` runs from ``weakref.finalize``, i.e. possibly inside a garbage
+    collection triggered while ``take`` holds the lock on the same thread -- the lock is
+    re-entrant, and ``hipHostFree`` (which synchronises the device) is only ever called
+    after the lock has been released.'''
     MIN_BYTES = 1 << 20
-    # Bounds (bytes; MOD16_PINNED_CACHE / MOD16_PINNED_LIVE override them): idle blocks kept
-    # for re-use, and page-locked memory handed out in total -- results beyond the second
-    # bound are ordinary numpy arrays (slower to fill, but swappable: a caller that keeps a year
-    # of day/night rasters must not pin tens of GB of RAM).
     MAX_CACHED = int(os.environ.get('MOD16_PINNED_CACHE', 1 << 30))
-    MAX_LIVE = int(os.environ.get('MOD16_PINNED_LIVE', 8 << 30))
+    MAX_LIVE = int(os.environ.get('MOD16_PINNED_LIVE',
+                                  min(64 << 30, max(8 << 30, _host_ram_bytes() // 4))))
 
     def __init__(self):
-        self.lock = threading.Lock()
+        import collections
+        self.lock = threading.RLock()
         self.free = {}          # nbytes -> [address, ...]
         self.cached = 0         # idle bytes in `free`
         self.live = 0           # bytes allocated (handed out + idle)
+        self.recent = collections.deque(maxlen=8)     # sizes of the last results handed out
+        self.fallbacks = 0      # results that had to be plain numpy arrays
+        self._warned = False
+
+    def _cache_bound(self):
+        return min(self.MAX_LIVE, max(self.MAX_CACHED, sum(self.recent)))
+
+    def _free_blocks(self, doomed):
+        '''hipHostFree of blocks already taken off the books; called WITHOUT the lock.'''
+        for addr in doomed:
+            try:
+                load().mod16_host_free(addr)
+            except Exception:       # interpreter shutdown
+                pass
+
+    def _trim_locked(self, want, doomed):
+        '''Takes idle blocks worth `want` bytes off the books (largest first) into `doomed`.'''
+        for size in sorted(self.free, reverse=True):
+            blocks = self.free[size]
+            while blocks and want > 0:
+                doomed.append(blocks.pop())
+                self.cached -= size
+                self.live -= size
+                want -= size
+        return want
 
     def take(self, nbytes):
+        doomed = []
         with self.lock:
+            self.recent.append(nbytes)
             blocks = self.free.get(nbytes)
             if blocks:
                 self.cached -= nbytes
                 return blocks.pop()
+            room = True
             if self.live + nbytes > self.MAX_LIVE:
-                self._trim_locked(self.live + nbytes - self.MAX_LIVE)
-                if self.live + nbytes > self.MAX_LIVE:
-                    return None
-            self.live += nbytes
+                self._trim_locked(self.live + nbytes - self.MAX_LIVE, doomed)
+                room = self.live + nbytes <= self.MAX_LIVE
+            if room:
+                self.live += nbytes
+        self._free_blocks(doomed)
+        if not room:
+            self._over_bound(nbytes)
+            return None
         p = C.c_void_p()
         if load().mod16_host_alloc(nbytes, C.byref(p)) != OK or not p.value:
-            with self.lock:
+            with self.lock:         # no page-locked memory to be had (no GPU / the host's limit)
                 self.live -= nbytes
             return None
         return p.value
 
-    def _release(self, addr, nbytes):
-        self.live -= nbytes
-        try:
-            load().mod16_host_free(addr)
-        except Exception:       # interpreter shutdown
-            pass
-
-    def _trim_locked(self, want):
-        for size in sorted(self.free, reverse=True):
-            blocks = self.free[size]
-            while blocks and want > 0:
-                self._release(blocks.pop(), size)
-                self.cached -= size
-                want -= size
-        return want
+    def _over_bound(self, nbytes):
+        self.fallbacks += 1
+        if not self._warned:
+            self._warned = True
+            import warnings
+            warnings.warn(
+                'mod16_amd: a result array of %.3f GB did not fit the page-locked pool (%.3f of %.3f GB '
+                'in use; MOD16_PINNED_LIVE raises the bound): it is an ordinary numpy array and its '
+                'device-to-host copy runs at the page-fault rate, not the PCIe rate'
+                % (nbytes / 1e9, self.live / 1e9, self.MAX_LIVE / 1e9), RuntimeWarning, stacklevel=4)
 
     def trim(self, keep=0):
         '''Free idle blocks until at most ``keep`` bytes of them remain.'''
+        doomed = []
         with self.lock:
-            self._trim_locked(self.cached - keep)
+            self._trim_locked(self.cached - keep, doomed)
+        self._free_blocks(doomed)
 
     def give(self, addr, nbytes):
+        doomed = []
         with self.lock:
-            if self.cached + nbytes <= self.MAX_CACHED:
+            if self.cached + nbytes <= self._cache_bound():
                 self.free.setdefault(nbytes, []).append(addr)
                 self.cached += nbytes
-                return
-            self._release(addr, nbytes)
+            else:
+                self.live -= nbytes
+                doomed.append(addr)
+        self._free_blocks(doomed)
 
     def empty(self, shape, dtype):
         '''``numpy.empty(shape, dtype)``, page-locked when large enough.'''

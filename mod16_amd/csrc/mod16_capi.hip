@@ -51,12 +51,13 @@ struct mod16_ctx {
     int device = 0;
     int cus = 256;
     int grid_mult = 64;              // blocks per CU in the grid-stride launches of the plain kernels
-    bool use_dma = true;             // production pipeline (mod16_stream.hpp); MOD16_NO_DMA=1: plain kernels only
     int host_threads = 8;            // MOD16_HOST_THREADS: staging threads of the HOST mode (1..kSlots)
-    int run_shift = -1;              // MOD16_RUN_SHIFT: force 2^k pieces per run (experiments)
-    int stream_blocks = 2;           // MOD16_STREAM_BLOCKS: blocks of the pipeline kernel per CU (measurements: 1 = one wave per SIMD)
-    int static_below = 8;            // MOD16_STATIC_BELOW: runs per wave below which runs are dealt out statically (0: never)
-    int use_pitch = 1;               // scalar base + pitch addressing for slab layouts (MOD16_PITCH=0: off)
+    // launch geometry; fixed in the shipped library, overridable in -DMOD16_EXPERIMENTS builds only
+    bool use_dma = true;             // production pipeline (mod16_stream.hpp); off: plain kernels only
+    int run_shift = -1;              // force 2^k pieces per run
+    int stream_blocks = 2;           // blocks of the pipeline kernel per CU (1 = one wave per SIMD)
+    int static_below = 8;            // runs per wave below which runs are dealt out statically (0: never)
+    int use_pitch = 1;               // scalar base + pitch addressing for slab layouts
     unsigned long long* dyn_counters = nullptr;   // ring of ticket counters, 128 B apart
     int dyn_next = 0;
     bool have_lut = false;
@@ -110,6 +111,11 @@ static int fail(mod16_ctx* ctx, int code, const char* msg) {
 }
 
 extern "C" int mod16_version(void) { return MOD16_ABI_VERSION; }
+
+#ifndef MOD16_BUILD_ID
+#define MOD16_BUILD_ID "unknown"
+#endif
+extern "C" const char* mod16_build_id(void) { return MOD16_BUILD_ID; }
 
 extern "C" const char* mod16_strerror(int status) {
     switch (status) {
@@ -180,13 +186,18 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
             return MOD16_ERR_NO_DEVICE;
         }
         ctx->cus = prop.multiProcessorCount;
+        // the one documented tuning knob of the shipped library: staging threads of the HOST mode
+        if (const char* g = getenv("MOD16_HOST_THREADS")) ctx->host_threads = std::max(1, std::min(kSlots, atoi(g)));
+#ifdef MOD16_EXPERIMENTS
+        // launch-geometry overrides of the experiments build (libmod16hip_exp.so: tools/, and the
+        // tests that put the flag record through the other schedules); never in the shipped library
         if (const char* g = getenv("MOD16_GRID_MULT")) ctx->grid_mult = std::max(1, atoi(g));
         if (const char* g = getenv("MOD16_NO_DMA")) ctx->use_dma = atoi(g) == 0;
         if (const char* g = getenv("MOD16_PITCH")) ctx->use_pitch = atoi(g);
-        if (const char* g = getenv("MOD16_HOST_THREADS")) ctx->host_threads = std::max(1, std::min(kSlots, atoi(g)));
         if (const char* g = getenv("MOD16_RUN_SHIFT")) ctx->run_shift = std::max(1, std::min(6, atoi(g)));
         if (const char* g = getenv("MOD16_STATIC_BELOW")) ctx->static_below = std::max(0, std::min(64, atoi(g)));
         if (const char* g = getenv("MOD16_STREAM_BLOCKS")) ctx->stream_blocks = std::max(1, std::min(2, atoi(g)));
+#endif
         HIPCHK(ctx, hipMalloc(&ctx->dyn_counters, 64 * 128));
         const size_t nlut = MOD16_LUT_ROWS * kLutCols;
         HIPCHK(ctx, hipMalloc(&ctx->lut64, nlut * sizeof(double)));
@@ -435,7 +446,8 @@ constexpr int64_t kFuseFinalBelow = 16384;   // partials up to which the pipelin
 // be a multiple of the vector width. ddiag != NULL: also the fixed-order sum
 // of the per-run diagnostics partials -> ddiag (8 doubles on the device), over
 // n_valid_total pixels.
-template <typename T, int MODE>
+// GUARD = false: MOD16_DOMAIN_TRUSTED (the instance without the domain test; totals forms).
+template <typename T, int MODE, bool GUARD = true>
 static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double* ddiag = nullptr) {
     constexpr int V = VecOf<T>::v;
     s.lut64 = ctx->lut64;
@@ -477,13 +489,13 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     for (int k = 2; k < NW && pitched; ++k)
         pitched = reinterpret_cast<const char*>(s.wide[k]) - reinterpret_cast<const char*>(s.wide[0]) == k * pitch_b;
     s.wide_pitch = pitched ? pitch_b / (ptrdiff_t)sizeof(T) : 0;
-    if (pitched) hipLaunchKernelGGL((et_stream_kernel<T, MODE, true>), dim3(grid), dim3(kBlock), 0, st, s);
-    else hipLaunchKernelGGL((et_stream_kernel<T, MODE, false>), dim3(grid), dim3(kBlock), 0, st, s);
+    if (pitched) hipLaunchKernelGGL((et_stream_kernel<T, MODE, true, GUARD>), dim3(grid), dim3(kBlock), 0, st, s);
+    else hipLaunchKernelGGL((et_stream_kernel<T, MODE, false, GUARD>), dim3(grid), dim3(kBlock), 0, st, s);
     // pixels outside the domain of the production arithmetic (mod16_physics.hpp, "domain
     // guard"): a statically scheduled (small) raster has revisited them inside the kernel; a
     // large one left one flag per piece in its runs' partials for this kernel
 #ifndef MOD16_NO_REDO_LAUNCH
-    if (!g.static_sched) {
+    if constexpr (GUARD) if (!g.static_sched) {
         const int64_t groups = (nruns + 63) / 64;
         const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>((groups + kBlock / 64 - 1) / (kBlock / 64),
                                                                       (int64_t)ctx->cus * 4));
@@ -504,6 +516,20 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
                            fin, (int)count, s.n, ddiag);
     }
     return ws_release(ctx, st);
+}
+
+// The totals form (the production step): FAST or, float32, MIXED arithmetic; with
+// MOD16_DOMAIN_TRUSTED the instance without the domain test.
+template <typename T>
+static int launch_totals(mod16_ctx* ctx, const StreamArgs<T>& s, hipStream_t st, double* ddiag, unsigned flags) {
+    const bool trusted = (flags & MOD16_DOMAIN_TRUSTED) != 0;
+    if constexpr (std::is_same<T, float>::value) {
+        if (flags & MOD16_MATH_MIXED)
+            return trusted ? launch_stream<T, kStreamTotalsMixed, false>(ctx, s, st, ddiag)
+                           : launch_stream<T, kStreamTotalsMixed>(ctx, s, st, ddiag);
+    }
+    return trusted ? launch_stream<T, kStreamTotals, false>(ctx, s, st, ddiag)
+                   : launch_stream<T, kStreamTotals>(ctx, s, st, ddiag);
 }
 
 template <typename T> static bool has_rows_or_cols(const EtArgs<T>& a) {
@@ -564,14 +590,7 @@ static int launch_et(mod16_ctx* ctx, EtArgs<T> a, unsigned flags, hipStream_t st
         if (smode == kStreamTotals) {
             s.out[0] = a.out[0]; s.out[1] = a.out[1];
             fused_diag = ddiag && nbody == a.n;
-            if constexpr (std::is_same<T, float>::value) {
-                if (flags & MOD16_MATH_MIXED)
-                    rc = launch_stream<T, kStreamTotalsMixed>(ctx, s, st, fused_diag ? ddiag : nullptr);
-                else
-                    rc = launch_stream<T, kStreamTotals>(ctx, s, st, fused_diag ? ddiag : nullptr);
-            } else {
-                rc = launch_stream<T, kStreamTotals>(ctx, s, st, fused_diag ? ddiag : nullptr);
-            }
+            rc = launch_totals<T>(ctx, s, st, fused_diag ? ddiag : nullptr, flags);
         } else {
             // float32 rasters: MOD16_MATH_MIXED selects the mixed-precision pixel function
             bool mixed = false;
@@ -987,7 +1006,6 @@ static int graph_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drive
         // the graph lives, whatever the context's own workspace does meanwhile
         HIPCHK(ctx, ws_alloc(g->ws, std::max<int64_t>(kDiagBlocks, stream_geom(ctx, std::max<int64_t>(n, 0), VecOf<T>::v).nruns + kStage)));
         ctx->force_ws = &g->ws;
-        // once outside a capture: validates the arguments and brings the workspace to size
         HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         int r = et_diag_entry<T>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, st);
         hipError_t e = hipStreamEndCapture(st, &g->graph);
@@ -1760,6 +1778,26 @@ extern "C" int mod16_reduce_diag_f32(mod16_ctx* ctx, const float* day, const flo
     return reduce_entry<float>(ctx, day, night, n, diag, ddiag, stream);
 }
 
+// rank-order fold of the gathered diagnostics vectors (mod16_amd/dist.py)
+__global__ void fold_diag_kernel(const double* gathered, int world, double* diag) {
+    const int k = threadIdx.x;
+    if (k >= kDiag) return;
+    double acc = gathered[k];
+    for (int r = 1; r < world; ++r) {          // fixed order: rank 0 + rank 1 + ...
+        const double o = gathered[r * kDiag + k];
+        acc = k < 6 ? acc + o : (o > acc ? o : acc);
+    }
+    diag[k] = acc;
+}
+extern "C" int mod16_fold_diag(mod16_ctx* ctx, const double* gathered, int world, double* diag, void* stream) {
+    MOD16_LOCK(ctx);
+    if (!ctx || !gathered || !diag || world < 1) return fail(ctx, MOD16_ERR_ARG, "mod16_fold_diag: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(fold_diag_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), gathered, world, diag);
+    HIPCHK(ctx, hipGetLastError());
+    return MOD16_OK;
+}
+
 // ---------------------------------------------------------------- generator
 // tile (pixels) -> log2, or -1 if it is not a power of two >= lo
 static int tile_log2(int64_t tile, int64_t lo) {
@@ -1863,13 +1901,7 @@ static int tiled_entry(mod16_ctx* ctx, const mod16_layout* lay, const uint8_t* c
     s.out_row = lay->out_row;
     s.byte_row = lay->cls_row;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc;
-    if constexpr (std::is_same<T, float>::value) {
-        if (flags & MOD16_MATH_MIXED) rc = launch_stream<T, kStreamTotalsMixed>(ctx, s, st, ddiag);
-        else rc = launch_stream<T, kStreamTotals>(ctx, s, st, ddiag);
-    } else {
-        rc = launch_stream<T, kStreamTotals>(ctx, s, st, ddiag);
-    }
+    int rc = launch_totals<T>(ctx, s, st, ddiag, flags);
     if (rc != MOD16_OK) return rc;
     HIPCHK(ctx, hipGetLastError());
     return MOD16_OK;
@@ -1956,7 +1988,7 @@ static int form_tiled_entry(mod16_ctx* ctx, const mod16_layout* lay, int form,
         mixed = (flags & MOD16_MATH_MIXED) != 0;
         if (mixed) {
             switch (form) {
-            case MOD16_FORM_TOTALS: rc = launch_stream<T, kStreamTotalsMixed>(ctx, s, st); break;
+            case MOD16_FORM_TOTALS: rc = launch_totals<T>(ctx, s, st, nullptr, flags); break;
             case MOD16_FORM_PET: rc = launch_stream<T, kStreamPetMixed>(ctx, s, st); break;
             case MOD16_FORM_COMPONENTS: rc = launch_stream<T, kStreamSep6Mixed>(ctx, s, st); break;
             case MOD16_FORM_TOTALS_COMPONENTS: rc = launch_stream<T, kStreamSep8Mixed>(ctx, s, st); break;
@@ -1968,7 +2000,7 @@ static int form_tiled_entry(mod16_ctx* ctx, const mod16_layout* lay, int form,
     }
     if (!mixed) {
         switch (form) {
-        case MOD16_FORM_TOTALS: rc = launch_stream<T, kStreamTotals>(ctx, s, st); break;
+        case MOD16_FORM_TOTALS: rc = launch_totals<T>(ctx, s, st, nullptr, flags); break;
         case MOD16_FORM_PET: rc = launch_stream<T, kStreamPet>(ctx, s, st); break;
         case MOD16_FORM_COMPONENTS: rc = launch_stream<T, kStreamSep6>(ctx, s, st); break;
         case MOD16_FORM_TOTALS_COMPONENTS: rc = launch_stream<T, kStreamSep8>(ctx, s, st); break;

@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(kBlock, FAST ? 2 : 1) et_kernel(const EtArgs<T
     constexpr int kTab = FAST ? FastMath<double>::kTabDoubles : 1;
     __shared__ C lut[MOD16_LUT_ROWS * kLutCols];
     __shared__ __attribute__((aligned(16))) double tab[kTab];
+    if constexpr (FAST) ignore_signalling_nans();       // the domain guard's NaN-ignoring chain
     if (LUT)
         for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) {
             if constexpr (FAST) lut[i] = a.lut64[i];

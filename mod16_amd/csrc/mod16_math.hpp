@@ -10,9 +10,33 @@
 //                 straight IEEE transcription of this pixel stack is bound by
 //                 (DESIGN.md "Arithmetic budget").
 #pragma once
+// Measurement and mapping switches (tools/README.md) exist only in builds made with
+// -DMOD16_EXPERIMENTS, which mod16_amd/csrc/build.py passes to libmod16hip_exp.so alone: the
+// shipped library has one arithmetic and one launch geometry, and reads no environment variable
+// that changes either (tests/test_abi.py checks its strings).
+#ifndef MOD16_EXPERIMENTS
+#if defined(MOD16_TRIVIAL_BODY) || defined(MOD16_NO_GUARD) || defined(MOD16_EXPERIMENT_SEED_RCP) || \
+    defined(MOD16_PRIO) || defined(MOD16_REPRO_V4) || defined(MOD16_NO_FUSED_FINAL) ||                \
+    defined(MOD16_NO_REDO_LAUNCH) || defined(MOD16_KK_M) || defined(MOD16_NO_FMA_KK) ||               \
+    defined(MOD16_DYN_RUN)
+#error "MOD16_* measurement switches need -DMOD16_EXPERIMENTS (they are not part of the product build)"
+#endif
+#endif
 #include <hip/hip_runtime.h>
 
 namespace mod16 {
+
+// The domain guards (mod16_physics.hpp, mod16_mixed.hpp) are chains of v_max_f64 / v_max3_f32,
+// which ignore NaN operands -- QUIET ones. Compute waves start with MODE.IEEE = 1, where a
+// SIGNALLING NaN operand makes v_max return the quieted NaN instead, and the next link of the
+// chain then drops the running maximum: an sNaN bit pattern in one driver would hide an infinity
+// in another. With MODE.IEEE = 0 v_min / v_max treat signalling NaNs like quiet
+// ones. Nothing else in these kernels depends on the bit (it only governs sNaN quieting; every
+// comparison of the pixel functions is an ordinary v_cmp), so the kernels that evaluate a guard
+// clear it for their waves first thing: one scalar instruction per wave.
+__device__ __forceinline__ void ignore_signalling_nans() {
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 9, 1), 0\n\ts_nop 3" ::: "memory");
+}
 
 template <typename T> struct ExactMath {
     static __device__ __forceinline__ T exp(T x);

@@ -389,6 +389,7 @@ __global__ void __launch_bounds__(kBlock) et_raw_kernel(const RawArgs<T> a) {
     constexpr int kTab = FAST ? FastMath<double>::kTabDoubles : 1;
     __shared__ C lut[MOD16_LUT_ROWS * kLutCols];
     __shared__ __attribute__((aligned(16))) double tab[kTab];
+    if constexpr (FAST) ignore_signalling_nans();       // the domain guard's NaN-ignoring chain
     for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) {
         if constexpr (FAST) lut[i] = a.lut64[i];
         else lut[i] = a.lut[i];

@@ -399,11 +399,12 @@ __device__ __forceinline__ unsigned pair_out_of_domain(const float (&in)[14][2])
     return pair_guard<12>(y);
 }
 // raw drivers (raw_pair_mixed): the fields that pass through as above; specific humidity
-// below 1 kg/kg, the surface pressures like the air pressure, elevation below 40 km
+// below 1 kg/kg, the surface pressures like the air pressure, |elevation| below 25 km (the air
+// pressure computed from it then stays inside 1e3 .. 1e7 Pa: 1.1e3 Pa at 25 km, 1.1e6 at -25 km)
 __device__ __forceinline__ unsigned raw_pair_out_of_domain(const float (&raw)[14][2]) {
     auto col = [&](int k) { return f2{raw[k][0], raw[k][1]}; };
     const f2 y[12] = {col(0), col(1), col(2), col(3), col(4), col(9) * splat(kGuardMixed),
-                      col(10) * splat(kGuardMixed), col(13) * splat(2.5f),
+                      col(10) * splat(kGuardMixed), col(13) * splat(4.f),
                       guard_scale_t(col(5)), guard_scale_t(col(6)), guard_scale_p(col(11)),
                       guard_scale_p(col(12))};
     return pair_guard<12>(y);
@@ -438,7 +439,7 @@ __device__ __forceinline__ bool raw_out_of_domain_f32(const RawIn<double>& r) {
     return false;
 #else
     const float y[12] = {(float)r.lw_d, (float)r.lw_n, (float)r.sw_d, (float)r.sw_n, (float)r.alb,
-                         (float)r.qv_d * kGuardMixed, (float)r.qv_n * kGuardMixed, (float)r.elev * 2.5f,
+                         (float)r.qv_d * kGuardMixed, (float)r.qv_n * kGuardMixed, (float)r.elev * 4.f,
                          guard_scale_t1((float)r.t_d), guard_scale_t1((float)r.t_n),
                          guard_scale_p1((float)r.ps_d), guard_scale_p1((float)r.ps_n)};
     return guard_list_f32(y, 12);

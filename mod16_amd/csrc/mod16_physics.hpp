@@ -883,7 +883,8 @@ __device__ __forceinline__ PixelIn<double> raw_to_pixel_fast(const RawIn<double>
 // Domain of raw_to_pixel_fast + et_pixel_fast on raw drivers: as above for the fields that
 // pass through, plus what the fused pre-processing assumes: a specific humidity below 1 kg/kg
 // (0.379 qv + 0.622 > 0: one reciprocal serves both quotients), a finite surface pressure, an
-// elevation below 40 km (1 - 0.0065 z / 288.15 > 0: log_tab wants a positive normal number).
+// elevation below 39 km (1 - 0.0065 z / 288.15 > 0: log_tab wants a positive normal number, and the
+// air pressure computed from it stays above the 1 Pa lower bound of fast_out_of_domain).
 // fPAR, LAI (byte decodings) and the air pressure (from the bounded elevation) cannot leave it.
 __device__ __forceinline__ bool raw_out_of_domain(const RawIn<double>& r) {
 #ifdef MOD16_NO_GUARD
@@ -897,7 +898,7 @@ __device__ __forceinline__ bool raw_out_of_domain(const RawIn<double>& r) {
     m = max_abs(m, r.ps_n);
     m = max_abs(m, r.qv_d * in_vgpr(kGuardHuge));          // |qv| < 1
     m = max_abs(m, r.qv_n * in_vgpr(kGuardHuge));
-    m = max_abs(m, r.elev * in_vgpr(kGuardHuge / 4e4));  // |z| < 40 km
+    m = max_abs(m, r.elev * in_vgpr(kGuardHuge / 3.9e4));  // |z| < 39 km: the air pressure stays above the 1 Pa of fast_out_of_domain (1.5 Pa at 39 km)
     m = max_abs(m, guard_temperature(r.t_d));
     m = max_abs(m, guard_temperature(r.t_n));
     return m >= in_vgpr(kGuardHuge);

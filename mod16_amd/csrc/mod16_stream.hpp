@@ -303,13 +303,16 @@ constexpr int kFlagBits = 52;        // ... as an exact integer in a double
 // k * pitch by two scalar adds instead of a pointer load.
 // (no second __launch_bounds__ argument: asking for two waves per SIMD outright made hipcc pick a
 // schedule 1.2 % slower for the same 188 registers -- profiles/r03_ab_bisect.txt)
+// GUARD = false (MOD16_DOMAIN_TRUSTED, totals forms only): the caller vouches for the drivers; no
+// domain test, no flag record, nothing revisited -- the loop of round 2.
 #define MOD16_STREAM_BOUNDS __launch_bounds__(kBlock)
-template <typename T, int MODE, bool PITCHED = false>
+template <typename T, int MODE, bool PITCHED = false, bool GUARD = true>
 __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     typedef StreamSpec<MODE> S;
     constexpr int V = 16 / (int)sizeof(T);
     constexpr int NW = S::NW, NB = S::NB, NOUT = S::NOUT;
     constexpr int kSlot = NW * 1024 + NB * 256;
+    ignore_signalling_nans();
     constexpr bool RAW = MODE == kStreamRaw || MODE == kStreamRawTotal || MODE == kStreamRawTotalHours;
     constexpr int kTab = FastMath<double>::kTabDoubles;
     __shared__ double lut[MOD16_LUT_ROWS * kLutCols];
@@ -548,10 +551,12 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                         raw_pair_mixed(pin, fp, lx, tab, din, vpd64);
                         et_pair_mixed_parts<false, true>(din, lut + c0, lut + c1, kLutCols, tab, pd, pn, vpd64, lutf + c0, lutf + c1);
                     } else {
-                        const unsigned b2 = pair_out_of_domain(pin);
-                        bad |= b2 != 0u;
-                        pin[12][0] = (b2 & 1u) ? __builtin_nanf("") : pin[12][0];
-                        pin[12][1] = (b2 & 2u) ? __builtin_nanf("") : pin[12][1];
+                        if constexpr (GUARD) {
+                            const unsigned b2 = pair_out_of_domain(pin);
+                            bad |= b2 != 0u;
+                            pin[12][0] = (b2 & 1u) ? __builtin_nanf("") : pin[12][0];
+                            pin[12][1] = (b2 & 2u) ? __builtin_nanf("") : pin[12][1];
+                        }
                         et_pair_mixed_parts<MODE == kStreamPetMixed, true>(pin, lut + c0, lut + c1, kLutCols, tab, pd, pn, nullptr, lutf + c0, lutf + c1);
                     }
                     const f2 day2 = (pd.canopy + pd.soil) + pd.trans;        // :792
@@ -621,10 +626,12 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                                         (double)in[6][j], (double)in[7][j], (double)in[8][j],
                                         (double)in[9][j], (double)in[10][j], (double)in[11][j],
                                         (double)in[12][j], (double)in[13][j]};
-                    const bool out = fast_out_of_domain(x);
-                    bad |= out;
-                    // (the high word decides: 0x7ff80000'xxxxxxxx is a quiet NaN -- one v_cndmask)
-                    x.fpar = __hiloint2double(out ? 0x7ff80000 : __double2hiint(x.fpar), __double2loint(x.fpar));
+                    if constexpr (GUARD) {
+                        const bool out = fast_out_of_domain(x);
+                        bad |= out;
+                        // (the high word decides: 0x7ff80000'xxxxxxxx is a quiet NaN -- one v_cndmask)
+                        x.fpar = __hiloint2double(out ? 0x7ff80000 : __double2hiint(x.fpar), __double2loint(x.fpar));
+                    }
                 }
                 const unsigned c = cls_of[j];
                 const double* l = lut + c;
@@ -687,9 +694,11 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
             for (int k = 0; k < NOUT; ++k)
                 __builtin_nontemporal_store(res[k], reinterpret_cast<VT*>((a.out[k] + first) + lane_elem));
             // a flagged pixel in this piece: remember the piece (see redo_piece above)
-            if (__builtin_expect(__any(bad), 0)) {
-                const int bit = a.static_sched ? iters : run;
-                flags |= 1ull << (bit < kFlagBits - 1 ? bit : kFlagBits - 1);
+            if constexpr (GUARD) {
+                if (__builtin_expect(__any(bad), 0)) {
+                    const int bit = a.static_sched ? iters : run;
+                    flags |= 1ull << (bit < kFlagBits - 1 ? bit : kFlagBits - 1);
+                }
             }
         }
         ++iters;
@@ -736,7 +745,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         if (first_cbase < npiece) {
             const unsigned long long mine = (unsigned long long)uniform64((int64_t)flags);     // (diag_fields() stores and clears them)
             f = diag_fields();
-            if (__builtin_expect(mine != 0ull, 0)) {
+            if constexpr (GUARD) if (__builtin_expect(mine != 0ull, 0)) {
                 RedoAcc acc;
                 const int64_t w0 = first_cbase >> rs;
 #pragma nounroll
@@ -836,6 +845,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
 template <typename T, int MODE>
 __global__ void __launch_bounds__(kBlock) et_stream_redo_kernel(const StreamArgs<T> a) {
     constexpr int V = 16 / (int)sizeof(T);
+    ignore_signalling_nans();       // the guard is asked again: the same answer as in the pipeline kernel
     __shared__ double lut[MOD16_LUT_ROWS * kLutCols];
     for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) lut[i] = a.lut64[i];
     __syncthreads();

@@ -33,7 +33,7 @@ def pixel_range(rows, cols, rank, world):
 _GATHER = {}
 
 
-def allreduce_diag(diag, group=None):
+def allreduce_diag(diag, group=None, engine=None):
     '''In-place reduction of a diagnostics vector (``raster.DIAG_FIELDS``) over
     the ranks: sums and counts [0:6] added, maxima [6:8] maximised. ``diag`` is
     a float64 tensor of 8 on the device the process group's backend serves.
@@ -42,11 +42,15 @@ def allreduce_diag(diag, group=None):
     rank: latency-bound whatever the algorithm) -- and the reduction itself is
     done by every rank on the gathered ``(world, 8)`` block in RANK ORDER, so
     the global sums are the same bits on every rank and from run to run,
-    whatever order the collective library moves the pieces in.'''
+    whatever order the collective library moves the pieces in. With ``engine`` (a
+    ``RasterEngine`` on the tensor's device) that fold is one library kernel
+    (``mod16_fold_diag``) behind the gather; without, a handful of torch operations
+    (CPU tensors under gloo). A group of ONE still runs the collective: whatever the
+    process group is, is what a step executes (``bench.py`` rehearses the N > 1 step on
+    one GPU that way).'''
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or \
-            dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return diag
     world = dist.get_world_size(group)
     key = (diag.device, world)
@@ -54,6 +58,8 @@ def allreduce_diag(diag, group=None):
     if buf is None:
         buf = _GATHER[key] = torch.empty(world * 8, dtype=torch.float64, device=diag.device)
     dist.all_gather_into_tensor(buf, diag, group=group)
+    if engine is not None and diag.is_cuda:
+        return engine.fold_ranks(buf, world, diag)
     buf = buf.view(world, 8)
     acc = buf[0, 0:6].clone()
     for r in range(1, world):          # fixed order: rank 0 + rank 1 + ...

@@ -160,9 +160,17 @@ class RasterEngine(object):
     math : int
         ``_lib.MATH_FAST`` (default), ``_lib.MATH_EXACT`` or, for float32
         rasters, ``_lib.MATH_MIXED`` (see ``include/mod16_hip.h``)
+    trusted : bool
+        ``MOD16_DOMAIN_TRUSTED``: the caller vouches that every driver lies inside
+        the domain of the production arithmetic (quality-controlled or NaN-masked
+        rasters; the bounds are in ``include/mod16_hip.h``) -- the totals form then
+        runs without the domain test and without the dispatch that revisits flagged
+        pixels (-2.6 % kernel time on the float64 global grid). Default: False, the
+        arithmetic that returns the reference's result on every input.
     '''
 
-    def __init__(self, table, device=None, dtype='float64', math=_lib.MATH_FAST):
+    def __init__(self, table, device=None, dtype='float64', math=_lib.MATH_FAST, trusted=False,
+                 experiments=False):
         torch = _torch()
         if not torch.cuda.is_available():
             raise _lib.Mod16Error(
@@ -171,11 +179,13 @@ class RasterEngine(object):
         # a context of its own: the BPLUT set here is what this engine's launches
         # (and the graphs bound from it) read at run time, whatever table other
         # engines or the numpy entry points of the process use meanwhile
-        self.ctx = _lib.Context(self.device)
+        # (experiments: a context of libmod16hip_exp.so, which reads the launch-geometry overrides
+        # from the environment -- tests and tools only)
+        self.ctx = _lib.Context(self.device, experiments=experiments)
         self.ctx.set_bplut(table)
         self.np_dtype = np.dtype(dtype)
         self.dtype = {'float64': torch.float64, 'float32': torch.float32}[self.np_dtype.name]
-        self.math = math
+        self.math = int(math) | (_lib.DOMAIN_TRUSTED if trusted else 0)
         self.bytes_per_pixel = BYTES_PER_PIXEL[self.np_dtype.name]
 
     #: bytes of one field per tile of a ``TiledRaster`` (16-64 KiB measured: 32 KiB best)
@@ -626,6 +636,17 @@ class RasterEngine(object):
         self.ctx.check(self.ctx.lib.mod16_measure_copy(self.ctx.handle, int(nbytes), int(reps),
                                                        C.byref(gbps)))
         return gbps.value
+
+    def fold_ranks(self, gathered, world, diag):
+        '''The rank-order fold behind the all-gather of the diagnostics vectors
+        (``mod16_fold_diag``; ``mod16_amd.dist.allreduce_diag`` calls it): ``gathered`` is the
+        ``(world, 8)`` float64 block, ``diag`` (8) receives sums in rank order and maxima. One
+        kernel on the current stream.'''
+        torch = _torch()
+        self.ctx.check(self.ctx.lib.mod16_fold_diag(
+            self.ctx.handle, self._check_tensor(gathered, torch.float64, world * 8, 'gathered'),
+            int(world), self._check_tensor(diag, torch.float64, 8, 'diag'), self._stream()))
+        return diag
 
     def check(self):
         '''Synchronise and raise deferred errors (IndexError for a class code

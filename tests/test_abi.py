@@ -140,3 +140,33 @@ def test_form_table_matches_the_library():
         assert lib.mod16_form_shape(form, C.byref(nw), C.byref(nb), C.byref(no)) == 0
         assert (nw.value, nb.value, no.value) == shape, form
     assert lib.mod16_form_shape(len(_lib.FORM_SHAPE), None, None, None) != 0
+
+
+def test_shipped_library_reads_no_experiment_switch(lib):
+    """Launch-geometry overrides and measurement paths exist only in -DMOD16_EXPERIMENTS builds
+    (libmod16hip_exp.so, tools/): the shipped library names ONE environment variable, the
+    documented MOD16_HOST_THREADS, and the sources refuse to compile a measurement switch
+    without the experiments define."""
+    import shutil
+    import subprocess
+
+    def env_names(path):
+        blob = open(path, 'rb').read()
+        return set(m.decode() for m in re.findall(rb'MOD16_[A-Z0-9_]{3,}', blob))
+    switches = {'MOD16_NO_DMA', 'MOD16_RUN_SHIFT', 'MOD16_STATIC_BELOW', 'MOD16_STREAM_BLOCKS',
+                'MOD16_PITCH', 'MOD16_GRID_MULT'}
+    shipped = env_names(lib.LIB_PATH)      # (the rest are enum names inside error messages)
+    assert 'MOD16_HOST_THREADS' in shipped and not (shipped & switches), shipped
+    assert not any(n.startswith(('MOD16_NO_', 'MOD16_EXPERIMENT', 'MOD16_TRIVIAL', 'MOD16_PRIO', 'MOD16_DYN'))
+                   for n in shipped), shipped
+    assert switches | {'MOD16_HOST_THREADS'} <= env_names(lib.EXP_LIB_PATH)
+    src = open(os.path.join(ROOT, 'mod16_amd', 'csrc', 'mod16_capi.hip')).read()
+    product = re.sub(r'#ifdef MOD16_EXPERIMENTS.*?#endif', '', src, flags=re.S)
+    assert re.findall(r'getenv\("(\w+)"\)', product) == ['MOD16_HOST_THREADS']
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if os.path.exists(hipcc):
+        for switch in ('-DMOD16_NO_GUARD', '-DMOD16_TRIVIAL_BODY', '-DMOD16_DYN_RUN=4'):
+            proc = subprocess.run([hipcc, '--offload-arch=gfx950', '-std=c++17', '-fsyntax-only', '--cuda-device-only',
+                                   '-x', 'hip', switch, os.path.join(ROOT, 'mod16_amd', 'csrc', 'mod16_math.hpp')],
+                                  capture_output=True, text=True)
+            assert proc.returncode != 0 and 'MOD16_EXPERIMENTS' in proc.stderr, switch

@@ -135,7 +135,7 @@ def test_flagged_pixels_in_the_other_forms_at_size(env, dtype):
     os.environ['MOD16_NO_DMA'] = '1'
     try:
         plain = RasterEngine(table, dtype=dtype)
-        plain.ctx = _lib.Context(0)
+        plain.ctx = _lib.Context(0, experiments=True)
         plain.ctx.set_bplut(np.ascontiguousarray(table, np.float64))
     finally:
         del os.environ['MOD16_NO_DMA']
@@ -200,7 +200,7 @@ def test_flags_under_other_schedules(env, switches):
         os.environ[k] = v
     try:
         eng = RasterEngine(table)
-        eng.ctx = _lib.Context(0)
+        eng.ctx = _lib.Context(0, experiments=True)
         eng.ctx.set_bplut(np.ascontiguousarray(table, np.float64))
     finally:
         for k in switches:
@@ -256,3 +256,89 @@ def test_flagged_pixels_through_the_numpy_path_over_many_tiles(env):
         w32 = [w.astype(np.float32) for w in o32]
     assert_parity(got32[0][sub], w32[0], 1e-6, 'day, float32')
     assert_parity(got32[1][sub], w32[1], 1e-6, 'night, float32')
+
+
+@pytest.mark.parametrize('n', [1200 * 1200, 24_000_000])
+def test_signalling_nans_do_not_hide_their_neighbours(env, n):
+    """A SIGNALLING NaN bit pattern (0x7ff0000000000001: what uninitialised or bit-packed memory
+    can hold; numpy's own NaN is quiet) in a driver that enters the guard's chain LATE -- pressure,
+    VPD, the temperatures -- next to an infinity or a huge value in one that enters it EARLY
+    (radiation, fPAR, LAI). Under MODE.IEEE = 1 v_max_f64 would return the quieted NaN and the
+    next link drop the running maximum: the pixel would stay on the fast path. The kernels clear
+    the bit (mod16_math.hpp: ignore_signalling_nans), so the pixel is redone in the reference's
+    order: masks and values of the reference-order kernel and of the oracle. Both schedules."""
+    torch, RasterEngine, table, _lib = env
+    eng = RasterEngine(table)
+    ref = RasterEngine(table, math=_lib.MATH_EXACT)
+    cls, drv = eng.synth(n, seed=31)
+    snan = torch.tensor([0x7ff0000000000001, -0x000ffffffffffff], dtype=torch.int64).view(torch.float64).cuda()
+    assert bool(torch.isnan(snan).all())
+    g = torch.Generator(device='cpu').manual_seed(5)
+    idx = torch.arange(17, n, max(1, n // 40000))
+    late = torch.tensor([11, 9, 10, 5, 6])[torch.randint(0, 5, (idx.numel(),), generator=g)]
+    early = torch.tensor([0, 2, 4, 1, 3, 12, 13])[torch.randint(0, 7, (idx.numel(),), generator=g)]
+    big = torch.tensor([np.inf, -np.inf, 1e300, -1e300])[torch.randint(0, 4, (idx.numel(),), generator=g)].double()
+    which = torch.randint(0, 2, (idx.numel(),), generator=g)
+    for k in range(14):
+        sel = late == k
+        if sel.any():
+            drv[k][idx[sel].cuda()] = snan[which[sel].cuda()]
+        sel = early == k
+        if sel.any():
+            drv[k][idx[sel].cuda()] = big[sel].cuda()
+    idx = idx.cuda()
+    diag = torch.zeros(8, dtype=torch.float64, device='cuda')
+    day, night = eng.run(cls, drv, diag=diag)
+    eng.check()
+    want = ref.run(cls[idx].contiguous(), [d[idx].contiguous() for d in drv])
+    ref.check()
+    assert_parity(day[idx].cpu().numpy(), want[0].cpu().numpy(), 1e-9, 'day')
+    assert_parity(night[idx].cpu().numpy(), want[1].cpu().numpy(), 1e-9, 'night')
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    sub = idx[:20000]
+    with np.errstate(all='ignore'):
+        o_day, o_night = oracle.evapotranspiration_raster(bplut, cls[sub].cpu().numpy(), *[d[sub].cpu().numpy() for d in drv])
+    assert_parity(day[sub].cpu().numpy(), o_day, 1e-8, 'day vs oracle')
+    assert_parity(night[sub].cpu().numpy(), o_night, 1e-8, 'night vs oracle')
+    want_d = host_diag(torch, day, night)
+    got = diag.cpu().numpy()
+    assert np.array_equal(got[2:6], want_d[2:6]) and got[6] == want_d[6] and got[7] == want_d[7]
+    # the other kernels that evaluate the guard: one pixel per thread / ragged, and float32 MIXED
+    m = 4099
+    d1, n1 = eng.run(cls[idx[:m]].contiguous(), [d[idx[:m]].contiguous() for d in drv])
+    assert torch.equal(torch.nan_to_num(d1, nan=-7.0, posinf=9e300, neginf=-9e300),
+                       torch.nan_to_num(day[idx[:m]], nan=-7.0, posinf=9e300, neginf=-9e300))
+    assert torch.equal(torch.nan_to_num(n1, nan=-7.0, posinf=9e300, neginf=-9e300),
+                       torch.nan_to_num(night[idx[:m]], nan=-7.0, posinf=9e300, neginf=-9e300))
+
+
+@pytest.mark.parametrize('dtype,math', [('float64', 'fast'), ('float32', 'fast'), ('float32', 'mixed')])
+def test_trusted_domain_is_the_same_arithmetic_without_the_test(env, dtype, math):
+    """MOD16_DOMAIN_TRUSTED (RasterEngine(trusted=True)): on drivers inside the domain -- NaN fill
+    included -- the instance without the domain test gives the guarded instance's bits: outputs and
+    diagnostics, plain arrays (both schedules) and the tiled layout, direct launches and a captured
+    step. (Outside the domain it returns whatever the rearranged arithmetic gives: the caller's
+    word is what the flag is.)"""
+    torch, RasterEngine, table, _lib = env
+    m = {'fast': _lib.MATH_FAST, 'mixed': _lib.MATH_MIXED}[math]
+    eng = RasterEngine(table, dtype=dtype, math=m)
+    fast = RasterEngine(table, dtype=dtype, math=m, trusted=True)
+    assert fast.math == (m | _lib.DOMAIN_TRUSTED)
+    same = lambda a, b: torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+    for n in (1200 * 1200, 30_000_000):
+        cls, drv = eng.synth(n, seed=41)
+        d0 = torch.zeros(8, dtype=torch.float64, device='cuda')
+        d1 = torch.zeros(8, dtype=torch.float64, device='cuda')
+        want = eng.run(cls, drv, diag=d0)
+        got = fast.run(cls, drv, diag=d1)
+        fast.check()
+        assert same(got[0], want[0]) and same(got[1], want[1]) and same(d0, d1), n
+        r = fast.to_tiled(cls, drv)
+        d2 = torch.zeros(8, dtype=torch.float64, device='cuda')
+        step = fast.bind_tiled(r, d2)
+        step()
+        torch.cuda.synchronize()
+        assert same(r.flat(r.day), want[0]) and same(r.flat(r.night), want[1])
+        assert np.array_equal(d2.cpu().numpy()[2:], d0.cpu().numpy()[2:])
+        assert np.allclose(d2.cpu().numpy()[:2], d0.cpu().numpy()[:2], rtol=1e-12)
+        del r, step

@@ -217,7 +217,7 @@ def test_band_sharding_composes_to_the_global_run(env, world):
     torch, RasterEngine, table = env
     from mod16_amd import dist as tiles
     eng = RasterEngine(table)
-    rows, cols = 2700 // 9 * world // world * 8, 1440     # small stand-in for 21600 x 43200
+    rows, cols = 2400, 1440      # small stand-in for 21600 x 43200 (divisible by 2 and 8 bands)
     n = rows * cols
     cls, drv = eng.synth(n, seed=16)
     gdiag = torch.zeros(8, dtype=torch.float64, device='cuda')
@@ -777,29 +777,48 @@ def test_global_grid_float64(env):
 
 def test_pinned_pool_is_bounded(env):
     """The page-locked memory behind result arrays is bounded: beyond MAX_LIVE bytes handed out the
-    results are plain numpy arrays (a caller keeping many rasters must not pin RAM without limit),
-    idle blocks beyond MAX_CACHED are freed, trim() frees the rest."""
+    results are plain numpy arrays (a caller keeping many rasters must not pin RAM without limit) and
+    the pool says so once; idle blocks are kept up to the sizes of the last results handed out (one
+    step of a time loop finds its blocks again) or MAX_CACHED, whichever is larger; trim() frees the
+    rest. give() runs from a finalizer -- also inside a collection that take() triggers while it
+    holds the (re-entrant) lock."""
     import gc
+    import warnings
     from mod16_amd import _lib
     pool = _lib._PinnedPool()
     pool.MAX_LIVE, pool.MAX_CACHED = 5 << 20, 2 << 20
     held = [pool.empty((1 << 20,), np.uint8) for _ in range(5)]        # 5 MiB: all page-locked
     assert all(a.base is not None for a in held) and pool.live == 5 << 20
-    extra = pool.empty((1 << 20,), np.uint8)                           # over the bound: ordinary
-    assert extra.base is None and pool.live == 5 << 20
+    with pytest.warns(RuntimeWarning, match='did not fit the page-locked pool'):
+        extra = pool.empty((1 << 20,), np.uint8)                       # over the bound: ordinary, and said
+    assert extra.base is None and pool.live == 5 << 20 and pool.fallbacks == 1
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                                 # ... once
+        extra2 = pool.empty((1 << 20,), np.uint8)
+    assert extra2.base is None and pool.fallbacks == 2
     del held
     gc.collect()
-    assert pool.cached == 2 << 20 and pool.live == 2 << 20             # two kept idle, three freed
+    assert pool.cached == 5 << 20 and pool.live == 5 << 20             # the last results' blocks stay idle
     again = pool.empty((1 << 20,), np.uint8)
-    assert again.base is not None and pool.cached == 1 << 20           # an idle block came back
+    assert again.base is not None and pool.cached == 4 << 20           # an idle block came back
+    pool.trim(keep=1 << 20)
+    assert pool.cached == 1 << 20 and pool.live == 2 << 20
     pool.trim()
     assert pool.cached == 0 and pool.live == 1 << 20
-    # an idle block of another size makes room when the bound is reached
+    # with nothing recent, idle blocks beyond MAX_CACHED are freed when they come back
+    more = [again] + [pool.empty((1 << 20,), np.uint8) for _ in range(3)]
     del again
+    pool.recent.clear()
+    del more
     gc.collect()
+    assert pool.cached == 2 << 20 and pool.live == 2 << 20
+    # an idle block of another size makes room when the bound is reached
     big = pool.empty((4 << 20,), np.uint8)
     big2 = pool.empty((1 << 20,), np.uint8)
     assert big.base is not None and big2.base is not None and pool.live <= 5 << 20
+    # a finalizer firing inside take(): the lock is re-entrant
+    with pool.lock:
+        pool.give(0, 0)
 
 
 def test_flat_always_copies(env):
@@ -844,3 +863,90 @@ def test_bench_reads_the_sensors_of_its_own_device(env):
     assert res is not None and res['samples'] >= 1
     assert 90 <= res['sclk_mhz'] <= 3000 and 0 < res['power_w'] <= 1.2 * cap
     assert res['power_cap_w'] == cap
+
+
+def test_rank_order_fold_of_gathered_diagnostics(env):
+    """mod16_fold_diag (the kernel behind dist.allreduce_diag's all-gather): sums and counts added
+    in rank order -- the bits of a left-to-right float64 sum --, maxima maximised; 1, 2 and 8 ranks,
+    in place on a vector that is also row 0 of nothing (the gather buffer is separate)."""
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table)
+    rng = np.random.default_rng(3)
+    for world in (1, 2, 8):
+        block = rng.normal(0, 1e6, (world, 8))
+        block[:, 2:6] = rng.integers(0, 1 << 30, (world, 4))
+        want = np.empty(8)
+        for k in range(6):
+            acc = block[0, k]
+            for r in range(1, world):
+                acc = acc + block[r, k]
+            want[k] = acc
+        want[6:] = block[:, 6:].max(axis=0)
+        gathered = torch.from_numpy(block).cuda().reshape(-1)
+        diag = torch.zeros(8, dtype=torch.float64, device='cuda')
+        eng.fold_ranks(gathered, world, diag)
+        torch.cuda.synchronize()
+        assert np.array_equal(diag.cpu().numpy(), want), world
+    with pytest.raises(Exception):
+        eng.fold_ranks(gathered, 0, diag)
+
+
+def test_graph_as_the_first_gpu_call_of_a_process(env):
+    """A captured step built as the very first GPU work of a fresh process (no launch of any
+    library kernel before hipStreamBeginCapture: lazy code-object loading, the scalar-driver
+    staging and the workspace set-up all happen on the capture path), plain arrays with and
+    without a broadcast scalar driver, and a tiled raster; replayed twice and checked against
+    direct launches. A child process: this one has long initialised the device."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch
+from mod16_amd import _lib
+from mod16_amd.raster import RasterEngine
+from mod16_amd.utils import restore_bplut, bplut_table
+from mod16_amd.models import COLLECTION61_BPLUT
+table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
+which = sys.argv[1]
+eng = RasterEngine(table)
+n = 3_000_000 if which != 'tiled_large' else 40_000_000
+same = lambda a, b: torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+diag = torch.zeros(8, dtype=torch.float64, device='cuda')
+if which.startswith('tiled'):
+    r = eng.alloc_tiled(n)
+    r.slab.zero_()                       # torch kernels only so far
+    for k, v in enumerate((-50., -30., 150., 0., .2, 293., 290., 285., 285., 1000., 500., 1e5, .5, 1.5)):
+        r.drivers[k].fill_(v)
+    r.cls.fill_(7)
+    step = eng.bind_tiled(r, diag)       # FIRST library launch sequence: inside the capture
+    step(); step()
+    torch.cuda.synchronize()
+    d2 = torch.zeros(8, dtype=torch.float64, device='cuda')
+    day, night = r.flat(r.day), r.flat(r.night)
+    eng.run_tiled(r, diag=d2)
+    torch.cuda.synchronize()
+    assert same(day, r.flat(r.day)) and same(night, r.flat(r.night)) and same(diag, d2)
+    assert float(diag[2]) == n and 1e-7 < float(day[0]) < 1e-3
+else:
+    cls = torch.full((n,), 7, dtype=torch.uint8, device='cuda')
+    vals = (-50., -30., 150., 0., .2, 293., 290., 285., 285., 1000., 500., 1e5, .5, 1.5)
+    drv = [torch.full((n,), v, dtype=torch.float64, device='cuda') for v in vals]
+    if which == 'scalar':
+        drv[3] = 0.0                     # sw_rad_night as a broadcast scalar (notebook cell 17)
+    day, night = eng.empty(n, 2)
+    step = eng.bind(cls, drv, day, night, diag, graph=True)
+    step(); step()
+    torch.cuda.synchronize()
+    d2 = torch.zeros(8, dtype=torch.float64, device='cuda')
+    rd, rn = eng.run(cls, drv, diag=d2)
+    eng.check()
+    assert same(day, rd) and same(night, rn) and same(diag, d2), which
+    assert float(diag[2]) == n
+print('ok', which)
+''' % ROOT
+    for which in ('dense', 'scalar', 'tiled', 'tiled_large'):
+        proc = subprocess.run([sys.executable, '-c', code, which], capture_output=True, text=True, timeout=600)
+        assert proc.returncode == 0 and ('ok ' + which) in proc.stdout, (which, proc.stdout[-1000:], proc.stderr[-3000:])

@@ -39,7 +39,7 @@ def plain_engine(RasterEngine, table, dtype='float64'):
     try:
         from mod16_amd import _lib
         eng = RasterEngine(table, dtype=dtype)
-        eng.ctx = _lib.Context(0)          # a context of its own (contexts are cached per device)
+        eng.ctx = _lib.Context(0, experiments=True)          # a context of its own (contexts are cached per device)
         eng.ctx.set_bplut(np.ascontiguousarray(table, np.float64))
         return eng
     finally:

@@ -146,3 +146,33 @@ def test_broadcast_kinds_are_not_made_dense():
     # without the switch everything but scalars is dense, as before
     keep, ptrs, strides = mod16_amd._marshal(values, (T, N), np.float64)
     assert strides == [1, 1, 1, 0, 1] and [a.size for a in keep] == [T * N, T * N, T * N, 1, T * N]
+
+
+def test_pmc_traffic_belongs_to_the_build(tmp_path):
+    """bench.py reports roofline.traffic only from a PMC record measured on the very build of the
+    library that is loaded (mod16_build_id): a record of another build -- a kernel change without
+    fresh tools/run_profiles.sh passes -- gives None and says why."""
+    import json
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    from mod16_amd import _lib
+    mine = _lib.build_id()
+    assert len(mine) == 16 and mine != 'unknown'
+    assert _lib.load_experiments().mod16_build_id().decode() != mine      # another set of flags
+    rec = {'pixels_per_launch': 1000, 'dtype': 'float64', 'layout': 'tiled',
+           'traffic_bytes_per_launch': 129050.0, 'build_id': 'feedfacefeedface', 'git_commit': 'abc'}
+    (tmp_path / 'r09_pmc_hbm_traffic.json').write_text(json.dumps(rec))
+    got = bench.pmc_traffic(1000, 'float64', 'tiled', mine, profiles_dir=str(tmp_path))
+    assert got[0] is None and got[1] is None and 'feedfacefeedface' in got[2] and mine in got[2]
+    rec['build_id'] = mine
+    (tmp_path / 'r10_pmc_hbm_traffic.json').write_text(json.dumps(rec))
+    got = bench.pmc_traffic(1000, 'float64', 'tiled', mine, profiles_dir=str(tmp_path))
+    assert got[0] == 129050.0 and got[1].endswith('r10_pmc_hbm_traffic.json')
+    # another shape: nothing applies
+    assert bench.pmc_traffic(2000, 'float64', 'tiled', mine, profiles_dir=str(tmp_path))[0] is None
+    assert bench.pmc_traffic(1000, 'float32', 'tiled', mine, profiles_dir=str(tmp_path))[0] is None
+    # the committed records (older rounds carry no build id): never reported for this build unless measured on it
+    t, src, note = bench.pmc_traffic(933120000, 'float64', 'tiled', mine)
+    assert (t is None) == (src is None) and note

@@ -15,7 +15,9 @@ from mod16_amd.models import COLLECTION61_BPLUT  # noqa: E402
 
 
 def main():
-    eng = RasterEngine(bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250))
+    # MOD16_STATIC_BELOW etc. are read by the experiments build of the library only
+    eng = RasterEngine(bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250),
+                       experiments=any(k in os.environ for k in ('MOD16_STATIC_BELOW', 'MOD16_RUN_SHIFT', 'MOD16_STREAM_BLOCKS')))
     diag = torch.zeros(8, dtype=torch.float64, device='cuda')
     for tiles in (1, 4, 64):
         n = 1200 * 1200 * tiles

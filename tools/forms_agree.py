@@ -23,7 +23,7 @@ def plain_engine(table, dtype):
     os.environ['MOD16_NO_DMA'] = '1'
     try:
         eng = RasterEngine(table, dtype=dtype)
-        eng.ctx = _lib.Context(0)
+        eng.ctx = _lib.Context(0, experiments=True)
         eng.ctx.set_bplut(np.ascontiguousarray(table, np.float64))
         return eng
     finally:

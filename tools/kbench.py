@@ -60,7 +60,7 @@ def child(args):
         for val in vals:
             os.environ[args.ab] = val
             e = RasterEngine(table, dtype=args.dtype, math=math)
-            e.ctx = _lib.Context(0)
+            e.ctx = _lib.Context(0, experiments=True)
             e.ctx.set_bplut(np.ascontiguousarray(table, np.float64))
             engs[val] = e
         del os.environ[args.ab]

@@ -39,7 +39,19 @@ try:
     n = line['roofline']['pixels_per_launch']
     rd = res['FETCH_SIZE'][0] * 1024 * 2
     wr = res['WRITE_SIZE'][0] * 1024
-    rec = {'kernel': line['roofline']['kernel'], 'layout': line['config']['raster_layout']['layout'],
+    import hashlib, sys
+    sys.path.insert(0, os.getcwd())
+    from mod16_amd import _lib
+    info = {}
+    try:
+        info = json.load(open(os.path.join('mod16_amd', 'build_info.json')))
+    except (OSError, ValueError):
+        pass
+    # the record belongs to the library that produced it: bench.py reports it only for this build
+    rec = {'build_id': _lib.build_id(), 'lib_sha256': hashlib.sha256(open(_lib.LIB_PATH, 'rb').read()).hexdigest(),
+           'git_commit': info.get('git_commit') if info.get('build_id') == _lib.build_id() else None,
+           'git_dirty_at_build': info.get('git_dirty') if info.get('build_id') == _lib.build_id() else None,
+           'kernel': line['roofline']['kernel'], 'layout': line['config']['raster_layout']['layout'],
            'dtype': {'f64': 'float64', 'f32': 'float32'}[line['dtype']],
            'launches_averaged': [res['FETCH_SIZE'][1], res['WRITE_SIZE'][1]],
            'FETCH_SIZE_KB_per_launch': res['FETCH_SIZE'][0], 'WRITE_SIZE_KB_per_launch': res['WRITE_SIZE'][0],

@@ -43,7 +43,7 @@ def main():
     eng = RasterEngine(table, dtype=dtype, math=math)
     os.environ['MOD16_NO_DMA'] = '1'
     plain = RasterEngine(table, dtype=dtype)
-    plain.ctx = _lib.Context(0)
+    plain.ctx = _lib.Context(0, experiments=True)
     plain.ctx.set_bplut(np.ascontiguousarray(table, np.float64))
     del os.environ['MOD16_NO_DMA']
     esz = eng.np_dtype.itemsize
