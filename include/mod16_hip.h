@@ -389,9 +389,10 @@ MOD16_API int mod16_et_static_f32(mod16_ctx* ctx, const float* const* drivers,
  * flags = MOD16_MATH_EXACT row d is bit-identical to mod16_et_static_* called
  * with the scalars params[d] (r_corr computed, `rcorr` = NULL); MOD16_MATH_FAST
  * uses the strength-reduced arithmetic of the forward run (float64 throughout,
- * within 1e-9 of EXACT, same NaN and zero masks, several times faster -- on finite
- * drivers of physical sign and magnitude, NaN included: this opt-in form has no domain guard;
- * towers' drivers are quality-controlled, the default is EXACT). With `observed` [n] (and optional
+ * within 1e-9 of EXACT, same NaN and zero masks, several times faster); pixels outside that
+ * arithmetic's domain (the test of MOD16_MATH_FAST above, on the drivers) are left out by the
+ * FAST kernels and computed in the reference's operation order behind them, so FAST returns
+ * what EXACT returns for them. With `observed` [n] (and optional
  * `weights` [n]) the call also reduces each draw to
  *     sse[d]   = sum_i (weights[i] * (out_total[d][i] - observed[i]))^2
  *     count[d] = number of pairs used (NaN pairs are skipped),
@@ -411,6 +412,49 @@ MOD16_API int mod16_et_static_batch_f32(mod16_ctx* ctx, const float* const* driv
                         float* out_total, const float* observed,
                         const float* weights, double* sse, double* count,
                         unsigned flags, int where, void* stream);
+
+/*
+ * The same problem RESIDENT on the device: what the reference's MCMC sampler
+ * (calibration.py:907-909) and Sobol analysis (sensitivity.py:94-96) actually do is evaluate
+ * MOD16._et thousands of times on the SAME drivers with new parameter vectors.
+ * mod16_static_batch_bind_* takes the 14 drivers (dstride 0 / 1 as above), the observations
+ * and optional weights once -- where = MOD16_HOST: copied to the device; MOD16_DEVICE: the
+ * caller's device arrays are used in place and must outlive the object -- marks the pixels
+ * outside the FAST domain, and sizes a workspace for up to `max_draws` parameter vectors.
+ *   mod16_static_batch_objective  params [ndraw][11] (HOST, the problem's data type) ->
+ *       sse[ndraw], count[ndraw] (HOST float64, as defined above). One evaluation = the
+ *       parameters up (ndraw x 88 bytes), ONE graph launch, 16 bytes per draw down; nothing of
+ *       size [ndraw][n] exists: the residuals are reduced where they are computed, in a fixed
+ *       order (lanes, waves, blocks: the result does not depend on the schedule). The
+ *       reference's whole-array branch any(g_surf > 0) (mod16/__init__.py:343-348) is resolved
+ *       inside the same launch sequence: every draw is evaluated with transpiration while the
+ *       blocks report whether any pixel has g_surf > 0, and the (normally zero) draws without it
+ *       are evaluated again without. flags = MOD16_MATH_EXACT at bind time: the kernels of the
+ *       unbound call on the resident drivers (bit-identical sums to mod16_et_static_batch_*).
+ *   mod16_static_batch_rows       the [ndraw][n] rows (HOST; day / night / total, any may be
+ *       NULL): the unbound call's kernels on the resident drivers -- bit-identical rows.
+ *   mod16_static_batch_info       n, max_draws and the number of pixels outside the FAST domain.
+ *   mod16_static_batch_time       mean milliseconds of the GPU part of the last-shaped
+ *       objective evaluation (graph replays bracketed by HIP events).
+ * Calls on one object are serialised by its ctx's mutex. Synchronous.
+ */
+typedef struct mod16_batch mod16_batch;
+MOD16_API int mod16_static_batch_bind_f64(mod16_ctx* ctx, const double* const* drivers,
+                        const int64_t* dstride, int64_t n, const double* observed,
+                        const double* weights, int64_t max_draws, unsigned flags, int where,
+                        mod16_batch** out);
+MOD16_API int mod16_static_batch_bind_f32(mod16_ctx* ctx, const float* const* drivers,
+                        const int64_t* dstride, int64_t n, const float* observed,
+                        const float* weights, int64_t max_draws, unsigned flags, int where,
+                        mod16_batch** out);
+MOD16_API int mod16_static_batch_objective(mod16_batch* problem, const void* params, int64_t ndraw,
+                        double* sse, double* count);
+MOD16_API int mod16_static_batch_rows(mod16_batch* problem, const void* params, int64_t ndraw,
+                        void* out_day, void* out_night, void* out_total);
+MOD16_API int mod16_static_batch_info(const mod16_batch* problem, int64_t* n, int64_t* max_draws,
+                        int64_t* n_outside_domain);
+MOD16_API int mod16_static_batch_time(mod16_batch* problem, int launches, float* ms);
+MOD16_API int mod16_static_batch_destroy(mod16_batch* problem);
 
 /*
  * Waits for the ctx's outstanding work on `stream` and reports deferred

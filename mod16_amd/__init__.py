@@ -428,8 +428,10 @@ class MOD16(object):
         equals ``MOD16._et(params[d], *drivers)`` bit for bit -- or, with
         ``separate=True``, ``[day, night]``. ``math=_lib.MATH_FAST`` trades the
         bit-identity for speed: the strength-reduced float64 arithmetic of the
-        forward run, within 1e-9 of the default with the same NaN / zero masks on finite
-        drivers of physical sign and magnitude (this opt-in form has no domain guard). With ``observed`` (and optional
+        forward run, within 1e-9 of the default with the same NaN / zero masks (pixels
+        outside that arithmetic's domain are computed in the reference's order, as in the
+        forward run). A loop over many calls on the same drivers should bind them once:
+        ``MOD16._et_bind``. With ``observed`` (and optional
         ``weights``, both of the drivers' shape) nothing of that size comes
         back: the result is ``(sse, count)``, two float64 arrays (D,) with
         ``sse[d] = sum((weights * (_et_d - observed))**2)`` over the non-NaN
@@ -473,6 +475,32 @@ class MOD16(object):
                          None if separate else adr(outs[0]), None, None, None, None,
                          int(math), _lib.HOST, None))
         return outs if separate else outs[0]
+
+    @staticmethod
+    def _et_bind(lw_net_day, lw_net_night, sw_rad_day, sw_rad_night, sw_albedo,
+                 temp_day, temp_night, temp_annual, tmin, vpd_day, vpd_night,
+                 pressure, fpar, lai, observed=None, weights=None, max_draws=4096,
+                 math=_lib.MATH_FAST, device=0):
+        '''
+        (Extension.) The calibration problem made RESIDENT on the GPU: what the
+        reference's sampler (calibration.py:907-909) and Sobol analysis
+        (sensitivity.py:94-96) do is call ``MOD16._et(params, *drivers)`` thousands
+        of times on the same drivers. Returns a ``BoundCalibration`` holding the
+        drivers (and ``observed`` / ``weights``) on the device; each
+        ``problem.objective(params)`` then moves ``D x 11`` parameters up and
+        ``(sse, count)`` down around one graph launch -- nothing of the drivers'
+        size crosses PCIe again, nothing of size ``D x n`` exists anywhere.
+        ``problem.rows(params)`` gives the ``(D x shape)`` array
+        ``MOD16._et_batch(params, *drivers, math=math)`` gives, bit for bit.
+        ``math``: ``MATH_FAST`` (default here: the strength-reduced float64
+        arithmetic, within 1e-9 of the reference order; pixels outside its domain
+        are computed in the reference's order, as in the forward run) or
+        ``MATH_EXACT``.
+        '''
+        drivers = [lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
+                   sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
+                   vpd_night, pressure, fpar, lai]
+        return BoundCalibration(drivers, observed, weights, max_draws, math, device)
 
     @staticmethod
     def air_density(temp_k, pressure, rhumidity):
@@ -572,6 +600,96 @@ class MOD16(object):
              rhumidity, f_wet],
             self._p('tmin_close', 'tmin_open', 'vpd_open', 'vpd_close', 'gl_sh',
                     'g_cuticular', 'csl'), device=self.device, tiny=tiny)
+
+
+class BoundCalibration(object):
+    '''A calibration problem resident on the GPU (``MOD16._et_bind``;
+    ``mod16_static_batch_bind_*`` of the C ABI).'''
+
+    def __init__(self, drivers, observed, weights, max_draws, math, device):
+        import ctypes as C
+        if weights is not None and observed is None:
+            raise ValueError('weights need observed')
+        extra = [v for v in (observed, weights) if v is not None]
+        self.dtype = _result_dtype(list(drivers) + extra)
+        self.shape = np.broadcast_shapes(*[np.shape(v) for v in list(drivers) + extra])
+        self.n = int(np.prod(self.shape, dtype=np.int64))
+        if self.n == 0:
+            raise ValueError('a calibration problem needs at least one pixel')
+        self.max_draws = int(max_draws)
+        self.math = int(math)
+        self._ctx = _lib.context(device)
+        keep, dptr, dstr = _marshal(drivers, self.shape, self.dtype)
+        full = lambda v: np.ascontiguousarray(np.broadcast_to(np.asarray(v, self.dtype), self.shape))
+        obs = full(observed) if observed is not None else None
+        wts = full(weights) if weights is not None else None
+        self.has_observed = obs is not None
+        fn = self._ctx.lib.mod16_static_batch_bind_f32 if self.dtype == np.float32 \
+            else self._ctx.lib.mod16_static_batch_bind_f64
+        self._handle = C.c_void_p()
+        self._ctx.check(fn(self._ctx.handle, _lib.ptr_array(dptr), _lib.i64_array(dstr), self.n,
+                           obs.ctypes.data if obs is not None else None,
+                           wts.ctypes.data if wts is not None else None,
+                           self.max_draws, self.math, _lib.HOST, C.byref(self._handle)))
+        n_out = C.c_int64(0)
+        self._ctx.check(self._ctx.lib.mod16_static_batch_info(self._handle, None, None, C.byref(n_out)))
+        #: pixels outside the domain of the FAST arithmetic (computed in the reference's order)
+        self.n_outside_domain = n_out.value
+
+    def _params(self, params):
+        par = np.ascontiguousarray(params, self.dtype)
+        if par.ndim != 2 or par.shape[1] != 11:
+            raise IndexError('params must be (D x 11), columns in MOD16.required_parameters order')
+        if par.shape[0] > self.max_draws:
+            raise ValueError('%d parameter vectors, the problem was bound for max_draws = %d'
+                             % (par.shape[0], self.max_draws))
+        return par
+
+    def objective(self, params):
+        '''``(sse, count)``: two float64 arrays (D,) with ``sse[d] = sum((weights *
+        (_et_d - observed))**2)`` over the non-NaN pairs and their number, as
+        ``MOD16._et_batch(params, *drivers, observed=..., weights=...)``; e.g.
+        ``rmsd = np.sqrt(sse / count)``.'''
+        if not self.has_observed:
+            raise ValueError('the problem was bound without observed')
+        par = self._params(params)
+        sse, count = np.zeros(par.shape[0]), np.zeros(par.shape[0])
+        if par.shape[0]:
+            self._ctx.check(self._ctx.lib.mod16_static_batch_objective(
+                self._handle, par.ctypes.data, par.shape[0], sse.ctypes.data, count.ctypes.data))
+        return sse, count
+
+    def rows(self, params, separate=False):
+        '''The (D x shape) array of ``MOD16._et`` per parameter vector (W m-2), or
+        with ``separate`` ``[day, night]`` -- what ``MOD16._et_batch`` returns.'''
+        par = self._params(params)
+        outs = [np.empty((par.shape[0],) + self.shape, self.dtype) for _ in range(2 if separate else 1)]
+        if par.shape[0]:
+            adr = lambda a: a.ctypes.data
+            self._ctx.check(self._ctx.lib.mod16_static_batch_rows(
+                self._handle, par.ctypes.data, par.shape[0],
+                adr(outs[0]) if separate else None, adr(outs[1]) if separate else None,
+                None if separate else adr(outs[0])))
+        return outs if separate else outs[0]
+
+    def gpu_milliseconds(self, launches=10):
+        '''Mean GPU time of one objective evaluation of the last shape (HIP events
+        around graph replays); FAST problems only, after a first ``objective``.'''
+        import ctypes as C
+        ms = C.c_float(0)
+        self._ctx.check(self._ctx.lib.mod16_static_batch_time(self._handle, int(launches), C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if getattr(self, '_handle', None) is not None and self._handle.value:
+            self._ctx.lib.mod16_static_batch_destroy(self._handle)
+            self._handle.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def latent_heat_vaporization(temp_k):

@@ -136,6 +136,17 @@ PROTOTYPES = {
         C.c_void_p, _PP, _I64P, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_uint, C.c_int, C.c_void_p]),
+    'mod16_static_batch_bind_f64': (C.c_int, [
+        C.c_void_p, _PP, _I64P, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint, C.c_int,
+        C.POINTER(C.c_void_p)]),
+    'mod16_static_batch_bind_f32': (C.c_int, [
+        C.c_void_p, _PP, _I64P, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint, C.c_int,
+        C.POINTER(C.c_void_p)]),
+    'mod16_static_batch_objective': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'mod16_static_batch_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mod16_static_batch_info': (C.c_int, [C.c_void_p, _I64P, _I64P, _I64P]),
+    'mod16_static_batch_time': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    'mod16_static_batch_destroy': (C.c_int, [C.c_void_p]),
     'mod16_check_status': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mod16_reduce_diag_f64': (C.c_int, [
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,

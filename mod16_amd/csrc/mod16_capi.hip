@@ -199,6 +199,7 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
         if (const char* g = getenv("MOD16_STREAM_BLOCKS")) ctx->stream_blocks = std::max(1, std::min(2, atoi(g)));
 #endif
         HIPCHK(ctx, hipMalloc(&ctx->dyn_counters, 64 * 128));
+        HIPCHK(ctx, hipMemset(ctx->dyn_counters, 0, 64 * 128));
         const size_t nlut = MOD16_LUT_ROWS * kLutCols;
         HIPCHK(ctx, hipMalloc(&ctx->lut64, nlut * sizeof(double)));
         HIPCHK(ctx, hipMalloc(&ctx->lut32, nlut * sizeof(float)));
@@ -460,9 +461,9 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     const StreamGeom g = stream_geom(ctx, s.n, V, s.tile_shift);
     unsigned long long* ctr = ctx->force_counter ? ctx->force_counter
                                                  : ctx->dyn_counters + 16 * (ctx->dyn_next++ % 64);
-    // the ticket counter of the dynamic schedule; a statically scheduled (small) raster
-    // never reads it, and the fill is a dispatch of its own (4 us + the gap behind it)
-    if (!g.static_sched) HIPCHK(ctx, hipMemsetAsync(ctr, 0, sizeof(unsigned long long), st));
+    // the ticket counter of the dynamic schedule (a statically scheduled raster never reads it):
+    // zero when it was allocated, and every launch leaves it at zero again (the kernel's last
+    // block resets it) -- no memset in front of the kernel, see et_stream_kernel
     s.dyn_counter = ctr;
     s.run_shift = g.run_shift;
     s.static_sched = g.static_sched;
@@ -1001,6 +1002,7 @@ static int graph_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drive
         // caller's streams are still doing to the raster is needed; replays are ordered by
         // the stream they are launched on)
         HIPCHK(ctx, hipMalloc(&g->counter, 128));
+        HIPCHK(ctx, hipMemset(g->counter, 0, 128));       // (not captured: the launches keep it at zero)
         ctx->force_counter = g->counter;
         // the graph's kernel nodes keep pointing at this workspace for as long as
         // the graph lives, whatever the context's own workspace does meanwhile
@@ -1589,6 +1591,49 @@ extern "C" int mod16_et_static_f32(mod16_ctx* ctx, const float* const* drivers,
 }
 
 // ---------------------- calibration path batched over parameter vectors (N2)
+__global__ void zero_u32_kernel(unsigned* p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
+// The device-side pass of the batched calibration path over device pointers: d.drv / d.params /
+// d.out are set; rows [ndraw][n] into d.out, and with dsse the objective from d.out[2]. FAST: the
+// pixels outside the domain of the strength-reduced arithmetic (dskip, [n] bytes of workspace) are
+// left out by the FAST kernels and computed in the reference's operation order behind them.
+template <typename T>
+static int static_batch_rows(mod16_ctx* ctx, StaticBatchArgs<T> d, int64_t ndraw, const T* dobs, const T* dw,
+                             double* dsse, double* dcnt, unsigned* dflags, uint8_t* dskip, unsigned flags,
+                             hipStream_t st, bool skip_ready = false) {
+    const int64_t n = d.n;
+    d.flags = dflags;
+    d.tab = ctx->tab64;
+    d.ndraw = ndraw;
+    const bool fast = (flags & MOD16_MATH_EXACT) == 0;
+    d.skip = fast ? dskip : nullptr;
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((ndraw + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, dflags, ndraw);
+    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, (int64_t)ctx->cus * 8));
+    if (fast && !skip_ready)
+        hipLaunchKernelGGL((static_domain_kernel<T>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, d, dskip);
+    for (int64_t d0 = 0; d0 < ndraw; d0 += 32768 * (int64_t)kBatchDraws) {
+        const unsigned gy = (unsigned)((std::min<int64_t>(32768 * (int64_t)kBatchDraws, ndraw - d0) + kBatchDraws - 1) / kBatchDraws);
+        d.draw0 = d0;
+        if (fast) {
+            hipLaunchKernelGGL((static_batch_flag_fast_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
+            hipLaunchKernelGGL((static_batch_flag_skipped_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
+            hipLaunchKernelGGL((static_batch_fast_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
+            hipLaunchKernelGGL((static_batch_redo_rows_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
+        } else {
+            hipLaunchKernelGGL((static_batch_flag_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
+            hipLaunchKernelGGL((static_batch_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
+        }
+    }
+    if (dsse)
+        hipLaunchKernelGGL((static_batch_sse_kernel<T>), dim3((unsigned)ndraw), dim3(kBlock), 0, st,
+                           d.out[2], dobs, dw, n, dsse, dcnt);
+    HIPCHK(ctx, hipGetLastError());
+    return MOD16_OK;
+}
+
 template <typename T>
 static int static_batch_entry(mod16_ctx* ctx, const T* const* drivers, const int64_t* dstride,
                               int64_t n, const T* params, int64_t ndraw, T* out_day, T* out_night,
@@ -1614,42 +1659,19 @@ static int static_batch_entry(mod16_ctx* ctx, const T* const* drivers, const int
     a.n = n;
     if (n == 0 || ndraw == 0) return MOD16_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    // device-side pass over device pointers
-    auto run = [&](StaticBatchArgs<T> d, const T* dobs, const T* dw, double* dsse, double* dcnt,
-                   unsigned* dflags, hipStream_t st) -> int {
-        d.flags = dflags;
-        d.tab = ctx->tab64;
-        const bool fast = (flags & MOD16_MATH_EXACT) == 0;
-        HIPCHK(ctx, hipMemsetAsync(dflags, 0, sizeof(unsigned) * ndraw, st));
-        const int gx = (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, (int64_t)ctx->cus * 8));
-        d.ndraw = ndraw;
-        for (int64_t d0 = 0; d0 < ndraw; d0 += 32768 * (int64_t)kBatchDraws) {
-            const unsigned gy = (unsigned)((std::min<int64_t>(32768 * (int64_t)kBatchDraws, ndraw - d0) + kBatchDraws - 1) / kBatchDraws);
-            d.draw0 = d0;
-            if (fast) {
-                hipLaunchKernelGGL((static_batch_flag_fast_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
-                hipLaunchKernelGGL((static_batch_fast_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
-            } else {
-                hipLaunchKernelGGL((static_batch_flag_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
-                hipLaunchKernelGGL((static_batch_kernel<T>), dim3(gx, gy), dim3(kBlock), 0, st, d);
-            }
-        }
-        if (dsse)
-            hipLaunchKernelGGL((static_batch_sse_kernel<T>), dim3((unsigned)ndraw), dim3(kBlock), 0, st,
-                               d.out[2], dobs, dw, n, dsse, dcnt);
-        HIPCHK(ctx, hipGetLastError());
-        return MOD16_OK;
-    };
     if (ndraw > 0x7fffffff) return fail(ctx, MOD16_ERR_ARG, "mod16_et_static_batch: too many draws");
     if (where == MOD16_DEVICE) {
         hipStream_t st = static_cast<hipStream_t>(stream);
         unsigned* dflags = nullptr;
-        // flags: a per-call allocation freed on the stream (asynchronous)
+        uint8_t* dskip = nullptr;
+        // flags and the domain mask: per-call allocations freed on the stream (asynchronous)
         HIPCHK(ctx, hipMallocAsync(reinterpret_cast<void**>(&dflags), sizeof(unsigned) * ndraw, st));
+        HIPCHK(ctx, hipMallocAsync(reinterpret_cast<void**>(&dskip), (size_t)n, st));
         a.params = params;
         a.out[0] = out_day; a.out[1] = out_night; a.out[2] = out_total;
-        int rc = run(a, observed, weights, sse, count, dflags, st);
+        int rc = static_batch_rows<T>(ctx, a, ndraw, observed, weights, sse, count, dflags, dskip, flags, st);
         (void)hipFreeAsync(dflags, st);
+        (void)hipFreeAsync(dskip, st);
         return rc;
     }
     if (where != MOD16_HOST) return fail(ctx, MOD16_ERR_ARG, "mod16_et_static_batch: bad `where`");
@@ -1663,10 +1685,12 @@ static int static_batch_entry(mod16_ctx* ctx, const T* const* drivers, const int
     const size_t par_b = (((size_t)ndraw * 11 * sizeof(T)) + 255) / 256 * 256;
     const size_t red_b = (((size_t)ndraw * sizeof(double)) + 255) / 256 * 256;
     const size_t flag_b = (((size_t)ndraw * sizeof(unsigned)) + 255) / 256 * 256;
-    const size_t total = per_arr * 16 + par_b + 2 * red_b + flag_b +
+    const size_t skip_b = ((size_t)n + 255) / 256 * 256;
+    const size_t total = per_arr * 16 + par_b + 2 * red_b + flag_b + skip_b +
                          per_out * ((int)want[0] + (int)want[1] + (int)want[2]);
     // workspace kept in the context between calls (a calibration loop repeats the same
-    // shape thousands of times); it only grows, up to kBatchKeepBytes it is kept
+    // shape thousands of times -- better still: mod16_static_batch_bind_*); it only grows, up to
+    // kBatchKeepBytes it is kept
     constexpr size_t kBatchKeepBytes = size_t(8) << 30;
     if (ctx->batch_bytes < total) {
         if (ctx->batch_buf) HIPCHK(ctx, hipFree(ctx->batch_buf));
@@ -1700,8 +1724,11 @@ static int static_batch_entry(mod16_ctx* ctx, const T* const* drivers, const int
     double* dsse = reinterpret_cast<double*>(take(red_b));
     double* dcnt = reinterpret_cast<double*>(take(red_b));
     unsigned* dflags = reinterpret_cast<unsigned*>(take(flag_b));
+    uint8_t* dskip = reinterpret_cast<uint8_t*>(take(skip_b));
     for (int k = 0; k < 3; ++k) d.out[k] = want[k] ? reinterpret_cast<T*>(take(per_out)) : nullptr;
-    if (rc == MOD16_OK) rc = run(d, dobs, (sse && weights) ? dw : nullptr, sse ? dsse : nullptr, dcnt, dflags, st);
+    if (rc == MOD16_OK)
+        rc = static_batch_rows<T>(ctx, d, ndraw, dobs, (sse && weights) ? dw : nullptr, sse ? dsse : nullptr, dcnt,
+                                  dflags, dskip, flags, st);
     if (rc == MOD16_OK) {
         for (int k = 0; k < 3; ++k)
             if (host_out[k]) chk(hipMemcpyAsync(host_out[k], d.out[k], sizeof(T) * n * ndraw, hipMemcpyDeviceToHost, st));
@@ -1738,6 +1765,347 @@ extern "C" int mod16_et_static_batch_f32(mod16_ctx* ctx, const float* const* dri
     MOD16_LOCK(ctx);
     return static_batch_entry<float>(ctx, drivers, dstride, n, params, ndraw, out_day, out_night,
                                      out_total, observed, weights, sse, count, flags, where, stream);
+}
+
+// ---- the calibration problem RESIDENT on the device (mod16_static_batch_bind_*): drivers,
+// observations and weights go up once; an evaluation is parameters up, one graph launch (kernels
+// only), (sse, count) down.
+struct mod16_batch {
+    mod16_ctx* ctx = nullptr;
+    int device = 0;
+    bool f32 = false;
+    unsigned flags = 0;
+    int64_t n = 0, max_draws = 0;
+    int gx = 0;
+    void* owned = nullptr;              // the resident copies (HOST bind); NULL when the caller's device arrays are used
+    const void* drv[14] = {};
+    uint32_t dense_drv = 0;
+    const void* obs = nullptr;
+    const void* wts = nullptr;
+    uint8_t* skip = nullptr;            // [n]: 1 = outside the FAST domain
+    int64_t* list = nullptr;            // those pixels, ascending
+    int64_t nlist = 0;
+    void* ws = nullptr;                 // evaluation workspace (one allocation)
+    void* dparams = nullptr;            // [max_draws][11] of the data type
+    double *par16 = nullptr, *partial = nullptr, *redo = nullptr, *dsse = nullptr, *dcnt = nullptr;
+    unsigned *any_gs = nullptr, *any_draw = nullptr, *dflags = nullptr;
+    void* rows = nullptr;               // [ndraw][n] x up to 3: rows workspace, allocated when first asked for
+    size_t rows_bytes = 0;
+    void* hparams = nullptr;            // pinned staging
+    double* hout = nullptr;             // pinned [2][max_draws]
+    hipStream_t st = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int64_t graph_ndraw = -1;
+};
+
+extern "C" int mod16_static_batch_destroy(mod16_batch* b) {
+    if (!b) return MOD16_OK;
+    (void)hipSetDevice(b->device);
+    if (b->st) (void)hipStreamSynchronize(b->st);
+    if (b->exec) (void)hipGraphExecDestroy(b->exec);
+    if (b->graph) (void)hipGraphDestroy(b->graph);
+    if (b->owned) (void)hipFree(b->owned);
+    if (b->skip) (void)hipFree(b->skip);
+    if (b->list) (void)hipFree(b->list);
+    if (b->ws) (void)hipFree(b->ws);
+    if (b->rows) (void)hipFree(b->rows);
+    if (b->hparams) (void)hipHostFree(b->hparams);
+    if (b->hout) (void)hipHostFree(b->hout);
+    if (b->st) (void)hipStreamDestroy(b->st);
+    delete b;
+    return MOD16_OK;
+}
+
+template <typename T>
+static StaticBatchArgs<T> batch_args(const mod16_batch* b) {
+    StaticBatchArgs<T> a;
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < 14; ++k) a.drv[k] = static_cast<const T*>(b->drv[k]);
+    a.dense_drv = b->dense_drv;
+    a.n = b->n;
+    a.params = static_cast<const T*>(b->dparams);
+    return a;
+}
+
+template <typename T>
+static int batch_bind(mod16_ctx* ctx, const T* const* drivers, const int64_t* dstride, int64_t n,
+                      const T* observed, const T* weights, int64_t max_draws, unsigned flags, int where,
+                      mod16_batch** out) {
+    if (!ctx || !out) return MOD16_ERR_ARG;
+    *out = nullptr;
+    if (!drivers || !dstride || n <= 0 || max_draws <= 0 || max_draws > 0x7fffffff)
+        return fail(ctx, MOD16_ERR_ARG, "mod16_static_batch_bind: NULL drivers, n <= 0 or max_draws out of range");
+    if (weights && !observed) return fail(ctx, MOD16_ERR_ARG, "mod16_static_batch_bind: weights need observed");
+    if (where != MOD16_HOST && where != MOD16_DEVICE) return fail(ctx, MOD16_ERR_ARG, "mod16_static_batch_bind: bad `where`");
+    for (int k = 0; k < 14; ++k) {
+        if (!drivers[k]) return fail(ctx, MOD16_ERR_ARG, "mod16_static_batch_bind: NULL driver");
+        if (dstride[k] != 0 && dstride[k] != 1) return fail(ctx, MOD16_ERR_ARG, "mod16_static_batch_bind: driver stride must be 0 or 1");
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    mod16_batch* b = new (std::nothrow) mod16_batch;
+    if (!b) return MOD16_ERR_NOMEM;
+    b->ctx = ctx;
+    b->device = ctx->device;
+    b->f32 = std::is_same<T, float>::value;
+    b->flags = flags;
+    b->n = n;
+    b->max_draws = max_draws;
+    b->gx = (int)((n + kBlock - 1) / kBlock);
+    int rc = [&]() -> int {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking));
+        const size_t per_arr = (((size_t)n * sizeof(T)) + 255) / 256 * 256;
+        for (int k = 0; k < 14; ++k) if (dstride[k]) b->dense_drv |= 1u << k;
+        if (where == MOD16_HOST) {
+            HIPCHK(ctx, hipMalloc(&b->owned, per_arr * 16));
+            char* base = static_cast<char*>(b->owned);
+            for (int k = 0; k < 14; ++k) {
+                HIPCHK(ctx, hipMemcpyAsync(base + per_arr * k, drivers[k], sizeof(T) * (dstride[k] ? n : 1), hipMemcpyHostToDevice, b->st));
+                b->drv[k] = base + per_arr * k;
+            }
+            if (observed) {
+                HIPCHK(ctx, hipMemcpyAsync(base + per_arr * 14, observed, sizeof(T) * n, hipMemcpyHostToDevice, b->st));
+                b->obs = base + per_arr * 14;
+            }
+            if (weights) {
+                HIPCHK(ctx, hipMemcpyAsync(base + per_arr * 15, weights, sizeof(T) * n, hipMemcpyHostToDevice, b->st));
+                b->wts = base + per_arr * 15;
+            }
+        } else {
+            for (int k = 0; k < 14; ++k) b->drv[k] = drivers[k];
+            b->obs = observed;
+            b->wts = weights;
+        }
+        // evaluation workspace
+        const int64_t D = max_draws;
+        auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+        const size_t sz_par = al((size_t)D * 11 * sizeof(T)), sz_p16 = al((size_t)D * kPar16 * 8),
+                     sz_part = al((size_t)D * b->gx * 16), sz_any = al((size_t)D * b->gx * 4),
+                     sz_d = al((size_t)D * 8), sz_redo = al((size_t)D * 40), sz_u = al((size_t)D * 4);
+        HIPCHK(ctx, hipMalloc(&b->ws, sz_par + sz_p16 + sz_part + sz_any + 2 * sz_d + sz_redo + 2 * sz_u));
+        char* cur = static_cast<char*>(b->ws);
+        auto take = [&](size_t x) { char* p = cur; cur += x; return p; };
+        b->dparams = take(sz_par);
+        b->par16 = reinterpret_cast<double*>(take(sz_p16));
+        b->partial = reinterpret_cast<double*>(take(sz_part));
+        b->any_gs = reinterpret_cast<unsigned*>(take(sz_any));
+        b->dsse = reinterpret_cast<double*>(take(sz_d));
+        b->dcnt = reinterpret_cast<double*>(take(sz_d));
+        b->redo = reinterpret_cast<double*>(take(sz_redo));
+        b->any_draw = reinterpret_cast<unsigned*>(take(sz_u));
+        b->dflags = reinterpret_cast<unsigned*>(take(sz_u));
+        HIPCHK(ctx, hipHostMalloc(&b->hparams, (size_t)D * 11 * sizeof(T)));
+        HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&b->hout), (size_t)D * 16));
+        // the pixels outside the domain of the FAST arithmetic: marked once, listed in ascending order
+        HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&b->skip), (size_t)n));
+        StaticBatchArgs<T> a = batch_args<T>(b);
+        hipLaunchKernelGGL((static_domain_kernel<T>), dim3((unsigned)b->gx), dim3(kBlock), 0, b->st, a, b->skip);
+        HIPCHK(ctx, hipGetLastError());
+        std::vector<uint8_t> mask((size_t)n);
+        HIPCHK(ctx, hipMemcpyAsync(mask.data(), b->skip, (size_t)n, hipMemcpyDeviceToHost, b->st));
+        HIPCHK(ctx, hipStreamSynchronize(b->st));
+        std::vector<int64_t> list;
+        for (int64_t i = 0; i < n; ++i) if (mask[(size_t)i]) list.push_back(i);
+        b->nlist = (int64_t)list.size();
+        if (b->nlist) {
+            HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&b->list), sizeof(int64_t) * list.size()));
+            HIPCHK(ctx, hipMemcpy(b->list, list.data(), sizeof(int64_t) * list.size(), hipMemcpyHostToDevice));
+        }
+        return MOD16_OK;
+    }();
+    if (rc != MOD16_OK) {
+        mod16_static_batch_destroy(b);
+        return rc;
+    }
+    *out = b;
+    return MOD16_OK;
+}
+
+extern "C" int mod16_static_batch_bind_f64(mod16_ctx* ctx, const double* const* drivers, const int64_t* dstride,
+                                           int64_t n, const double* observed, const double* weights,
+                                           int64_t max_draws, unsigned flags, int where, mod16_batch** out) {
+    MOD16_LOCK(ctx);
+    return batch_bind<double>(ctx, drivers, dstride, n, observed, weights, max_draws, flags, where, out);
+}
+extern "C" int mod16_static_batch_bind_f32(mod16_ctx* ctx, const float* const* drivers, const int64_t* dstride,
+                                           int64_t n, const float* observed, const float* weights,
+                                           int64_t max_draws, unsigned flags, int where, mod16_batch** out) {
+    MOD16_LOCK(ctx);
+    return batch_bind<float>(ctx, drivers, dstride, n, observed, weights, max_draws, flags, where, out);
+}
+
+extern "C" int mod16_static_batch_info(const mod16_batch* b, int64_t* n, int64_t* max_draws, int64_t* n_outside_domain) {
+    if (!b) return MOD16_ERR_ARG;
+    if (n) *n = b->n;
+    if (max_draws) *max_draws = b->max_draws;
+    if (n_outside_domain) *n_outside_domain = b->nlist;
+    return MOD16_OK;
+}
+
+// the kernels of one objective evaluation (FAST arithmetic), enqueued on b->st
+template <typename T>
+static void batch_objective_launches(mod16_batch* b, int64_t ndraw) {
+    hipStream_t st = b->st;
+    const unsigned gd = (unsigned)((ndraw + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((static_obj_params_kernel<T>), dim3(gd), dim3(kBlock), 0, st, static_cast<const T*>(b->dparams), ndraw, b->par16);
+    StaticObjArgs<T> a;
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < 14; ++k) a.drv[k] = static_cast<const T*>(b->drv[k]);
+    a.dense_drv = b->dense_drv;
+    a.n = b->n;
+    a.observed = static_cast<const T*>(b->obs);
+    a.weights = static_cast<const T*>(b->wts);
+    a.skip = b->nlist ? b->skip : nullptr;
+    a.par16 = b->par16;
+    a.tab = b->ctx->tab64;
+    a.ndraw = ndraw;
+    a.any_draw = b->any_draw;
+    a.partial = b->partial;
+    a.any_gs = b->any_gs;
+    const dim3 grid((unsigned)b->gx, (unsigned)((ndraw + kObjDraws - 1) / kObjDraws));
+    hipLaunchKernelGGL((static_obj_kernel<T, true>), grid, dim3(kBlock), 0, st, a);
+    if (b->nlist) {
+        StaticObjRedoArgs<T> r;
+        memset(&r, 0, sizeof r);
+        for (int k = 0; k < 14; ++k) r.drv[k] = static_cast<const T*>(b->drv[k]);
+        r.dense_drv = b->dense_drv;
+        r.params = static_cast<const T*>(b->dparams);
+        r.observed = a.observed;
+        r.weights = a.weights;
+        r.list = b->list;
+        r.nlist = b->nlist;
+        r.redo = b->redo;
+        hipLaunchKernelGGL((static_obj_redo_kernel<T>), dim3((unsigned)ndraw), dim3(kBlock), 0, st, r);
+    }
+    const double* redo = b->nlist ? b->redo : nullptr;
+    hipLaunchKernelGGL(static_obj_any_kernel, dim3(gd), dim3(kBlock), 0, st, b->any_gs, redo, ndraw, b->gx, b->any_draw);
+    hipLaunchKernelGGL((static_obj_kernel<T, false>), grid, dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL(static_obj_final_kernel, dim3(gd), dim3(kBlock), 0, st, b->partial, redo, b->any_draw, ndraw, b->gx,
+                       b->dsse, b->dcnt);
+}
+
+template <typename T>
+static int batch_objective(mod16_batch* b, const T* params, int64_t ndraw, double* sse, double* count) {
+    mod16_ctx* ctx = b->ctx;
+    if (!params || !sse || !count || ndraw < 0 || ndraw > b->max_draws)
+        return fail(ctx, MOD16_ERR_ARG, "mod16_static_batch_objective: NULL argument or more draws than the problem was bound for");
+    if (!b->obs) return fail(ctx, MOD16_ERR_ARG, "mod16_static_batch_objective: the problem was bound without observations");
+    if (ndraw == 0) return MOD16_OK;
+    HIPCHK(ctx, hipSetDevice(b->device));
+    memcpy(b->hparams, params, sizeof(T) * (size_t)ndraw * 11);
+    HIPCHK(ctx, hipMemcpyAsync(b->dparams, b->hparams, sizeof(T) * (size_t)ndraw * 11, hipMemcpyHostToDevice, b->st));
+    if (b->flags & MOD16_MATH_EXACT) {
+        // reference order: rows into a workspace, then the residuals' sums (the kernels of the unbound call)
+        const size_t need = sizeof(T) * (size_t)ndraw * (size_t)b->n;
+        if (b->rows_bytes < need) {
+            if (b->rows) HIPCHK(ctx, hipFree(b->rows));
+            b->rows = nullptr;
+            b->rows_bytes = 0;
+            if (hipMalloc(&b->rows, need) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(ctx, MOD16_ERR_NOMEM, "mod16_static_batch_objective: device memory for the [ndraw][n] rows");
+            }
+            b->rows_bytes = need;
+        }
+        StaticBatchArgs<T> a = batch_args<T>(b);
+        a.out[2] = static_cast<T*>(b->rows);
+        int rc = static_batch_rows<T>(ctx, a, ndraw, static_cast<const T*>(b->obs), static_cast<const T*>(b->wts), b->dsse, b->dcnt,
+                                      b->dflags, b->skip, b->flags, b->st, true);
+        if (rc != MOD16_OK) return rc;
+    } else {
+        if (b->graph_ndraw != ndraw) {          // (re)capture: the kernels' arguments hold the number of draws
+            if (b->exec) (void)hipGraphExecDestroy(b->exec);
+            if (b->graph) (void)hipGraphDestroy(b->graph);
+            b->exec = nullptr;
+            b->graph = nullptr;
+            b->graph_ndraw = -1;
+            HIPCHK(ctx, hipStreamBeginCapture(b->st, hipStreamCaptureModeThreadLocal));
+            batch_objective_launches<T>(b, ndraw);
+            hipError_t e = hipStreamEndCapture(b->st, &b->graph);
+            HIPCHK(ctx, e);
+            HIPCHK(ctx, hipGraphInstantiate(&b->exec, b->graph, nullptr, nullptr, 0));
+            b->graph_ndraw = ndraw;
+        }
+        HIPCHK(ctx, hipGraphLaunch(b->exec, b->st));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(b->hout, b->dsse, sizeof(double) * (size_t)ndraw, hipMemcpyDeviceToHost, b->st));
+    HIPCHK(ctx, hipMemcpyAsync(b->hout + b->max_draws, b->dcnt, sizeof(double) * (size_t)ndraw, hipMemcpyDeviceToHost, b->st));
+    HIPCHK(ctx, hipStreamSynchronize(b->st));
+    memcpy(sse, b->hout, sizeof(double) * (size_t)ndraw);
+    memcpy(count, b->hout + b->max_draws, sizeof(double) * (size_t)ndraw);
+    return MOD16_OK;
+}
+
+extern "C" int mod16_static_batch_objective(mod16_batch* b, const void* params, int64_t ndraw, double* sse, double* count) {
+    if (!b) return MOD16_ERR_ARG;
+    MOD16_LOCK(b->ctx);
+    return b->f32 ? batch_objective<float>(b, static_cast<const float*>(params), ndraw, sse, count)
+                  : batch_objective<double>(b, static_cast<const double*>(params), ndraw, sse, count);
+}
+
+// rows [ndraw][n] (host) of the bound problem: the kernels of the unbound call on the resident drivers
+template <typename T>
+static int batch_rows(mod16_batch* b, const T* params, int64_t ndraw, T* out_day, T* out_night, T* out_total) {
+    mod16_ctx* ctx = b->ctx;
+    if (!params || ndraw < 0 || ndraw > b->max_draws || (!out_day && !out_night && !out_total))
+        return fail(ctx, MOD16_ERR_ARG, "mod16_static_batch_rows: NULL argument, no output or more draws than the problem was bound for");
+    if (ndraw == 0) return MOD16_OK;
+    HIPCHK(ctx, hipSetDevice(b->device));
+    T* const host_out[3] = {out_day, out_night, out_total};
+    const size_t per_out = (sizeof(T) * (size_t)ndraw * (size_t)b->n + 255) / 256 * 256;
+    const size_t need = per_out * ((out_day != nullptr) + (out_night != nullptr) + (out_total != nullptr));
+    if (b->rows_bytes < need) {
+        if (b->rows) HIPCHK(ctx, hipFree(b->rows));
+        b->rows = nullptr;
+        b->rows_bytes = 0;
+        if (hipMalloc(&b->rows, need) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(ctx, MOD16_ERR_NOMEM, "mod16_static_batch_rows: device memory for the [ndraw][n] rows");
+        }
+        b->rows_bytes = need;
+    }
+    memcpy(b->hparams, params, sizeof(T) * (size_t)ndraw * 11);
+    HIPCHK(ctx, hipMemcpyAsync(b->dparams, b->hparams, sizeof(T) * (size_t)ndraw * 11, hipMemcpyHostToDevice, b->st));
+    StaticBatchArgs<T> a = batch_args<T>(b);
+    char* cur = static_cast<char*>(b->rows);
+    for (int k = 0; k < 3; ++k)
+        if (host_out[k]) { a.out[k] = reinterpret_cast<T*>(cur); cur += per_out; }
+    int rc = static_batch_rows<T>(ctx, a, ndraw, nullptr, nullptr, nullptr, nullptr, b->dflags, b->skip, b->flags, b->st, true);
+    if (rc != MOD16_OK) return rc;
+    for (int k = 0; k < 3; ++k)
+        if (host_out[k]) HIPCHK(ctx, hipMemcpyAsync(host_out[k], a.out[k], sizeof(T) * (size_t)ndraw * (size_t)b->n, hipMemcpyDeviceToHost, b->st));
+    HIPCHK(ctx, hipStreamSynchronize(b->st));
+    return MOD16_OK;
+}
+
+extern "C" int mod16_static_batch_rows(mod16_batch* b, const void* params, int64_t ndraw, void* out_day, void* out_night,
+                                       void* out_total) {
+    if (!b) return MOD16_ERR_ARG;
+    MOD16_LOCK(b->ctx);
+    return b->f32 ? batch_rows<float>(b, static_cast<const float*>(params), ndraw, static_cast<float*>(out_day),
+                                      static_cast<float*>(out_night), static_cast<float*>(out_total))
+                  : batch_rows<double>(b, static_cast<const double*>(params), ndraw, static_cast<double*>(out_day),
+                                       static_cast<double*>(out_night), static_cast<double*>(out_total));
+}
+
+// mean milliseconds of the GPU part of an objective evaluation (graph replays on the problem's
+// stream, HIP events): what bench.py puts next to the wall-clock rate of the call
+extern "C" int mod16_static_batch_time(mod16_batch* b, int launches, float* ms) {
+    if (!b || !ms || launches <= 0 || !b->exec) return MOD16_ERR_ARG;
+    MOD16_LOCK(b->ctx);
+    if (hipSetDevice(b->device) != hipSuccess) return MOD16_ERR_HIP;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return MOD16_ERR_HIP;
+    bool ok = hipEventRecord(e0, b->st) == hipSuccess;
+    for (int i = 0; i < launches && ok; ++i) ok = hipGraphLaunch(b->exec, b->st) == hipSuccess;
+    ok = ok && hipEventRecord(e1, b->st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+    float t = 0.f;
+    ok = ok && hipEventElapsedTime(&t, e0, e1) == hipSuccess;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (!ok) return MOD16_ERR_HIP;
+    *ms = t / (float)launches;
+    return MOD16_OK;
 }
 
 // ------------------------------------------------------------- diagnostics
@@ -2049,6 +2417,7 @@ static int graph_tiled_entry(mod16_ctx* ctx, const mod16_layout* lay, const uint
         // caller's streams are still doing to the raster is needed; replays are ordered by
         // the stream they are launched on)
         HIPCHK(ctx, hipMalloc(&g->counter, 128));
+        HIPCHK(ctx, hipMemset(g->counter, 0, 128));       // (not captured: the launches keep it at zero)
         ctx->force_counter = g->counter;
         int pv = 0, tsh = lay->tile > 0 ? tile_log2(lay->tile, 1) : -1;
         while ((1 << pv) < 64 * VecOf<T>::v) ++pv;

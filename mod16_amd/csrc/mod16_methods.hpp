@@ -214,6 +214,8 @@ template <typename T> struct StaticBatchArgs {
     const double* tab;       // exp / log tables of FastMath<double> (FAST kernels)
     uint32_t dense_drv;
     unsigned* flags;         // [ndraw] words: bit 0 = any(g_surf > 0) for that draw
+    const uint8_t* skip;     // FAST kernels: [n] or NULL, 1 = pixel outside the FAST domain (left to the
+                             // reference-order kernels static_batch_flag_list_kernel / static_batch_redo_rows_kernel)
 };
 
 template <typename T>
@@ -297,11 +299,12 @@ __global__ void __launch_bounds__(kBlock) static_batch_flag_fast_kernel(const St
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += step) {
         PixelIn<double> x;
         batch_load_fast(a, i, x);
+        const bool skipped = a.skip && a.skip[i];
         const StaticPixel c = static_pixel_prep(x, tab);
         for (int64_t draw = d0; draw < d1; ++draw) {
             const ClassPar<double> p = batch_params_fast(a, draw);
             const StaticDraw d = static_draw_prep(c, p);
-            const bool any = static_gsurf(c.d, d, p) > 0.0;
+            const bool any = !skipped && static_gsurf(c.d, d, p) > 0.0;
             if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(a.flags + draw, 1u);
         }
     }
@@ -317,6 +320,7 @@ __global__ void __launch_bounds__(kBlock) static_batch_fast_kernel(const StaticB
     const int64_t d1 = (d0 + kBatchDraws < a.ndraw) ? d0 + kBatchDraws : a.ndraw;
     const int64_t step = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += step) {
+        if (a.skip && a.skip[i]) continue;          // static_batch_redo_rows_kernel writes this pixel's rows
         PixelIn<double> x;
         batch_load_fast(a, i, x);
         const StaticPixel c = static_pixel_prep(x, tab);
@@ -363,6 +367,314 @@ __global__ void __launch_bounds__(kBlock) static_batch_sse_kernel(const T* total
         for (int w = 1; w < kBlock / 64; ++w) { s += sm[0][w]; c += sm[1][w]; }
         sse[blockIdx.x] = s;
         cnt[blockIdx.x] = c;
+    }
+}
+
+// ---- the calibration objective on RESIDENT drivers (mod16_static_batch_bind_*):
+// what an MCMC chain or a Sobol analysis (reference calibration.py:907-909, sensitivity.py:94-96)
+// evaluates thousands of times on the same drivers. Per evaluation only the parameter vectors go
+// up and (sse, count) per draw come back; nothing of size [ndraw][n] exists. One launch
+// evaluates every (draw, pixel) pair with the FAST arithmetic and reduces the residuals in a
+// fixed order:
+//   static_obj_params_kernel   the 11 parameters of a draw + what depends on them alone (three
+//                              reciprocals, the rbl slope, the G threshold) -> 16 doubles per draw
+//   static_obj_kernel<TR>      thread = pixel, 32 consecutive draws; residual r = w (et - obs),
+//                              per-draw sums over the wave's 64 pixels through LDS (lane order),
+//                              over the block's waves in order -> one partial per (draw, block)
+//   static_obj_redo_kernel     the pixels outside the domain of the FAST arithmetic (marked once,
+//                              at bind time), per draw in the reference's operation order
+//   static_obj_any_kernel      any(g_surf > 0) per draw over all blocks (the reference's
+//                              whole-array branch, mod16/__init__.py:343-348)
+//   static_obj_kernel<false>   the draws without it, evaluated again without transpiration (normally
+//                              none: every block reads 32 flags and ends)
+//   static_obj_final_kernel    partials of a draw added up in block order -> sse[d], count[d]
+constexpr int kObjDraws = 32;
+constexpr int kObjPass = 16;     // draws reduced at a time (LDS: 16 x 64 doubles per wave)
+constexpr int kPar16 = 16;       // doubles per draw: 11 parameters, 1 / (tmin_open - tmin_close), 1 / (vpd_close -
+                                 // vpd_open), rbl slope, 1 / beta, 273.15 + tmin_open
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) static_obj_params_kernel(const T* params, int64_t ndraw, double* par16) {
+    const int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (d >= ndraw) return;
+    typedef FastMath<double> M;
+    const T* q = params + d * 11;
+    double* o = par16 + d * kPar16;
+    double p[11];
+    for (int k = 0; k < 11; ++k) o[k] = p[k] = (double)q[k];
+    // the same operations static_draw_prep performs (so that rows and objective share their bits)
+    o[11] = M::rcp(p[1] - p[0]);
+    o[12] = M::rcp(p[3] - p[2]);
+    o[13] = (p[9] - p[8]) * o[12];
+    o[14] = M::rcp(p[10]);
+    o[15] = 273.15 + p[1];
+}
+
+template <typename T> struct StaticObjArgs {
+    const T* drv[14];
+    uint32_t dense_drv;
+    int64_t n;
+    const T* observed;          // [n]
+    const T* weights;           // [n] or NULL
+    const uint8_t* skip;        // [n] or NULL: 1 = pixel outside the FAST domain (static_obj_redo_kernel takes it)
+    const double* par16;        // [ndraw][kPar16]
+    const double* tab;
+    int64_t ndraw;
+    const unsigned* any_draw;   // TR = false: [ndraw], only the draws with 0 here are evaluated
+    double* partial;            // [gridDim.x][ndraw][2]: sse, count
+    unsigned* any_gs;           // TR = true: [gridDim.x][ndraw], 1 = a pixel of the block has g_surf > 0
+};
+
+// TR: evaluate with the transpiration term (any(g_surf > 0) assumed true; the block also reports
+// whether one of ITS pixels has g_surf > 0). !TR: only the draws for which no block reported one,
+// transpiration = 0 (mod16/__init__.py:343-348) -- normally none: the block reads 32 flags and ends.
+template <typename T, bool TR>
+__global__ void __launch_bounds__(kBlock) static_obj_kernel(const StaticObjArgs<T> a) {
+    constexpr int kTab = FastMath<double>::kTabDoubles;
+    constexpr int kWaves = kBlock / 64;
+    __shared__ __attribute__((aligned(16))) double tab[kTab];
+    __shared__ double red[kWaves][kObjPass][64];     // 32 KiB a block
+    __shared__ double wsum[kWaves][kObjDraws][2];
+    __shared__ unsigned wany[kWaves][kObjDraws];
+    __shared__ unsigned todo;
+    const int64_t c0 = (int64_t)blockIdx.y * kObjDraws;
+    const int64_t c1 = c0 + kObjDraws < a.ndraw ? c0 + kObjDraws : a.ndraw;
+    const int nd = (int)(c1 - c0);
+    unsigned want = nd >= 32 ? 0xffffffffu : ((1u << nd) - 1u);     // bit j: evaluate draw c0 + j
+    if (!TR) {
+        if (threadIdx.x == 0) todo = 0u;
+        __syncthreads();
+        if ((int)threadIdx.x < nd && !a.any_draw[c0 + threadIdx.x]) atomicOr(&todo, 1u << threadIdx.x);
+        __syncthreads();
+        want = todo;
+        if (want == 0u) return;
+    }
+    for (int i = threadIdx.x; i < kTab; i += kBlock) tab[i] = a.tab[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < a.n && !(a.skip && a.skip[i]);
+    StaticPixel c;
+    double obs = 0.0, w = 1.0;
+    if (live) {
+        auto dv = [&](int k) { return (double)(((a.dense_drv >> k) & 1u) ? a.drv[k][i] : a.drv[k][0]); };
+        const PixelIn<double> x = {dv(0), dv(1), dv(2), dv(3), dv(4), dv(5), dv(6), dv(7), dv(8), dv(9), dv(10), dv(11), dv(12), dv(13)};
+        c = static_pixel_prep(x, tab);
+        obs = (double)a.observed[i];
+        w = a.weights ? (double)a.weights[i] : 1.0;
+    }
+    unsigned cnt = 0;            // bit j: draw c0 + j has a pair (the residual is a number) at this pixel
+    unsigned gs = 0;             // bit j: g_surf > 0 at this pixel for draw c0 + j
+#pragma unroll 1
+    for (int h = 0; h < kObjDraws; h += kObjPass) {
+#pragma unroll 1
+        for (int jj = 0; jj < kObjPass; ++jj) {
+            const int j = h + jj;
+            double r2 = 0.0;
+            if (live && ((want >> j) & 1u)) {
+                const double* q = a.par16 + (c0 + j) * kPar16;       // block-uniform: scalar loads
+                ClassPar<double> p;
+                p.tmin_close = q[0]; p.tmin_open = q[1]; p.vpd_open = q[2]; p.vpd_close = q[3];
+                p.gl_sh = q[4]; p.gl_wv = q[5]; p.g_cut = q[6]; p.csl = q[7];
+                p.rbl_min = q[8]; p.rbl_max = q[9]; p.beta = q[10];
+                StaticDraw d;
+                d.m_tmin = (c.tm >= p.tmin_open) ? 1.0
+                           : ((c.tm < p.tmin_close) ? 0.0 : (c.tm - p.tmin_close) * q[11]);
+                d.inv_dvpd = q[12];
+                d.rbl_slope = q[13];
+                d.inv_beta = q[14];
+                d.cond = c.base_cond && (c.t_ann > q[15]);                    // :230-234 (tmin_open, strict)
+                const int k = d.cond ? 1 : 0;
+                if (TR) gs |= (static_gsurf(c.d, d, p) > 0.0) ? 1u << j : 0u;
+                const double day = static_period_eval<true>(c, c.d, d, p, c.rs_d[k], TR, tab);
+                const double night = static_period_eval<false>(c, c.n, d, p, c.rs_n[k], false, tab);
+                const double r = ((day + night) - obs) * w;                    // MOD16._et, :193
+                const bool ok = r == r;
+                r2 = ok ? r * r : 0.0;
+                cnt |= ok ? 1u << j : 0u;
+            }
+            red[wave][jj][lane] = r2;
+        }
+        // per-draw sums over the wave's 64 pixels, in lane order (lane l of quarter q adds lanes
+        // 16 q .. 16 q + 15 of draw l & 15; then the quarters in order)
+        __builtin_amdgcn_wave_barrier();
+        const int dj = lane & 15, qt = lane >> 4;
+        double s = red[wave][dj][qt * 16];
+#pragma unroll
+        for (int l = 1; l < 16; ++l) s += red[wave][dj][qt * 16 + l];
+        const double s1 = __shfl(s, dj + 16, 64), s2 = __shfl(s, dj + 32, 64), s3 = __shfl(s, dj + 48, 64);
+        if (lane < 16) wsum[wave][h + lane][0] = ((s + s1) + s2) + s3;
+        __builtin_amdgcn_wave_barrier();
+    }
+    // pairs per draw: population counts of the lanes' bits
+#pragma unroll 1
+    for (int j = 0; j < kObjDraws; ++j) {
+        const unsigned long long m = __ballot((cnt >> j) & 1u);
+        const unsigned long long g = __ballot((gs >> j) & 1u);
+        if (lane == 0) {
+            wsum[wave][j][1] = (double)__builtin_popcountll(m);
+            wany[wave][j] = g != 0ull;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nd && ((want >> threadIdx.x) & 1u)) {
+        const int j = threadIdx.x;
+        double s = wsum[0][j][0], n = wsum[0][j][1];
+        unsigned any = wany[0][j];
+#pragma unroll
+        for (int wv = 1; wv < kWaves; ++wv) {
+            s += wsum[wv][j][0];
+            n += wsum[wv][j][1];
+            any |= wany[wv][j];
+        }
+        double* out = a.partial + ((int64_t)blockIdx.x * a.ndraw + (c0 + j)) * 2;
+        out[0] = s;
+        out[1] = n;
+        if (TR) a.any_gs[(int64_t)blockIdx.x * a.ndraw + (c0 + j)] = any;
+    }
+}
+
+// The pixels outside the FAST domain (list made at bind time, ascending), per draw in the
+// reference's operation order -- with and without transpiration, since whether any pixel of
+// the draw has g_surf > 0 is only known once every block has reported. One block per draw.
+template <typename T> struct StaticObjRedoArgs {
+    const T* drv[14];
+    uint32_t dense_drv;
+    const T* params;            // [ndraw][11]
+    const T* observed;
+    const T* weights;
+    const int64_t* list;        // flagged pixels
+    int64_t nlist;
+    double* redo;               // [ndraw][5]: sse with t, count with t, sse without, count without, pixels with g_surf > 0
+};
+template <typename T>
+__global__ void __launch_bounds__(kBlock) static_obj_redo_kernel(const StaticObjRedoArgs<T> a) {
+    const int64_t draw = blockIdx.x;
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int64_t u = threadIdx.x; u < a.nlist; u += kBlock) {
+#pragma clang fp contract(off)
+        const int64_t i = a.list[u];
+        auto dv = [&](int k) { return ((a.dense_drv >> k) & 1u) ? a.drv[k][i] : a.drv[k][0]; };
+        PixelIn<T> x = {dv(0), dv(1), dv(2), dv(3), dv(4), dv(5), dv(6), dv(7), dv(8), dv(9), dv(10), dv(11), dv(12), dv(13)};
+        const T* q = a.params + draw * 11;
+        ClassPar<T> p;
+        p.tmin_close = q[0]; p.tmin_open = q[1]; p.vpd_open = q[2]; p.vpd_close = q[3];
+        p.gl_sh = q[4]; p.gl_wv = q[5]; p.g_cut = q[6]; p.csl = q[7];
+        p.rbl_min = q[8]; p.rbl_max = q[9]; p.beta = q[10];
+        const bool any = (gsurf_static(p, x.tmin, x.vpd_d) / rcorr_exact(x.pa, x.t_d)) > T(0);
+        const double obs = (double)a.observed[i], w = a.weights ? (double)a.weights[i] : 1.0;
+        T day, night;
+        et_static_pixel(x, p, false, T(0), T(0), true, day, night);
+        double r = ((double)(T)(day + night) - obs) * w;
+        bool ok = r == r;
+        acc[0] += ok ? r * r : 0.0;
+        acc[1] += ok ? 1.0 : 0.0;
+        et_static_pixel(x, p, false, T(0), T(0), false, day, night);
+        r = ((double)(T)(day + night) - obs) * w;
+        ok = r == r;
+        acc[2] += ok ? r * r : 0.0;
+        acc[3] += ok ? 1.0 : 0.0;
+        acc[4] += any ? 1.0 : 0.0;
+    }
+    __shared__ double sm[5][kBlock / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[k] += __shfl_down(acc[k], off, 64);
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 5; ++k) sm[k][threadIdx.x >> 6] = acc[k];
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 5; ++k) {
+            double s = sm[k][0];
+            for (int wv = 1; wv < kBlock / 64; ++wv) s += sm[k][wv];
+            a.redo[draw * 5 + k] = s;
+        }
+}
+
+// any(g_surf > 0) of every draw over the blocks (and the flagged pixels). One thread per draw;
+// the per-block flags are laid out [block][draw], so a wave reads consecutive words.
+__global__ void __launch_bounds__(kBlock) static_obj_any_kernel(const unsigned* any_gs, const double* redo, int64_t ndraw,
+                                                                int gx, unsigned* any_draw) {
+    const int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (d >= ndraw) return;
+    unsigned any = 0;
+    for (int b = 0; b < gx; ++b) any |= any_gs[(int64_t)b * ndraw + d];
+    if (redo && redo[d * 5 + 4] > 0.0) any = 1u;
+    any_draw[d] = any;
+}
+
+// sse[d], count[d]: the block partials of the draw in block order, then the flagged pixels'.
+// (By now the partials of a draw without g_surf > 0 anywhere hold the pass without transpiration.)
+__global__ void __launch_bounds__(kBlock) static_obj_final_kernel(const double* partial, const double* redo,
+                                                                  const unsigned* any_draw, int64_t ndraw, int gx,
+                                                                  double* sse, double* count) {
+    const int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (d >= ndraw) return;
+    double s = 0.0, n = 0.0;
+    for (int b = 0; b < gx; ++b) {
+        s += partial[((int64_t)b * ndraw + d) * 2];
+        n += partial[((int64_t)b * ndraw + d) * 2 + 1];
+    }
+    if (redo) {
+        const int o = any_draw[d] ? 0 : 2;
+        s += redo[d * 5 + o];
+        n += redo[d * 5 + o + 1];
+    }
+    sse[d] = s;
+    count[d] = n;
+}
+
+// bind time: which pixels lie outside the domain of the FAST arithmetic (mod16_physics.hpp,
+// fast_out_of_domain: the static path rearranges the same terms)
+template <typename T>
+__global__ void __launch_bounds__(kBlock) static_domain_kernel(const StaticBatchArgs<T> a, uint8_t* skip) {
+    ignore_signalling_nans();
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n) return;
+    auto dv = [&](int k) { return (double)(((a.dense_drv >> k) & 1u) ? a.drv[k][i] : a.drv[k][0]); };
+    const PixelIn<double> x = {dv(0), dv(1), dv(2), dv(3), dv(4), dv(5), dv(6), dv(7), dv(8), dv(9), dv(10), dv(11), dv(12), dv(13)};
+    skip[i] = fast_out_of_domain(x) ? 1 : 0;
+}
+
+// The pixels the FAST kernels skip (a.skip), in the reference's operation order: their part of
+// any(g_surf > 0) per draw, then their rows. Same grid as the FAST kernels; a thread whose pixel is
+// inside the domain has nothing to do (one byte read).
+template <typename T>
+__global__ void __launch_bounds__(kBlock) static_batch_flag_skipped_kernel(const StaticBatchArgs<T> a) {
+    const int64_t d0 = a.draw0 + (int64_t)blockIdx.y * kBatchDraws;
+    const int64_t d1 = (d0 + kBatchDraws < a.ndraw) ? d0 + kBatchDraws : a.ndraw;
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += step) {
+        if (!a.skip[i]) continue;
+        for (int64_t draw = d0; draw < d1; ++draw) {
+#pragma clang fp contract(off)
+            PixelIn<T> x;
+            ClassPar<T> p;
+            batch_load(a, draw, i, x, p);
+            if ((gsurf_static(p, x.tmin, x.vpd_d) / rcorr_exact(x.pa, x.t_d)) > T(0)) atomicOr(a.flags + draw, 1u);
+        }
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(kBlock) static_batch_redo_rows_kernel(const StaticBatchArgs<T> a) {
+    const int64_t d0 = a.draw0 + (int64_t)blockIdx.y * kBatchDraws;
+    const int64_t d1 = (d0 + kBatchDraws < a.ndraw) ? d0 + kBatchDraws : a.ndraw;
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += step) {
+        if (!a.skip[i]) continue;
+        for (int64_t draw = d0; draw < d1; ++draw) {
+            const bool any_gs = (a.flags[draw] & 1u) != 0;
+            PixelIn<T> x;
+            ClassPar<T> p;
+            batch_load(a, draw, i, x, p);
+            T day, night;
+            et_static_pixel(x, p, false, T(0), T(0), any_gs, day, night);
+            const int64_t row = draw * a.n;
+            if (a.out[0]) a.out[0][row + i] = day;
+            if (a.out[1]) a.out[1][row + i] = night;
+            if (a.out[2]) a.out[2][row + i] = day + night;
+        }
     }
 }
 

@@ -90,7 +90,7 @@ template <typename T> struct StreamArgs {
     int64_t n;
     unsigned* status;
     double* diag_partial;      // [runs][8]
-    unsigned long long* dyn_counter;
+    unsigned long long* dyn_counter;   // ticket counter of the dynamic schedule; word [2] (unsigned) behind it: blocks finished
     double hours;              // kStreamRawTotal: the (scalar) hours of daylight
     int64_t wide_pitch;        // PITCHED: wide[k] = wide[0] + k * wide_pitch (elements)
     int run_shift;             // a run is 2^run_shift pieces (kDynRun for large rasters, less for
@@ -729,6 +729,27 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ka));
         __builtin_memcpy(&late, (const void*)ka, sizeof(late));
+    }
+    // -- dynamic schedule: the launch leaves its ticket counter at zero again. Every block counts
+    // itself finished once all its waves have left the loop (none of them claims any more); the
+    // block that counts last resets the ticket and the count. The next launch that uses this
+    // counter starts behind this kernel, so it finds zero -- without a memset in front of every
+    // launch: as a node of a captured graph that memset was seen to run LATE when replays were
+    // queued back to back between two torch.distributed barriers (RCCL on the null stream):
+    // replays then found the previous launch's final ticket, claimed nothing and left the
+    // outputs of the step before in place (round 4; tools/scratch notes in DESIGN.md section 7).
+    if (!late.static_sched) {
+        // (a wave claims one run ahead: its last claim may still be on its way to memory -- it must
+        // have RETURNED before the block counts itself finished, or it could land behind the reset)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned* fin = reinterpret_cast<unsigned*>(late.dyn_counter + 1);
+            if (__hip_atomic_fetch_add(fin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+                __hip_atomic_store(late.dyn_counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(fin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
     // -- static schedule (small rasters): the wave's flagged pieces again in the reference's
     // operation order, then its one partial. Iteration i of wave w was piece

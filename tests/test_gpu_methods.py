@@ -417,3 +417,146 @@ def test_batched_calibration_fast_float32(m16):
     for a, b in zip(got, want):
         assert a.dtype == np.float32 and b.dtype == np.float64
         assert np.array_equal(a, b.astype(np.float32), equal_nan=True)
+
+
+def test_bound_calibration_problem(m16, golden):
+    """MOD16._et_bind (mod16_static_batch_bind_*): the calibration problem resident on the GPU --
+    drivers up once, per evaluation parameters up and (sse, count) down around one graph launch.
+    Rows are the unbound call's bit for bit (FAST and reference order); the fused objective equals
+    the unbound one (counts exactly, sums to 1e-12: another, also fixed, order of addition) and the
+    oracle's; the reference's whole-array switch any(g_surf > 0) is resolved inside the launch
+    (csl = 0, a tmin_open above every tmin); repeated evaluations give the same bits; the number
+    of draws may change between evaluations."""
+    L = m16._lib
+    n = 20000
+    drv, lo, hi, rng = _calibration_inputs(n, 46)
+    drv[13][::50] = 0.0
+    drv[12][::61] = 0.0
+    drv[9][3::70] = -50.0
+    drv[10][5::70] = 9000.0
+    drv[5][::400] = np.nan
+    params = rng.uniform(lo, hi, (70, 11))
+    params[2, 7] = 0.0                        # csl = 0: no g_surf anywhere -> no transpiration for this draw
+    params[33, 1] = 400.0                     # tmin_open far above every tmin: the same
+    params[69, 7] = 0.0                       # ... also in the ragged last chunk of 32
+    unbound = m16.MOD16._et_batch(params, *drv, math=L.MATH_FAST)
+    obs = unbound[5] + rng.normal(0, 3, n)
+    obs[::97] = np.nan
+    w = rng.uniform(0.5, 2.0, n)
+    for math in (L.MATH_FAST, L.MATH_EXACT):
+        prob = m16.MOD16._et_bind(*drv, observed=obs, weights=w, max_draws=128, math=math)
+        assert prob.n == n and prob.n_outside_domain == 0
+        rows = prob.rows(params)
+        want = unbound if math == L.MATH_FAST else m16.MOD16._et_batch(params, *drv)
+        assert np.array_equal(rows, want, equal_nan=True)
+        day, night = prob.rows(params[:5], separate=True)
+        d0, n0 = m16.MOD16._et_batch(params[:5], *drv, separate=True, math=math)
+        assert np.array_equal(day, d0, equal_nan=True) and np.array_equal(night, n0, equal_nan=True)
+        sse, cnt = prob.objective(params)
+        s0, c0 = m16.MOD16._et_batch(params, *drv, observed=obs, weights=w, math=math)
+        assert np.array_equal(cnt, c0)
+        if math == L.MATH_EXACT:
+            assert np.array_equal(sse, s0)                # the same kernels
+        else:
+            np.testing.assert_allclose(sse, s0, rtol=1e-12)
+        r = (rows - obs) * w
+        ok = np.isfinite(r)
+        assert np.array_equal(cnt, ok.sum(1).astype(float))
+        np.testing.assert_allclose(sse, np.where(ok, r * r, 0).sum(1), rtol=1e-12)
+        assert np.argmin(sse / cnt) == 5
+        # the switched-off draws really have no transpiration in them
+        for d in (2, 33, 69):
+            with np.errstate(all='ignore'):
+                o = (oracle.et_static(list(params[d]), *drv) - obs) * w
+            np.testing.assert_allclose(sse[d], np.where(np.isfinite(o), o * o, 0).sum(), rtol=1e-8)
+        # the same bits again, and with another number of draws in between
+        s_few, c_few = prob.objective(params[:33])
+        assert np.array_equal(s_few, sse[:33]) and np.array_equal(c_few, cnt[:33])
+        s2, c2 = prob.objective(params)
+        assert np.array_equal(s2, sse) and np.array_equal(c2, cnt)
+        with pytest.raises(ValueError):
+            prob.objective(np.zeros((129, 11)))
+        with pytest.raises(IndexError):
+            prob.objective(np.zeros((3, 10)))
+        if math == L.MATH_FAST:
+            assert 0 < prob.gpu_milliseconds(3) < 100
+        prob.close()
+    # without observations: rows only
+    prob = m16.MOD16._et_bind(*drv, max_draws=8)
+    assert np.array_equal(prob.rows(params[:8]), unbound[:8], equal_nan=True)
+    with pytest.raises(ValueError):
+        prob.objective(params[:8])
+    # the reference's own vectors (F7) through the bound problem
+    f7 = golden('f7_static_path')
+    prob = m16.MOD16._et_bind(*list(f7['drivers']), max_draws=64)
+    got = prob.rows(f7['params'].T)
+    assert got.shape == (40, 12, 40)
+    assert_parity(np.stack([got[j, :, j] for j in range(40)], axis=1), f7['et'], 1e-9, 'F7')
+    # float32 tower-day arrays
+    d32 = [d.astype(np.float32) for d in drv]
+    p32 = params[:9].astype(np.float32)
+    prob = m16.MOD16._et_bind(*d32, observed=obs.astype(np.float32), max_draws=16)
+    assert prob.dtype == np.float32
+    assert np.array_equal(prob.rows(p32), m16.MOD16._et_batch(p32, *d32, math=L.MATH_FAST), equal_nan=True)
+    s32, c32 = prob.objective(p32)
+    s0, c0 = m16.MOD16._et_batch(p32, *d32, observed=obs.astype(np.float32), math=L.MATH_FAST)
+    assert np.array_equal(c32, c0)
+    np.testing.assert_allclose(s32, s0, rtol=1e-6)       # (the unbound call reduces rows rounded to float32)
+
+
+SPECIAL = [np.inf, -np.inf, 1e300, -1e300, 3.4e38, -9999.0, 65535.0, 1e15, 35.85, 1400.0, 0.0, -1.0, 1e-300]
+
+
+def test_calibration_fast_arithmetic_returns_the_reference_on_fill_values(m16):
+    """The FAST arithmetic of the calibration path (unbound rows, bound rows, bound objective) on
+    drivers with fill values, infinities, a temperature on the pole of the saturation formula, a zero
+    or negative pressure ...: the pixels outside the arithmetic's domain are computed in the
+    reference's operation order (mod16_physics.hpp "domain guard"; marked once at bind time), so
+    FAST returns what the reference-order kernels and the oracle return -- NaN / zero / inf masks and
+    values; the objective counts and sums them as the reference-order objective does."""
+    L = m16._lib
+    n = 6000
+    drv, lo, hi, rng = _calibration_inputs(n, 47)
+    drv = [d.copy() for d in drv]
+    idx = np.arange(5, n, 7)
+    which = rng.integers(0, 14, idx.size)
+    val = np.array(SPECIAL)[rng.integers(0, len(SPECIAL), idx.size)]
+    for k in range(14):
+        drv[k][idx[which == k]] = val[which == k]
+    params = rng.uniform(lo, hi, (40, 11))
+    params[7, 7] = 0.0
+    with np.errstate(all='ignore'):
+        exact = m16.MOD16._et_batch(params, *drv)
+        fast = m16.MOD16._et_batch(params, *drv, math=L.MATH_FAST)
+    assert_parity(fast, exact, 1e-9, 'unbound FAST vs reference order')
+    with np.errstate(all='ignore'):
+        for d in (0, 7, 39):
+            assert_parity(fast[d], oracle.et_static(list(params[d]), *drv), 1e-8, 'oracle, draw %d' % d)
+    obs = np.nan_to_num(exact[3], nan=10.0, posinf=10.0, neginf=10.0) + rng.normal(0, 3, n)
+    prob = m16.MOD16._et_bind(*drv, observed=obs, max_draws=64)
+    assert prob.n_outside_domain > 100
+    assert np.array_equal(prob.rows(params), fast, equal_nan=True)
+    sse, cnt = prob.objective(params)
+    with np.errstate(all='ignore'):
+        s_e, c_e = m16.MOD16._et_batch(params, *drv, observed=obs)
+    assert np.array_equal(cnt, c_e)
+    ok = np.isfinite(s_e)
+    np.testing.assert_allclose(sse[ok], s_e[ok], rtol=1e-8)
+    assert np.array_equal(np.isinf(sse), np.isinf(s_e)) and np.array_equal(np.isnan(sse), np.isnan(s_e))
+    # a problem whose ONLY pixels with g_surf > 0 lie outside the domain: the whole-array switch sees them
+    cold = [d.copy() for d in drv]
+    cold[8][:] = 200.0                        # tmin far below every tmin_close: the ramp is 0 ...
+    cold[8][idx[which == 0]] = 290.0          # ... except where lw_net_day holds a special value
+    flagged = idx[which == 0][np.isinf(drv[0][idx[which == 0]])]
+    assert flagged.size
+    with np.errstate(all='ignore'):
+        e2 = m16.MOD16._et_batch(params[:8], *cold)
+        f2 = m16.MOD16._et_batch(params[:8], *cold, math=L.MATH_FAST)
+    assert_parity(f2, e2, 1e-9, 'switch carried by flagged pixels')
+    p2 = m16.MOD16._et_bind(*cold, observed=obs, max_draws=8)
+    s2, c2 = p2.objective(params[:8])
+    with np.errstate(all='ignore'):
+        s_e2, c_e2 = m16.MOD16._et_batch(params[:8], *cold, observed=obs)
+    assert np.array_equal(c2, c_e2)
+    ok = np.isfinite(s_e2)
+    np.testing.assert_allclose(s2[ok], s_e2[ok], rtol=1e-8)

@@ -1,0 +1,55 @@
+import os, sys, time, socket
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+mode = sys.argv[1]
+os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1')
+with socket.socket() as s:
+    s.bind(('127.0.0.1', 0)); os.environ['MASTER_PORT'] = str(s.getsockname()[1])
+import torch, torch.distributed as dist
+from mod16_amd import _lib, dist as tiles
+from mod16_amd.raster import RasterEngine
+from mod16_amd.utils import restore_bplut, bplut_table
+from mod16_amd.models import COLLECTION61_BPLUT
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
+eng = RasterEngine(table)
+n = 5400 * 43200
+ras = eng.synth_tiled(eng.alloc_tiled(n), seed=16)
+diags = [torch.zeros(8, dtype=torch.float64, device='cuda') for _ in range(2)]
+bound = [eng.bind_tiled(ras, d) for d in diags]
+main = torch.cuda.current_stream()
+side = torch.cuda.Stream()
+cnt = [0]
+direct = 'direct' in mode
+def step(ev=None, poison=False, stream=None):
+    k = cnt[0] & 1; cnt[0] += 1
+    if poison: ras.day.fill_(-1.0)
+    if ev: ev[0].record()
+    if direct: eng.run_tiled(ras, diag=diags[k])
+    else: bound[k]()
+    if ev: ev[1].record()
+for _ in range(3): step()
+torch.cuda.synchronize()
+if 'barrier' in mode:
+    dist.barrier()
+elif 'allreduce' in mode:
+    t = torch.zeros(1, device='cuda'); dist.all_reduce(t)
+elif 'sidereduce' in mode:
+    with torch.cuda.stream(side):
+        t = torch.zeros(1, device='cuda'); dist.all_reduce(t)
+torch.cuda.synchronize()
+def loop(tag, use_side=False):
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(8)]
+    ctx = torch.cuda.stream(side) if use_side else torch.cuda.stream(main)
+    with ctx:
+        t0 = time.perf_counter()
+        for i in range(8): step(ev[i], poison=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print(mode, tag, 'wall ms/step %.3f' % (1e3 * dt / 8), 'event ms', ['%.2f' % a.elapsed_time(b) for a, b in ev],
+          'poisoned left', int((ras.day == -1.0).sum()), flush=True)
+loop('null-stream')
+loop('side-stream', True)
+loop('null-stream-again')
+dist.destroy_process_group()
