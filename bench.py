@@ -406,6 +406,8 @@ def main():
                     help="skip the 2 s of extra steps behind the timed region during which the device's clock and power are read")
     ap.add_argument('--no-configs', action='store_true',
                     help='skip the other BASELINE.json configurations (1200x1200 tile, series, float32)')
+    ap.add_argument('--no-ingest', action='store_true',
+                    help='N > 1: skip the host-ingest series every rank streams beside its band')
     ap.add_argument('--cpu-workers', type=int, default=16)
     ap.add_argument('--series-steps', type=int, default=46)
     args = ap.parse_args()
@@ -679,12 +681,29 @@ def main():
     if rank == 0:
         copy_gbps = eng.measure_copy(4 << 30, 3)
 
+    # real-data ingest in the light input form (every rank has its own PCIe link): N > 1 runs it on every
+    # rank beside the resident band; N = 1 runs it with the other configurations below (with the oracle)
+    ingest = None
+    if world > 1 and not args.no_ingest:
+        n_in = (args.rows * args.cols // 32) // 8192 * 8192
+        fence()
+        mine = ingest_raw_series(torch, np, _lib, RasterEngine, table, local_rank, _lib.MATH_MIXED, n_in, args.series_steps)
+        rates = torch.zeros(world, 2, dtype=torch.float64, device='cpu' if rehearsal else 'cuda')
+        rates[rank, 0], rates[rank, 1] = mine['pixels_per_s'], mine['h2d_GBps']
+        dist.all_reduce(rates)
+        ingest = dict(mine, pixels_per_s=float(rates[:, 0].sum()), h2d_GBps=float(rates[:, 1].sum()),
+                      pixels_per_s_by_rank=rates[:, 0].tolist(), h2d_GBps_by_rank=rates[:, 1].tolist(),
+                      note='every rank streams its own series at the same time; sums over the ranks')
     configs = None
     if rank == 0 and world == 1 and not args.no_configs and args.dtype == 'float64':
         # the other configurations need the whole card: drop this raster first
         steps_bound = ras = cls = drv = day = night = None
         torch.cuda.empty_cache()
+        if bplut is None:
+            from oracle import mod16_oracle as oracle
+            bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
         configs = other_configs(args, torch, np, _lib, RasterEngine, table, bplut)
+        ingest = configs['c4_series_float64']['host_ingest_raw']['float32_mixed']
 
     if rank == 0:
         traffic, traffic_source, traffic_note = pmc_traffic(n, args.dtype, args.layout, _lib.build_id())
@@ -731,6 +750,7 @@ def main():
             'cpu_baseline': cpu,
             'parity': parity,
             'configs': configs,
+            'ingest': ingest,
             'diagnostics': dict(zip(DIAG_NAMES, [float(v) for v in diag_host])),
         }
         if census is not None:
@@ -823,6 +843,11 @@ def other_configs(args, torch, np, _lib, RasterEngine, table, bplut):
     del ring, grabbed, sdiag
     torch.cuda.empty_cache()
     out['c4_series_float64']['host_ingest'] = series_from_host(torch, eng, args)
+    n_in = (args.rows * args.cols // 32) // 8192 * 8192
+    out['c4_series_float64']['host_ingest_raw'] = {
+        name: ingest_raw_series(torch, np, _lib, RasterEngine, table, torch.cuda.current_device(), math, n_in,
+                                args.series_steps, bplut)
+        for name, math in (('float32_fast', _lib.MATH_FAST), ('float32_mixed', _lib.MATH_MIXED))}
 
     # ---- configs[4]: the global grid in float32, mixed precision vs float64 tolerance
     c5 = {}
@@ -915,6 +940,95 @@ def series_from_host(torch, eng, args):
             'diagnostics_identical_across_steps': same,
             'note': 'drivers of every step from page-locked host memory (14 x %d B/pixel up per step, overlapped '
                     'with the kernel of the previous step); the class raster stays resident' % eng.np_dtype.itemsize}
+
+
+def ingest_raw_series(torch, np, _lib, RasterEngine, table, device, math, n, steps, bplut=None):
+    """A series whose drivers come from HOST memory in the light input form (the
+    reference's own pre-processing inputs, calibration.py:380-423): per step 14 float32 raw fields
+    (radiation, temperatures, QV10M, PS, elevation) + uint8 fPAR / LAI = 58 bytes per pixel copied
+    from page-locked memory straight into a two-slot ring of FORM_RAW tiled rasters (tile-wide rows
+    into the slot's pitch) on a second stream, under the kernel of the previous step; the class
+    raster stays resident. Three distinct host records take turns. With `bplut` the oracle checks a
+    320 k-pixel window of the first, the middle and the last step. Bound: this rank's PCIe link."""
+    eng = RasterEngine(table, device=device, dtype='float32', math=math)
+    ring = [eng.alloc_tiled(n, form=_lib.FORM_RAW) for _ in range(2)]
+    npad = ring[0].ntiles * ring[0].tile
+    g = torch.Generator(device='cuda').manual_seed(7)
+    pin = lambda x: torch.empty(x.shape, dtype=x.dtype, pin_memory=True).copy_(x)
+    host, cls = [], None
+    for k in range(3):
+        c, drv = eng.synth(npad, seed=SEED, step=k)
+        u = lambda lo, hi: torch.empty(npad, dtype=torch.float32, device='cuda').uniform_(lo, hi, generator=g)
+        raw = drv[:9] + [u(0.001, 0.02), u(0.001, 0.02), u(7e4, 1.0134e5), u(7e4, 1.0134e5), u(0, 3500)]
+        fpar = torch.randint(0, 101, (npad,), dtype=torch.uint8, device='cuda', generator=g)
+        lai = torch.randint(0, 71, (npad,), dtype=torch.uint8, device='cuda', generator=g)
+        fill = torch.rand(npad, device='cuda', generator=g) < 0.01
+        fpar[fill] = 255
+        lai[fill] = 250
+        host.append({'wide': [pin(x) for x in raw], 'bytes': [None, pin(fpar), pin(lai)]})
+        if cls is None:
+            cls = c                          # land cover is static
+        del c, drv, raw, fpar, lai, fill
+    for r in ring:
+        r.bytes[0].copy_(cls.view(r.ntiles, r.tile))
+    torch.cuda.empty_cache()
+    lo = (n // 2) // 8192 * 8192
+    hi = min(n, lo + 320000)
+    checked = sorted(set([0, steps // 2, steps - 1]))
+    grabbed = {}
+
+    def grab(s, slot):
+        if s in checked:
+            grabbed[s] = (slot.flat(slot.outs[0], lo, hi), slot.flat(slot.outs[1], lo, hi))
+
+    eng.run_series_host(ring, host, 2)          # warm-up: both slots, both streams
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.run_series_host(ring, host, steps, on_step=grab)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.check()
+    bpp = 14 * 4 + 2
+    res = {'pixels': n, 'steps': steps, 'seconds': dt, 'pixels_per_s': n * steps / dt,
+           'bytes_per_pixel_and_step_over_pcie': bpp, 'h2d_GBps': bpp * npad * steps / dt / 1e9,
+           'math': 'mixed' if math == _lib.MATH_MIXED else 'fast (float64 arithmetic)',
+           'host_records': len(host), 'form': 'FORM_RAW (14 float32 raw fields + uint8 fPAR, LAI; class raster resident)'}
+    if bplut is not None:
+        from oracle import mod16_oracle as oracle
+        worst, worst_abs, masks, n_gt, n_all = 0.0, 0.0, True, 0, 0
+        mixed = math == _lib.MATH_MIXED
+        tiny = float(np.finfo(np.float32).tiny)
+        h_cls = cls[lo:hi].cpu().numpy()
+        for s_, outs in grabbed.items():
+            rec = host[s_ % len(host)]
+            with np.errstate(all='ignore'):
+                want = oracle.evapotranspiration_raw(
+                    bplut, h_cls, [x[lo:hi].numpy().astype(np.float64) for x in rec['wide']],
+                    rec['bytes'][1][lo:hi].numpy(), rec['bytes'][2][lo:hi].numpy())
+            for o, w in zip(outs, want):
+                got = o.cpu().numpy().astype(np.float64)
+                w = w.astype(np.float32).astype(np.float64)
+                if mixed:
+                    got = np.where(np.abs(got) < tiny, 0, got)
+                    w = np.where(np.abs(w) < tiny, 0, w)
+                masks = masks and bool(np.array_equal(np.isnan(got), np.isnan(w)) and np.array_equal(got == 0, w == 0))
+                ok = np.isfinite(w) & (w != 0)
+                err = np.abs(got[ok] - w[ok])
+                rel = err / np.abs(w[ok])
+                worst = max(worst, float(rel.max()))
+                worst_abs = max(worst_abs, float(err.max() / np.abs(w[ok]).max()))
+                n_gt += int(np.count_nonzero(rel > 1e-5))
+                n_all += int(rel.size)
+        res['parity'] = {'steps_checked': sorted(grabbed), 'pixels_per_step': hi - lo, 'masks_equal': masks,
+                         'max_rel_err_vs_oracle': worst}
+        if mixed:
+            res['parity'].update({'max_abs_err_over_max_value': worst_abs, 'within_abs_bound_1e-6': worst_abs <= 1e-6,
+                                  'fraction_rel_err_gt_1e-5': n_gt / max(n_all, 1)})
+        else:
+            res['parity']['within_rtol_1e-6'] = worst <= 1e-6
+    del ring, host, grabbed, cls
+    torch.cuda.empty_cache()
+    return res
 
 
 def forms_config(torch, np, _lib, RasterEngine, table, bplut, dtype, math, rows):

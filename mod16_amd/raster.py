@@ -628,6 +628,51 @@ class RasterEngine(object):
         compute.wait_stream(ingest)
         return diag, last
 
+    def run_series_host(self, ring, host_steps, steps, day_hours=None, on_step=None):
+        '''A time series whose drivers arrive from HOST memory (a real ingest: SURVEY.md 8f
+        N1 / N4, reference calibration.py:380-423): ``ring`` is two ``TiledRaster`` slots of one
+        form -- typically ``FORM_RAW`` on a float32 engine, the light input form: 14 float32 raw
+        fields + uint8 fPAR / LAI = 58 bytes per pixel and step over PCIe instead of the 113 of
+        float64 plain drivers. ``host_steps`` is a list of K step records ``{'wide': [...],
+        'bytes': [...]}`` of page-locked CPU tensors with ``ntiles * tile`` elements each (``None``
+        = the field stays as it is in the slots: the class raster, static fields); step ``s``
+        takes record ``s % K``. The copies of step s + 1 run on a second stream -- tile-wide rows
+        straight into the slot's pitch, no repacking pass -- under the kernel of step s; the
+        kernel is ``run_form_tiled`` (the reference's pre-processing is inside it).
+        ``on_step(s, slot)`` is called with the compute stream current behind step s's kernel.
+        Returns the slot of the last step.'''
+        torch = _torch()
+        compute = torch.cuda.current_stream(self.device)
+        ingest = torch.cuda.Stream(device=self._dev())
+        filled = [torch.cuda.Event() for _ in range(steps)]
+        consumed = [torch.cuda.Event() for _ in range(steps)]
+        ingest.wait_stream(compute)
+
+        def produce(s):
+            rec, slot = host_steps[s % len(host_steps)], ring[s % 2]
+            with torch.cuda.stream(ingest):
+                if s >= 2:
+                    ingest.wait_event(consumed[s - 2])      # the slot is free again
+                for dst, src in list(zip(slot.wide, rec.get('wide', []))) + list(zip(slot.bytes, rec.get('bytes', []))):
+                    if src is not None:
+                        dst.copy_(src.view(slot.ntiles, slot.tile), non_blocking=True)
+                filled[s].record(ingest)
+
+        for s in range(min(2, steps)):
+            produce(s)
+        last = None
+        for s in range(steps):
+            compute.wait_event(filled[s])
+            last = ring[s % 2]
+            self.run_form_tiled(last, day_hours)
+            if on_step is not None:
+                on_step(s, last)
+            consumed[s].record(compute)
+            if s + 2 < steps:
+                produce(s + 2)
+        compute.wait_stream(ingest)
+        return last
+
     def measure_copy(self, nbytes=4 << 30, reps=3):
         '''GB/s of a plain device-to-device copy kernel on this GPU
         (``mod16_measure_copy``): the measured reference point next to the

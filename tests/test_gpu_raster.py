@@ -950,3 +950,60 @@ print('ok', which)
     for which in ('dense', 'scalar', 'tiled', 'tiled_large'):
         proc = subprocess.run([sys.executable, '-c', code, which], capture_output=True, text=True, timeout=600)
         assert proc.returncode == 0 and ('ok ' + which) in proc.stdout, (which, proc.stdout[-1000:], proc.stderr[-3000:])
+
+
+@pytest.mark.parametrize('math', ['fast', 'mixed'])
+def test_series_from_host_in_the_light_input_form(env, math):
+    """RasterEngine.run_series_host: per step the 14 float32 raw fields and the uint8 fPAR / LAI of a
+    host record copied (page-locked memory, a second stream, tile-wide rows into the slot's pitch)
+    into a two-slot ring of FORM_RAW tiled rasters under the kernel of the step before; the class
+    raster stays resident. Every step's outputs equal the plain raw-driver call on that record's
+    arrays bit for bit, and the oracle's (the reference's pre-processing + forward run) on a step."""
+    from mod16_amd import _lib
+    torch, RasterEngine, table = env
+    m = {'fast': _lib.MATH_FAST, 'mixed': _lib.MATH_MIXED}[math]
+    eng = RasterEngine(table, dtype='float32', math=m)
+    n = 8192 * 37
+    ring = [eng.alloc_tiled(n, form=_lib.FORM_RAW) for _ in range(2)]
+    g = torch.Generator(device='cuda').manual_seed(3)
+    pin = lambda x: torch.empty(x.shape, dtype=x.dtype, pin_memory=True).copy_(x)
+    recs, dev = [], []
+    for k in range(3):
+        cls, drv = eng.synth(n, seed=5, step=k)
+        u = lambda lo, hi: torch.empty(n, dtype=torch.float32, device='cuda').uniform_(lo, hi, generator=g)
+        raw = drv[:9] + [u(0.001, 0.02), u(0.001, 0.02), u(7e4, 1.0134e5), u(7e4, 1.0134e5), u(0, 3500)]
+        fpar = torch.randint(0, 101, (n,), dtype=torch.uint8, device='cuda', generator=g)
+        lai = torch.randint(0, 71, (n,), dtype=torch.uint8, device='cuda', generator=g)
+        fpar[::97] = 255
+        raw[13][5::1001] = 5e4                       # an elevation outside the domain: revisited in the reference's order
+        recs.append({'wide': [pin(x) for x in raw], 'bytes': [None, pin(fpar), pin(lai)]})
+        dev.append((raw, fpar, lai))
+    for r in ring:
+        r.put(r.bytes[0], cls)
+    seen = {}
+
+    def grab(s, slot):
+        seen[s] = (slot.flat(slot.outs[0]), slot.flat(slot.outs[1]))
+
+    last = eng.run_series_host(ring, recs, 7, on_step=grab)
+    eng.check()
+    assert last is ring[0] and sorted(seen) == list(range(7))
+    same = lambda a, b: torch.equal(torch.nan_to_num(a, nan=-7.0, posinf=9e30, neginf=-9e30),
+                                    torch.nan_to_num(b, nan=-7.0, posinf=9e30, neginf=-9e30))
+    for s in range(7):
+        raw, fpar, lai = dev[s % 3]
+        want = eng.run_raw(cls, raw, fpar, lai)
+        assert same(seen[s][0], want[0]) and same(seen[s][1], want[1]), s
+    raw, fpar, lai = dev[5 % 3]
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    with np.errstate(all='ignore'):
+        o = oracle.evapotranspiration_raw(bplut, cls.cpu().numpy(), [x.cpu().numpy().astype(np.float64) for x in raw],
+                                          fpar.cpu().numpy(), lai.cpu().numpy())
+    for got, w in zip(seen[5], o):
+        if math == 'mixed':
+            from parity import assert_mixed_parity
+            with np.errstate(over='ignore'):
+                assert_mixed_parity(got.cpu().numpy(), w.astype(np.float32), 'raw series, mixed')
+        else:
+            with np.errstate(over='ignore'):
+                assert_parity(got.cpu().numpy(), w.astype(np.float32), 1e-6, 'raw series')
