@@ -98,8 +98,9 @@ enum mod16_where { MOD16_HOST = 0, MOD16_DEVICE = 1 };
  * 1.2 M random pairs and a storm of independently special drivers (tests/fuzz_domain.py),
  * signalling-NaN patterns next to an infinity (tests/test_gpu_guard.py), NaN / zero / inf
  * masks included. The raw-driver forms test the raw fields instead: |specific humidity| < 1
- * kg/kg, |surface pressure| < 1e50 Pa, |elevation| < 39 km (the air pressure computed from it is
- * then above the 1 Pa bound: 1.5 Pa at 39 km), the temperatures and radiation terms as above.
+ * kg/kg, |surface pressure| < 1e50 Pa, an elevation between -2000 m and 12000 m (the interval on
+ * which the fast form evaluates air pressure as a polynomial, 3.7e-14 relative; MIXED: |z| < 25 km),
+ * the temperatures and radiation terms as above.
  * MOD16_MATH_EXACT is the reference's operation order throughout. */
 #define MOD16_MATH_FAST   0u  /* strength-reduced arithmetic (default)          */
 #define MOD16_MATH_EXACT  1u  /* reference operation order, IEEE divide/pow     */

@@ -214,6 +214,16 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
             }
             // entry 0 serves x = 1 (m = 1): make log_tab(1) cancel to exactly 0
             t[64 + 1] = -FastMath<double>::log1p_poly(std::fma(1.0, t[64], -1.0));
+            // air pressure [Pa] from elevation, MOD16.air_pressure (mod16/__init__.py:414-447):
+            // 101325 (1 - 0.0065 z / 288.15)^5.2559 interpolated at the 10 Chebyshev nodes of
+            // -2000 m .. 12000 m, in powers of u = (z - 5000) / 7000: 3.7e-14 relative on that
+            // interval (numpy fit, tools/fit_air_pressure.py); outside it the domain guard hands
+            // the pixel to the reference-order arithmetic
+            static const double kPressurePoly[10] = {
+                0x1.a607a9266ab84p+15, -0x1.8ac7a6364460ap+15, 0x1.2b06fedbccfd8p+14, -0x1.ce13d340b53c7p+11,
+                0x1.730bd6d1a9cc9p+8, -0x1.096571085f8f7p+4, 0x1.01d9b2280ab84p-3, 0x1.3835059a0bfaap-9,
+                0x1.8732949feb6b7p-14, 0x1.555f18e36b65ap-18};
+            for (int j = 0; j < 16; ++j) t[FastMath<double>::kTabRaw + j] = j < 10 ? kPressurePoly[j] : 0.0;
             HIPCHK(ctx, hipMalloc(&ctx->tab64, sizeof t));
             HIPCHK(ctx, hipMemcpy(ctx->tab64, t, sizeof t, hipMemcpyHostToDevice));
         }

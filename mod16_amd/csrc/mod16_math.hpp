@@ -128,7 +128,10 @@ template <> struct FastMath<double> {
     // ---- table-driven exp / log (tables in LDS, filled by the library)
     // tb[0..63]      = 2^(j/64)
     // tb[64 + 2j..]  = { 1/c_j rounded, -log(1/c_j) },  c_j = 1 + (j + 1/2)/128
-    static constexpr int kTabDoubles = 64 + 2 * 128;
+    // tb[320 .. 335]   constants of the raw-driver pre-processing (mod16_physics.hpp, raw_to_pixel_fast):
+    //                  [0..9] air pressure from elevation as a polynomial in u = (z - 5000) / 7000
+    static constexpr int kTabRaw = 64 + 2 * 128;
+    static constexpr int kTabDoubles = kTabRaw + 16;
     static constexpr double kRintShift = 6755399441055744.0;       // 1.5 * 2^52
 
     // e^x for finite x (no clamp: a huge |x| saturates through v_cvt_i32 and

@@ -850,6 +850,7 @@ __device__ __forceinline__ PixelIn<T> raw_to_pixel_exact(const RawIn<T>& r) {
     return x;
 }
 
+constexpr double kElevMid = 5000.0, kElevHalf = 7000.0;   // the fast form's elevations: -2000 m .. 12000 m
 __device__ __forceinline__ PixelIn<double> raw_to_pixel_fast(const RawIn<double>& r,
                                                              const double* tb) {
     typedef FastMath<double> M;
@@ -869,11 +870,18 @@ __device__ __forceinline__ PixelIn<double> raw_to_pixel_fast(const RawIn<double>
     x.vpd_d = vpd(r.qv_d, r.ps_d, r.t_d);
     double vn = vpd(r.qv_n, r.ps_n, r.t_n);
     x.vpd_n = (vn < 0.0) ? 0.0 : vn;
-    // 101325 (1 - 0.0065 z / 288.15)^5.2559 ; the ratio is in (0, 1.2] on Earth
-    double ratio = __builtin_fma(r.elev, -0.0065 / 288.15, 1.0);
-    x.pa = 101325.0 * M::exp_tab(
-        (9.80665 / (0.0065 * (8.3143 / 28.9644e-3))) * M::log_tab(ratio, tb), tb);
-    x.pa = __builtin_fma(ratio, 0.0, x.pa);      // log_tab's integer path drops a NaN: ratio * 0 carries it
+    // 101325 (1 - 0.0065 z / 288.15)^5.2559 as a polynomial of degree 9 in u = (z - 5000) / 7000
+    // (coefficients in LDS behind the exp / log tables: 3.7e-14 relative on -2000 m .. 12000 m, the
+    // interval the guard below admits; a log + an exp before -- 20 float64 instructions more). A NaN
+    // elevation stays NaN.
+    {
+        const double* c = tb + M::kTabRaw;
+        const double u = __builtin_fma(r.elev, 1.0 / kElevHalf, -kElevMid / kElevHalf);
+        double pa = __builtin_fma(c[9], u, c[8]);
+#pragma unroll
+        for (int k = 7; k >= 0; --k) pa = __builtin_fma(pa, u, c[k]);
+        x.pa = pa;
+    }
     const double nan = __builtin_nan("");
     x.fpar = (r.fpar_pct >= 249u) ? nan : (double)r.fpar_pct * 0.01;
     x.lai = (r.lai_x10 >= 249u) ? nan : (double)r.lai_x10 * 0.1;
@@ -883,8 +891,8 @@ __device__ __forceinline__ PixelIn<double> raw_to_pixel_fast(const RawIn<double>
 // Domain of raw_to_pixel_fast + et_pixel_fast on raw drivers: as above for the fields that
 // pass through, plus what the fused pre-processing assumes: a specific humidity below 1 kg/kg
 // (0.379 qv + 0.622 > 0: one reciprocal serves both quotients), a finite surface pressure, an
-// elevation below 39 km (1 - 0.0065 z / 288.15 > 0: log_tab wants a positive normal number, and the
-// air pressure computed from it stays above the 1 Pa lower bound of fast_out_of_domain).
+// elevation between -2000 m and 12000 m (the interval of the air-pressure polynomial; the Dead Sea
+// shore lies at -430 m, Mount Everest at 8849 m; a DEM's fill value goes the reference's way).
 // fPAR, LAI (byte decodings) and the air pressure (from the bounded elevation) cannot leave it.
 __device__ __forceinline__ bool raw_out_of_domain(const RawIn<double>& r) {
 #ifdef MOD16_NO_GUARD
@@ -898,7 +906,8 @@ __device__ __forceinline__ bool raw_out_of_domain(const RawIn<double>& r) {
     m = max_abs(m, r.ps_n);
     m = max_abs(m, r.qv_d * in_vgpr(kGuardHuge));          // |qv| < 1
     m = max_abs(m, r.qv_n * in_vgpr(kGuardHuge));
-    m = max_abs(m, r.elev * in_vgpr(kGuardHuge / 3.9e4));  // |z| < 39 km: the air pressure stays above the 1 Pa of fast_out_of_domain (1.5 Pa at 39 km)
+    // -2000 m < z < 12000 m: the interval of the pressure polynomial (19.4 kPa .. 127.8 kPa)
+    m = max_abs(m, __builtin_fma(r.elev, in_vgpr(kGuardHuge / kElevHalf), in_vgpr(-kElevMid * (kGuardHuge / kElevHalf))));
     m = max_abs(m, guard_temperature(r.t_d));
     m = max_abs(m, guard_temperature(r.t_n));
     return m >= in_vgpr(kGuardHuge);
