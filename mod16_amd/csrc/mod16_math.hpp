@@ -38,6 +38,16 @@ __device__ __forceinline__ void ignore_signalling_nans() {
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 9, 1), 0\n\ts_nop 3" ::: "memory");
 }
 
+// A constant in a VECTOR register pair: the production loops fill the scalar register file with
+// the pixel function's constants (v_fma_f64 takes no literal on gfx9: every float64 constant that is
+// not one of the inline ones occupies a scalar pair), and what does not fit is rebuilt from two
+// s_mov_b32 at every use; vector registers are to spare at two waves per SIMD. The compiler
+// hoists the (side-effect-free) statement in front of a loop.
+__device__ __forceinline__ double in_vgpr(double k) {
+    asm("" : "+v"(k));
+    return k;
+}
+
 template <typename T> struct ExactMath {
     static __device__ __forceinline__ T exp(T x);
     static __device__ __forceinline__ T pow(T x, T y);

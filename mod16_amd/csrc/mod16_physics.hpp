@@ -544,6 +544,22 @@ __device__ __forceinline__ double static_period_eval(const StaticPixel& px, cons
 }
 
 // ====================================================================== fast
+// Where the constants of the fast pixel function live. The production loop fills the scalar
+// register file (v_fma_f64 takes no literal on gfx9: every float64 constant that is not an inline
+// one occupies a scalar pair), and what does not fit is rebuilt from two s_mov_b32 at every use --
+// 57 of them per iteration of the float64 totals loop, plus 15 v_readlane / v_writelane of scalar
+// spills (round 4 listing). KPin<LEVEL> holds the constants that are used most in VECTOR register
+// pairs through the loop instead (the totals instances have the registers to spare at two waves per
+// SIMD; the other forms and the plain kernels do not: KLit, literals as before). Same values, same
+// operations: results are bit-identical either way.
+struct KLit {
+    static __device__ __forceinline__ double per_period(double c) { return c; }
+    static __device__ __forceinline__ double per_pixel(double c) { return c; }
+};
+template <int LEVEL> struct KPin {
+    static __device__ __forceinline__ double per_period(double c) { return LEVEL >= 1 ? in_vgpr(c) : c; }
+    static __device__ __forceinline__ double per_pixel(double c) { return LEVEL >= 2 ? in_vgpr(c) : c; }
+};
 // Quantities that do not depend on the period (day / night).
 template <typename T> struct PixelShared {
     T oma;        // 1 - albedo
@@ -563,7 +579,7 @@ template <typename T> struct PixelShared {
 // evaporation without the soil-moisture constraint + Priestley-Taylor
 // potential transpiration (MOD16.potential_transpiration, :546-602), as a mass
 // flux like the other outputs.
-template <typename T, bool DAY, bool PET = false>
+template <typename T, bool DAY, bool PET = false, typename KP = KLit>
 __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<T>& p,
                                             const PixelShared<T>& sh, const T* tb, T t, T vpd,
                                             T rad_net, T rad_soil, T& canopy, T& soil,
@@ -579,13 +595,13 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     // the two reciprocals of the temperature terms -- 1 / (tc + 237.3) for esat and
     // 1 / (tc + 239) for the slope of the curve -- from ONE v_rcp_f64 of their product
     // (a quarter-rate instruction and its Newton step against two multiplications)
-    T d_es = tc + T(237.3);
-    T ta = tc + T(239.0);                                          // (239 + T) - 273.15 to 1 ulp, :1395
+    T d_es = tc + KP::per_period(237.3);
+    T ta = tc + KP::per_period(239.0);                                          // (239 + T) - 273.15 to 1 ulp, :1395
     T r_both = M::rcp(d_es * ta);
     T r_es = r_both * ta, rta = r_both * d_es;
     // (a NaN temperature stays NaN through exp_tab: rint, the fmas and the table product
     // all propagate it; an infinite one gives inf * 0 in r_es)
-    T esat = T(1e3 * 0.6108) * M::exp_tab((T(17.27) * tc) * r_es, tb);
+    T esat = T(1e3 * 0.6108) * M::exp_tab((KP::per_period(17.27) * tc) * r_es, tb);
     T avp = esat - vpd;
     // rh drives the thresholds (rh < 0.7, 1 - fwet > 0), so this one quotient is
     // finished like an IEEE division (residual correction): x / x = 1 exactly
@@ -601,11 +617,11 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     T fwet = dry ? T(0) : rh2 * rh2;
     T omw = T(1) - fwet;
     // -- slope of the SVP curve (:1395-1397), latent heat (:121)
-    T s = (T(17.38 * 239.0) * esat) * (rta * rta);
+    T s = (KP::per_period(17.38 * 239.0) * esat) * (rta * rta);
     T lhv = M::fma_kk(tc, T(-0.002361e6), T(2.501e6));         // (2.501 - 0.002361 tc) 1e6, :121
     T slhv = s * lhv;
     // -- 1 / r_corr = (P / 101300) (T / 293.15)^-1.75, :771
-    T inv_rcorr = sh.p_rel * M::pow_m1p75(t * T(1.0 / 293.15));
+    T inv_rcorr = sh.p_rel * M::pow_m1p75(t * KP::per_period(1.0 / 293.15));
     // -- air density (:408-412) and radiative conductance 1/r_r (:947) from
     //    one reciprocal: rho = N / T, 1/r_r = 4 sigma T^4 / (Cp N)
     // p_mbar_k - (rh 100)(0.00252 tc - 0.020582); the contraction is written out so that
@@ -682,7 +698,7 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     }
 }
 
-template <typename T, bool PET = false>
+template <typename T, bool PET = false, typename KP = KLit>
 __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const ClassPar<T>& p,
                                                      const T* tb) {
 #pragma clang fp contract(off)
@@ -702,20 +718,21 @@ __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const 
     T a_n = x.lw_n;
     // `&` and `|`, not `&&` and `||`: the short-circuit forms make hipcc evaluate the
     // right-hand comparison inside an exec-masked branch (saveexec / cbranch / restore)
-    bool cond = (x.t_ann < T(273.15 + 25.0)) & (x.t_ann >= (K<T>::t0 + p.tmin_close)) &
-                ((x.t_d - x.t_n) >= T(5));
-    T g_d = cond ? __builtin_fma(T(4.73), x.t_d - K<T>::t0, T(-20.87)) : T(0);
-    g_d = (__builtin_fabs(g_d) > (T(0.39) * __builtin_fabs(a_d))) ? T(0.39) * a_d : g_d;
-    T g_n = cond ? __builtin_fma(T(4.73), x.t_n - K<T>::t0, T(-20.87)) : T(0);
-    g_n = (__builtin_fabs(g_n) > (T(0.39) * __builtin_fabs(a_n))) ? T(0.39) * a_n : g_n;
+    const T k473 = KP::per_pixel(4.73), k2087 = KP::per_pixel(-20.87), k039 = KP::per_pixel(0.39);
+    const T t_ann_max = KP::per_pixel(273.15 + 25.0), dt_min = KP::per_pixel(5.0);
+    bool cond = (x.t_ann < t_ann_max) & (x.t_ann >= (K<T>::t0 + p.tmin_close)) & ((x.t_d - x.t_n) >= dt_min);
+    T g_d = cond ? __builtin_fma(k473, x.t_d - K<T>::t0, k2087) : T(0);
+    g_d = (__builtin_fabs(g_d) > (k039 * __builtin_fabs(a_d))) ? k039 * a_d : g_d;
+    T g_n = cond ? __builtin_fma(k473, x.t_n - K<T>::t0, k2087) : T(0);
+    g_n = (__builtin_fabs(g_n) > (k039 * __builtin_fabs(a_n))) ? k039 * a_n : g_n;
     g_d = ((a_d - g_d < T(0)) & (a_d > T(0))) ? a_d : g_d;
     g_n = ((a_d > T(0)) & ((a_n - g_n) < (T(-0.5) * a_d))) ? __builtin_fma(T(0.5), a_d, a_n) : g_n;
     T rs_d = sh.omf * (a_d - g_d);
     T rs_n = sh.omf * (a_n - g_n);
     // -- period-independent terms
-    sh.p_rel = x.pa * T(1.0 / 101300.0);
-    sh.k_p = x.pa * T(1013.0 / 0.622);
-    sh.p_mbar_k = x.pa * T(0.348444 / 100.0);
+    sh.p_rel = x.pa * KP::per_pixel(1.0 / 101300.0);
+    sh.k_p = x.pa * KP::per_pixel(1013.0 / 0.622);
+    sh.p_mbar_k = x.pa * KP::per_pixel(0.348444 / 100.0);
     sh.l_wet = (x.lai == T(0)) ? K<T>::tiny : x.lai;
     sh.lai_tiny = sh.l_wet <= K<T>::tiny;
     sh.lai_pos = x.lai > T(0);
@@ -726,10 +743,10 @@ __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const 
     sh.m_tmin = (tm - p.tmin_close) * p.inv_dtmin;
     sh.m_tmin = (tm < p.tmin_close) ? T(0) : sh.m_tmin;
     sh.m_tmin = (tm >= p.tmin_open) ? T(1) : sh.m_tmin;
-    period_fast<T, true, PET>(x, p, sh, tb, x.t_d, x.vpd_d, a_d, rs_d, o.canopy_d, o.soil_d, o.trans_d,
+    period_fast<T, true, PET, KP>(x, p, sh, tb, x.t_d, x.vpd_d, a_d, rs_d, o.canopy_d, o.soil_d, o.trans_d,
                               &o.pet_d);
     T rn_n = __builtin_fma(x.sw_n, sh.oma, x.lw_n);
-    period_fast<T, false, PET>(x, p, sh, tb, x.t_n, x.vpd_n, rn_n, rs_n, o.canopy_n, o.soil_n, o.trans_n,
+    period_fast<T, false, PET, KP>(x, p, sh, tb, x.t_n, x.vpd_n, rn_n, rs_n, o.canopy_n, o.soil_n, o.trans_n,
                                &o.pet_n);
     return o;
 }
@@ -782,17 +799,27 @@ constexpr double kGuardTmax = 1332.0;         // K; latent heat of vaporization 
 // (The guard's constants live in VECTOR registers: the pixel function fills the scalar register
 // file with its own -- v_fma_f64 takes no literal on gfx9 -- and four more pairs there made the
 // loop spill scalar registers; vector registers are to spare at two waves per SIMD.)
-__device__ __forceinline__ double in_vgpr(double k) {
-    asm("" : "+v"(k));
-    return k;
-}
 __device__ __forceinline__ double guard_temperature(double t) {
     constexpr double mid = 0.5 * (kGuardTmin + kGuardTmax), k = kGuardHuge / (0.5 * (kGuardTmax - kGuardTmin));
     return __builtin_fma(t, in_vgpr(k), in_vgpr(-mid * k));
 }
-__device__ __forceinline__ bool fast_out_of_domain(const PixelIn<double>& x) {
+// The guard's three constants, in vector registers (in_vgpr: the compiler hoists them in front of a loop)
+struct GuardConsts {
+    double t_scale, t_shift, huge;
+};
+__device__ __forceinline__ GuardConsts guard_consts() {
+    constexpr double mid = 0.5 * (kGuardTmin + kGuardTmax), k = kGuardHuge / (0.5 * (kGuardTmax - kGuardTmin));
+    return GuardConsts{in_vgpr(k), in_vgpr(-mid * k), in_vgpr(kGuardHuge)};
+}
+// The guard's magnitude: >= kGuardHuge exactly for the pixels outside the domain. The pipeline keeps
+// it in a VECTOR register and tests it where it is used (a compare into VCC next to its select;
+// the maximum over a thread's pixels once per iteration for the flag record): as a lane mask
+// carried across the pixel function it cost the loop -- which fills the scalar register file on its
+// own -- 46 instructions of scalar-register relief per iteration (28 s_mov re-materialisations, 18
+// v_readlane / v_writelane), more than the guard's own 26 float64 operations (round 4).
+__device__ __forceinline__ double fast_guard_value(const PixelIn<double>& x, const GuardConsts& gc) {
 #ifdef MOD16_NO_GUARD      // measurement / mapping builds only (tests/fuzz_domain.py)
-    return false;
+    return 0.0;
 #else
     // lw_net_day, sw_rad_day and sw_albedo through the day's net radiation A = sw (1 - albedo) +
     // lw, which the pixel function needs anyway: an infinite one of them makes A infinite -- or
@@ -809,12 +836,17 @@ __device__ __forceinline__ bool fast_out_of_domain(const PixelIn<double>& x) {
     m = max_abs(m, x.pa);
     m = max_abs(m, x.vpd_d);
     m = max_abs(m, x.vpd_n);
-    m = max_abs(m, guard_temperature(x.t_d));
-    m = max_abs(m, guard_temperature(x.t_n));
+    m = max_abs(m, __builtin_fma(x.t_d, gc.t_scale, gc.t_shift));
+    m = max_abs(m, __builtin_fma(x.t_n, gc.t_scale, gc.t_shift));
     // (a pressure below 1 Pa -- zero, negative, 1e-300 -- as well: its products with the other
-    // drivers underflow where the reference's do not)
-    return (m >= in_vgpr(kGuardHuge)) | (x.pa < 1.0);
+    // drivers underflow where the reference's do not. Folded into the magnitude through its high
+    // word: 0x7fe00000'xxxxxxxx is at least 2^1023; a NaN pressure compares false)
+    return __hiloint2double((x.pa < 1.0) ? 0x7fe00000 : __double2hiint(m), __double2loint(m));
 #endif
+}
+__device__ __forceinline__ bool fast_out_of_domain(const PixelIn<double>& x) {
+    const GuardConsts gc = guard_consts();
+    return fast_guard_value(x, gc) >= gc.huge;
 }
 
 // ================================================================ raw drivers
@@ -894,24 +926,28 @@ __device__ __forceinline__ PixelIn<double> raw_to_pixel_fast(const RawIn<double>
 // elevation between -2000 m and 12000 m (the interval of the air-pressure polynomial; the Dead Sea
 // shore lies at -430 m, Mount Everest at 8849 m; a DEM's fill value goes the reference's way).
 // fPAR, LAI (byte decodings) and the air pressure (from the bounded elevation) cannot leave it.
-__device__ __forceinline__ bool raw_out_of_domain(const RawIn<double>& r) {
+__device__ __forceinline__ double raw_guard_value(const RawIn<double>& r, const GuardConsts& gc) {
 #ifdef MOD16_NO_GUARD
-    return false;
+    return 0.0;
 #else
-    const double oma = 1.0 - r.alb;                                     // see fast_out_of_domain
+    const double oma = 1.0 - r.alb;                                     // see fast_guard_value
     const double a_d = __builtin_fma(r.sw_d, oma, r.lw_d), rn_n = __builtin_fma(r.sw_n, oma, r.lw_n);
     double m = max_abs(a_d, r.lw_n);
     m = max_abs(m, rn_n);
     m = max_abs(m, r.ps_d);
     m = max_abs(m, r.ps_n);
-    m = max_abs(m, r.qv_d * in_vgpr(kGuardHuge));          // |qv| < 1
-    m = max_abs(m, r.qv_n * in_vgpr(kGuardHuge));
+    m = max_abs(m, r.qv_d * gc.huge);          // |qv| < 1
+    m = max_abs(m, r.qv_n * gc.huge);
     // -2000 m < z < 12000 m: the interval of the pressure polynomial (19.4 kPa .. 127.8 kPa)
     m = max_abs(m, __builtin_fma(r.elev, in_vgpr(kGuardHuge / kElevHalf), in_vgpr(-kElevMid * (kGuardHuge / kElevHalf))));
-    m = max_abs(m, guard_temperature(r.t_d));
-    m = max_abs(m, guard_temperature(r.t_n));
-    return m >= in_vgpr(kGuardHuge);
+    m = max_abs(m, __builtin_fma(r.t_d, gc.t_scale, gc.t_shift));
+    m = max_abs(m, __builtin_fma(r.t_n, gc.t_scale, gc.t_shift));
+    return m;
 #endif
+}
+__device__ __forceinline__ bool raw_out_of_domain(const RawIn<double>& r) {
+    const GuardConsts gc = guard_consts();
+    return raw_guard_value(r, gc) >= gc.huge;
 }
 
 }  // namespace mod16

@@ -54,6 +54,7 @@ constexpr int kDmaNt = 2;            // cache-policy bits of the LDS-DMA loads: 
 #define MOD16_DYN_RUN 8              // pieces per run: 4 saturates the ticket counter (88 atomics/us: +19 %), 16 leaves a longer tail (+0.4-1.4 %)
 #endif
 constexpr int kDynRun = MOD16_DYN_RUN;
+constexpr int kPinLevel = 1;         // constants of the pixel function held in vector registers by the float64 totals instances (mod16_physics.hpp, KPin)
 
 enum StreamMode {
     kStreamPet = 0, kStreamSep8, kStreamSep6, kStreamRaw, kStreamRawTotal, kStreamRawTotalHours,
@@ -466,6 +467,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     for (int i = threadIdx.x; i < kTab; i += kBlock) tab[i] = a.tab[i];
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const GuardConsts gc = guard_consts();      // (three register pairs held through the loop)
     bool flushed = false;
 #pragma nounroll
     for (; cbase + run < npiece; ) {
@@ -517,6 +519,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
             // diagnostics (redo_piece). A raster without such pixels executes the instructions it
             // did before the guard existed, plus the guard's (15 per pixel) and one select.
             bool bad = false;
+            double gmax = 0.0;          // float64 forms: the largest guard magnitude of this thread's pixels
             if constexpr (stream_is_mixed(MODE)) {
                 static_assert(V == 4 || !stream_is_mixed(MODE), "the mixed form is for float32 rasters");
                 // class codes of the four pixels first (the range check's side effect would
@@ -616,7 +619,9 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                                        (double)in[9][j], (double)in[10][j], (double)in[11][j],
                                        (double)in[12][j], (double)in[13][j],
                                        (bits[1] >> (8 * j)) & 0xffu, (bits[2] >> (8 * j)) & 0xffu};
-                    const bool out = raw_out_of_domain(r);
+                    // (a lane mask here, not the magnitude kept in a register pair as below: the raw-driver
+                    // instances have no vector registers to spare)
+                    const bool out = raw_guard_value(r, gc) >= gc.huge;
                     bad |= out;
                     x = raw_to_pixel_fast(r, tab);
                     x.fpar = out ? __builtin_nan("") : x.fpar;
@@ -627,10 +632,13 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                                         (double)in[9][j], (double)in[10][j], (double)in[11][j],
                                         (double)in[12][j], (double)in[13][j]};
                     if constexpr (GUARD) {
-                        const bool out = fast_out_of_domain(x);
-                        bad |= out;
-                        // (the high word decides: 0x7ff80000'xxxxxxxx is a quiet NaN -- one v_cndmask)
-                        x.fpar = __hiloint2double(out ? 0x7ff80000 : __double2hiint(x.fpar), __double2loint(x.fpar));
+                        // the guard's magnitude stays in a vector register: tested here for this
+                        // pixel's select (the high word decides: 0x7ff80000'xxxxxxxx is a quiet NaN --
+                        // one v_cndmask), and once per iteration, as the maximum over the thread's
+                        // pixels, for the flag record
+                        const double gm = fast_guard_value(x, gc);
+                        gmax = FastMath<double>::vmax(gmax, gm);
+                        x.fpar = __hiloint2double(gm >= gc.huge ? 0x7ff80000 : __double2hiint(x.fpar), __double2loint(x.fpar));
                     }
                 }
                 const unsigned c = cls_of[j];
@@ -651,7 +659,9 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                 p.inv_dvpd = l[12 * kLutCols];
                 p.rbl_slope = l[13 * kLutCols];
                 p.inv_beta = l[14 * kLutCols];
-                PixelOut<double> o = et_pixel_fast<double, MODE == kStreamPet>(x, p, tab);
+                // (the totals instances hold the pixel function's busiest constants in vector registers)
+                typedef typename std::conditional<MODE == kStreamTotals && std::is_same<T, double>::value, KPin<kPinLevel>, KLit>::type KP;
+                PixelOut<double> o = et_pixel_fast<double, MODE == kStreamPet, KP>(x, p, tab);
                 const double day = (o.canopy_d + o.soil_d) + o.trans_d;      // :792
                 const double night = (o.canopy_n + o.soil_n) + o.trans_n;
                 if constexpr (MODE == kStreamSep6) {
@@ -695,6 +705,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                 __builtin_nontemporal_store(res[k], reinterpret_cast<VT*>((a.out[k] + first) + lane_elem));
             // a flagged pixel in this piece: remember the piece (see redo_piece above)
             if constexpr (GUARD) {
+                if constexpr (!stream_is_mixed(MODE) && !RAW) bad = gmax >= gc.huge;
                 if (__builtin_expect(__any(bad), 0)) {
                     const int bit = a.static_sched ? iters : run;
                     flags |= 1ull << (bit < kFlagBits - 1 ? bit : kFlagBits - 1);
