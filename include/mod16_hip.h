@@ -393,7 +393,8 @@ MOD16_API int mod16_et_static_f32(mod16_ctx* ctx, const float* const* drivers,
  * within 1e-9 of EXACT, same NaN and zero masks, several times faster); pixels outside that
  * arithmetic's domain (the test of MOD16_MATH_FAST above, on the drivers) are left out by the
  * FAST kernels and computed in the reference's operation order behind them, so FAST returns
- * what EXACT returns for them. With `observed` [n] (and optional
+ * what EXACT returns for them (here also |VPD| >= 1e18 Pa: this path does not clamp the relative
+ * humidity from above, mod16/__init__.py:280-281). With `observed` [n] (and optional
  * `weights` [n]) the call also reduces each draw to
  *     sse[d]   = sum_i (weights[i] * (out_total[d][i] - observed[i]))^2
  *     count[d] = number of pairs used (NaN pairs are skipped),

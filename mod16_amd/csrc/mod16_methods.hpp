@@ -634,7 +634,12 @@ __global__ void __launch_bounds__(kBlock) static_domain_kernel(const StaticBatch
     if (i >= a.n) return;
     auto dv = [&](int k) { return (double)(((a.dense_drv >> k) & 1u) ? a.drv[k][i] : a.drv[k][0]); };
     const PixelIn<double> x = {dv(0), dv(1), dv(2), dv(3), dv(4), dv(5), dv(6), dv(7), dv(8), dv(9), dv(10), dv(11), dv(12), dv(13)};
-    skip[i] = fast_out_of_domain(x) ? 1 : 0;
+    // the forward run's test, and -- this path has no upper clamp on the relative humidity
+    // (mod16/__init__.py:280-281), so rh^4 = ((svp - vpd) / svp)^4 grows without bound for a very
+    // negative VPD and the conductance forms overflow where the reference's quotients do not -- a
+    // VPD beyond 1e18 Pa in magnitude (tests/fuzz_domain.py: -1e15 is inside, -1e30 was not)
+    const bool wild_vpd = (__builtin_fabs(x.vpd_d) >= 1e18) | (__builtin_fabs(x.vpd_n) >= 1e18);
+    skip[i] = (fast_out_of_domain(x) | wild_vpd) ? 1 : 0;
 }
 
 // The pixels the FAST kernels skip (a.skip), in the reference's operation order: their part of

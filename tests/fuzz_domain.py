@@ -105,7 +105,34 @@ def main():
     total += pairs(table, bplut)
     total += raw_pairs(table, bplut)
     total += storm(table, bplut)
+    total += calibration_path(table)
     return 0 if total == 0 else 1
+
+
+def calibration_path(table, ndraw=6):
+    """The FAST arithmetic of the calibration path (MOD16._et_batch(math=FAST) and the bound problem,
+    round 4) over the same ladder: one probe value in one driver per pixel, a few parameter vectors
+    (one with csl = 0: the whole-array switch off), against the oracle's restatement of
+    MOD16._evapotranspiration (mod16/__init__.py:195-382) and against the reference-order kernels."""
+    rng = np.random.default_rng(11)
+    _, drv, which = rasters(LADDER, per=128)
+    lo = np.array([-10, 5, 400, 2000, 0.01, 0.01, 1e-6, 0.001, 20, 60, 50.0])
+    hi = np.array([-6, 15, 1000, 5000, 0.12, 0.12, 1e-4, 0.01, 70, 120, 800.0])
+    params = rng.uniform(lo, hi, (ndraw, 11))
+    params[1, 7] = 0.0
+    fast = m16.MOD16._et_batch(params, *drv, math=m16._lib.MATH_FAST)
+    prob = m16.MOD16._et_bind(*drv, max_draws=ndraw)
+    bound = prob.rows(params)
+    bad = 0
+    if not np.array_equal(fast, bound, equal_nan=True):
+        print('calibration: bound rows differ from the unbound call')
+        bad += 1
+    with np.errstate(all='ignore'):
+        for d in range(ndraw):
+            want = oracle.et_static(list(params[d]), *drv)
+            bad += sum(report('calibration fast float64, draw %d' % d, [fast[d]], [want], which, LADDER, 1e-8))
+    print('calibration: %d of %d pixels outside the fast domain (reference order)' % (prob.n_outside_domain, fast.shape[1]))
+    return bad
 
 
 PAIR_VALUES = [0.0, -0.0, np.nan, np.inf, -np.inf, -9999.0, 65535.0, 1e15, 3.4e38, -3.4e38, 1e300, -1e300,
