@@ -32,6 +32,8 @@ def run_bench(extra_env):
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
     lines = [l for l in proc.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, proc.stdout[-2000:]
+    # rank 0's stdout is the ONE JSON line and nothing else (RCCL's version banner goes to stderr)
+    assert [l for l in proc.stdout.splitlines() if l.strip()] == lines, proc.stdout[:1000]
     return json.loads(lines[0])
 
 
@@ -51,6 +53,12 @@ def test_one_rank_rccl_group_runs_the_multi_gpu_step():
     full = forced['parity']['full_grid_fast_vs_exact_kernel']
     assert full == plain['parity']['full_grid_fast_vs_exact_kernel'] and full['pixels'] == 5400 * 43200
     assert full['nan_masks_equal'] and full['zero_mask_mismatches'] == 0
-    # the collective hides behind the next step's kernel: same step time (two processes, one device)
-    assert abs(forced['ms_per_step'] / plain['ms_per_step'] - 1.0) < 0.015, (forced['ms_per_step'], plain['ms_per_step'])
-    assert abs(forced['roofline']['kernel_ms'] / plain['roofline']['kernel_ms'] - 1.0) < 0.015
+    # the collective hides behind the next step's kernel: same step time. (Two processes one after the
+    # other on one device: 3 % allows for the clock the device holds at its power cap from run to run;
+    # measured 0.1 % -- profiles/r04_one_rank_rccl_group_line.json: 20.04 vs 20.06 ms on the full grid.
+    # The defect this guards against -- graph replays between two barriers that did nothing -- was a
+    # factor of twelve.)
+    assert abs(forced['ms_per_step'] / plain['ms_per_step'] - 1.0) < 0.03, (forced['ms_per_step'], plain['ms_per_step'])
+    assert abs(forced['roofline']['kernel_ms'] / plain['roofline']['kernel_ms'] - 1.0) < 0.03
+    # rank 0's stdout is the one JSON line (RCCL's banner goes to stderr)
+    assert forced['process_group']['backend'] == 'nccl'
