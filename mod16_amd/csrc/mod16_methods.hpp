@@ -433,7 +433,9 @@ __global__ void __launch_bounds__(kBlock) static_obj_kernel(const StaticObjArgs<
     constexpr int kTab = FastMath<double>::kTabDoubles;
     constexpr int kWaves = kBlock / 64;
     __shared__ __attribute__((aligned(16))) double tab[kTab];
-    __shared__ double red[kWaves][kObjPass][64];     // 32 KiB a block
+    // (rows of 65: the column sums below read 16 rows at one lane offset -- with 64 doubles per row all
+    // sixteen would hit the same banks)
+    __shared__ double red[kWaves][kObjPass][65];     // 33 KiB a block
     __shared__ double wsum[kWaves][kObjDraws][2];
     __shared__ unsigned wany[kWaves][kObjDraws];
     __shared__ unsigned todo;
