@@ -1988,9 +1988,10 @@ static void batch_objective_launches(mod16_batch* b, int64_t ndraw) {
         hipLaunchKernelGGL((static_obj_redo_kernel<T>), dim3((unsigned)ndraw), dim3(kBlock), 0, st, r);
     }
     const double* redo = b->nlist ? b->redo : nullptr;
-    hipLaunchKernelGGL(static_obj_any_kernel, dim3(gd), dim3(kBlock), 0, st, b->any_gs, redo, ndraw, b->gx, b->any_draw);
+    const unsigned gr = (unsigned)((ndraw + kObjPerBlock - 1) / kObjPerBlock);
+    hipLaunchKernelGGL(static_obj_any_kernel, dim3(gr), dim3(kBlock), 0, st, b->any_gs, redo, ndraw, b->gx, b->any_draw);
     hipLaunchKernelGGL((static_obj_kernel<T, false>), grid, dim3(kBlock), 0, st, a);
-    hipLaunchKernelGGL(static_obj_final_kernel, dim3(gd), dim3(kBlock), 0, st, b->partial, redo, b->any_draw, ndraw, b->gx,
+    hipLaunchKernelGGL(static_obj_final_kernel, dim3(gr), dim3(kBlock), 0, st, b->partial, redo, b->any_draw, ndraw, b->gx,
                        b->dsse, b->dcnt);
 }
 

@@ -594,37 +594,69 @@ __global__ void __launch_bounds__(kBlock) static_obj_redo_kernel(const StaticObj
         }
 }
 
-// any(g_surf > 0) of every draw over the blocks (and the flagged pixels). One thread per draw;
-// the per-block flags are laid out [block][draw], so a wave reads consecutive words.
+// any(g_surf > 0) of every draw over the blocks (and the flagged pixels), and the final sums. A
+// block handles 32 draws x 8 slices of the pixel blocks (thread: draw d, blocks slice, slice + 8,
+// ...; the per-block values are laid out [block][draw], so 32 lanes read 32 consecutive words),
+// several loads in flight per thread; the slices are combined in order through LDS. (One thread per
+// draw walking all 391 blocks was 92 us per kernel -- two of them 13 % of an evaluation.)
+constexpr int kObjSlices = 8, kObjPerBlock = kBlock / kObjSlices;
 __global__ void __launch_bounds__(kBlock) static_obj_any_kernel(const unsigned* any_gs, const double* redo, int64_t ndraw,
                                                                 int gx, unsigned* any_draw) {
-    const int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (d >= ndraw) return;
+    __shared__ unsigned sm[kObjSlices][kObjPerBlock];
+    const int dl = threadIdx.x % kObjPerBlock, slice = threadIdx.x / kObjPerBlock;
+    const int64_t d = (int64_t)blockIdx.x * kObjPerBlock + dl;
     unsigned any = 0;
-    for (int b = 0; b < gx; ++b) any |= any_gs[(int64_t)b * ndraw + d];
-    if (redo && redo[d * 5 + 4] > 0.0) any = 1u;
-    any_draw[d] = any;
+    if (d < ndraw) {
+#pragma unroll 4
+        for (int b = slice; b < gx; b += kObjSlices) any |= any_gs[(int64_t)b * ndraw + d];
+    }
+    sm[slice][dl] = any;
+    __syncthreads();
+    if (slice == 0 && d < ndraw) {
+#pragma unroll
+        for (int k = 1; k < kObjSlices; ++k) any |= sm[k][dl];
+        if (redo && redo[d * 5 + 4] > 0.0) any = 1u;
+        any_draw[d] = any;
+    }
 }
 
-// sse[d], count[d]: the block partials of the draw in block order, then the flagged pixels'.
-// (By now the partials of a draw without g_surf > 0 anywhere hold the pass without transpiration.)
+// sse[d], count[d]: the block partials of the draw -- slice k adds blocks k, k + 8, ... in order,
+// the slices are added in order -- then the flagged pixels'. A fixed order: the same bits on every
+// launch. (By now the partials of a draw without g_surf > 0 anywhere hold the pass without
+// transpiration.)
 __global__ void __launch_bounds__(kBlock) static_obj_final_kernel(const double* partial, const double* redo,
                                                                   const unsigned* any_draw, int64_t ndraw, int gx,
                                                                   double* sse, double* count) {
-    const int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (d >= ndraw) return;
+    __shared__ double sm[kObjSlices][kObjPerBlock][2];
+    const int dl = threadIdx.x % kObjPerBlock, slice = threadIdx.x / kObjPerBlock;
+    const int64_t d = (int64_t)blockIdx.x * kObjPerBlock + dl;
     double s = 0.0, n = 0.0;
-    for (int b = 0; b < gx; ++b) {
-        s += partial[((int64_t)b * ndraw + d) * 2];
-        n += partial[((int64_t)b * ndraw + d) * 2 + 1];
+    if (d < ndraw) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+#pragma unroll 4
+        for (int b = slice; b < gx; b += kObjSlices) {
+            const d2 v = *reinterpret_cast<const d2*>(partial + ((int64_t)b * ndraw + d) * 2);
+            s += v[0];
+            n += v[1];
+        }
     }
-    if (redo) {
-        const int o = any_draw[d] ? 0 : 2;
-        s += redo[d * 5 + o];
-        n += redo[d * 5 + o + 1];
+    sm[slice][dl][0] = s;
+    sm[slice][dl][1] = n;
+    __syncthreads();
+    if (slice == 0 && d < ndraw) {
+#pragma unroll
+        for (int k = 1; k < kObjSlices; ++k) {
+            s += sm[k][dl][0];
+            n += sm[k][dl][1];
+        }
+        if (redo) {
+            const int o = any_draw[d] ? 0 : 2;
+            s += redo[d * 5 + o];
+            n += redo[d * 5 + o + 1];
+        }
+        sse[d] = s;
+        count[d] = n;
     }
-    sse[d] = s;
-    count[d] = n;
 }
 
 // bind time: which pixels lie outside the domain of the FAST arithmetic (mod16_physics.hpp,
