@@ -432,14 +432,16 @@ static StreamGeom stream_geom(const mod16_ctx* ctx, int64_t n, int V, int tile_s
     if (tile_shift != kNoTile) ++run_shift;
     while (run_shift > 1 && (g.npiece >> run_shift) < chip_waves) --run_shift;   // >= 2 pieces: the claim of a run is consumed in its second iteration
     // A small raster (fewer than kStaticBelow runs per wave) is latency-bound and ends
-    // with its slowest wave: runs of 2 pieces dealt out round-robin -- all waves start
-    // together, so this is balanced to within one run, and no claim's round trip sits
-    // on a path that is only a few iterations long (1200 x 1200: 6 pieces at most per
-    // wave instead of 8).
+    // with its slowest SIMD: single pieces dealt out round-robin -- all waves start together,
+    // no claim's round trip sits on a path that is only a few iterations long, and the load is
+    // balanced to within one PIECE per wave. (Rounds 2-3 dealt runs of 2 pieces: a 1200 x 1200
+    // raster, 11250 pieces over 2048 waves, then gave the waves 6 or 4 pieces, and since a CU holds
+    // blocks c and c + 256, the first 127 CUs got 12 pieces per SIMD against an average of 11;
+    // piece by piece it is 6 or 5 per wave and at most 11 per SIMD.)
     g.static_sched = 0;
     if (ctx->static_below > 0 && (g.npiece >> run_shift) < (int64_t)ctx->static_below * chip_waves) {
         g.static_sched = 1;
-        run_shift = 1;
+        run_shift = 0;
     }
     if (ctx->run_shift > 0) run_shift = ctx->run_shift;
     run_shift = std::min(run_shift, tile_shift);     // a run never straddles two tiles
