@@ -1846,8 +1846,9 @@ static int batch_bind(mod16_ctx* ctx, const T* const* drivers, const int64_t* ds
                       mod16_batch** out) {
     if (!ctx || !out) return MOD16_ERR_ARG;
     *out = nullptr;
-    if (!drivers || !dstride || n <= 0 || max_draws <= 0 || max_draws > 0x7fffffff)
-        return fail(ctx, MOD16_ERR_ARG, "mod16_static_batch_bind: NULL drivers, n <= 0 or max_draws out of range");
+    // (a launch evaluates 32 draws per block row: 65535 rows at most)
+    if (!drivers || !dstride || n <= 0 || max_draws <= 0 || max_draws > (int64_t)65535 * kObjDraws)
+        return fail(ctx, MOD16_ERR_ARG, "mod16_static_batch_bind: NULL drivers, n <= 0 or max_draws outside 1 .. 2097120");
     if (weights && !observed) return fail(ctx, MOD16_ERR_ARG, "mod16_static_batch_bind: weights need observed");
     if (where != MOD16_HOST && where != MOD16_DEVICE) return fail(ctx, MOD16_ERR_ARG, "mod16_static_batch_bind: bad `where`");
     for (int k = 0; k < 14; ++k) {

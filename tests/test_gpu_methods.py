@@ -504,6 +504,28 @@ def test_bound_calibration_problem(m16, golden):
     np.testing.assert_allclose(s32, s0, rtol=1e-6)       # (the unbound call reduces rows rounded to float32)
 
 
+def test_bound_calibration_problem_at_size(m16):
+    """A million pixels (3907 pixel blocks behind every draw's sums) and a ragged number of draws:
+    the fused objective against the rows it never materialises, reduced with numpy."""
+    n = 1_000_003
+    drv, lo, hi, rng = _calibration_inputs(n, 48)
+    params = rng.uniform(lo, hi, (45, 11))
+    params[44, 7] = 0.0
+    obs, w = rng.normal(30, 10, n), rng.uniform(0.5, 2, n)
+    prob = m16.MOD16._et_bind(*drv, observed=obs, weights=w, max_draws=64)
+    sse, cnt = prob.objective(params)
+    rows = prob.rows(params)
+    assert rows.shape == (45, n)
+    assert np.all(cnt > 0.9 * n) and np.all(np.isfinite(sse))
+    # counts = finite rows (the observations and weights are finite)
+    r = (rows - obs) * w
+    ok = np.isfinite(r)
+    assert np.array_equal(cnt, ok.sum(1).astype(float))
+    np.testing.assert_allclose(sse, np.where(ok, r * r, 0).sum(1), rtol=1e-11)
+    with pytest.raises(m16._lib.Mod16Error):
+        m16.MOD16._et_bind(*drv, max_draws=65535 * 32 + 1)
+
+
 SPECIAL = [np.inf, -np.inf, 1e300, -1e300, 3.4e38, -9999.0, 65535.0, 1e15, 35.85, 1400.0, 0.0, -1.0, 1e-300]
 
 
