@@ -75,6 +75,11 @@ def test_no_device_fails_loudly(lib):
     model = mod16_amd.MOD16(dict.fromkeys(mod16_amd.MOD16.required_parameters, 1.0))
     with pytest.raises(lib.Mod16Error, match='no CPU fallback'):
         model.evapotranspiration(*([1.0] * 14))
+    # the calibration interface likewise: one vector, batched, bound
+    with pytest.raises(lib.Mod16Error, match='no CPU fallback'):
+        mod16_amd.MOD16._et([1.0] * 11, *([1.0] * 14))
+    with pytest.raises(lib.Mod16Error, match='no CPU fallback'):
+        mod16_amd.MOD16._et_bind(*([1.0] * 14), observed=1.0)
 
 
 def test_product_never_imports_the_oracle():
