@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MOD16_ABI_VERSION 3
+#define MOD16_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define MOD16_API __attribute__((visibility("default")))
@@ -209,6 +209,36 @@ MOD16_API int mod16_et_f32(mod16_ctx* ctx, const uint8_t* cls,
                  int64_t n, float* out_day, float* out_night,
                  float* const* out_sep, unsigned flags, int where,
                  void* stream);
+
+/*
+ * HOST mode with diagnostics, and the unit the multi-GPU entry points of the Python layer deal
+ * out. The numpy entry points (MOD16.evapotranspiration(), mod16/__init__.py:675-793, and
+ * evapotranspiration_raster) stage host arrays through the GPU in tiles of
+ * mod16_host_tile_pixels() pixels. mod16_et_hdiag_* is mod16_et_* with where = MOD16_HOST and
+ * both totals, plus ONE diagnostics vector per staged tile: tile_diag is a HOST array
+ * [ceil(n / mod16_host_tile_pixels())][8] (layout of mod16_reduce_diag_*), row t reduced on the
+ * device, in a fixed order, from the outputs of pixels [t * tile, (t + 1) * tile) while they are
+ * still there. Because a tile's row depends on that tile alone, a raster cut at tile boundaries
+ * and dealt over several contexts / GPUs (one host thread per ctx, each writing its rows of the
+ * one array) gives the same rows -- and, folded in tile order with mod16_fold_diag_host, the same
+ * diagnostics bit for bit -- as the undivided call, whatever the number of GPUs (SURVEY.md 8e:
+ * "tiles of the global grid shard embarrassingly", here for the PCIe-bound HOST paths, one link
+ * per GPU, no collective).
+ */
+MOD16_API int64_t mod16_host_tile_pixels(void);
+MOD16_API int mod16_et_hdiag_f64(mod16_ctx* ctx, const uint8_t* cls,
+                       const double* const* drivers, const int64_t* dstride,
+                       const double* const* params, const int64_t* pstride,
+                       int64_t n, double* out_day, double* out_night,
+                       unsigned flags, double* tile_diag);
+MOD16_API int mod16_et_hdiag_f32(mod16_ctx* ctx, const uint8_t* cls,
+                       const float* const* drivers, const int64_t* dstride,
+                       const float* const* params, const int64_t* pstride,
+                       int64_t n, float* out_day, float* out_night,
+                       unsigned flags, double* tile_diag);
+/* diag[8] = parts[0] (+) parts[1] (+) ... in the order given: sums and counts [0..5] added,
+ * maxima [6..7] maximised (host arrays; the rule of mod16_fold_diag). Needs no ctx. */
+MOD16_API int mod16_fold_diag_host(const double* parts, int64_t count, double* diag);
 
 /*
  * Forward run that also returns potential ET: as

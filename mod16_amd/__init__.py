@@ -107,12 +107,28 @@ def _marshal(values, shape, dtype, kinds=False):
     return keep, ptrs, strides
 
 
-def _forward(cls, drivers, params, separate, flags, device, pet=False, out=None):
+def _shift(ptrs, kinds, off, inner, itemsize):
+    '''The addresses of pixel ``off`` onwards: dense arrays move by ``off``
+    elements, (T, 1) columns by ``off // inner`` (``off`` is then a multiple of
+    ``inner``), scalars and (N,) rows stay.'''
+    if ptrs is None or off == 0:
+        return ptrs
+    step = {_lib.BC_SCALAR: 0, _lib.BC_DENSE: off, _lib.BC_ROW: 0, _lib.BC_COL: off // max(inner, 1)}
+    return [p + step[k] * itemsize if p is not None else None for p, k in zip(ptrs, kinds)]
+
+
+def _forward(cls, drivers, params, separate, flags, device, pet=False, out=None,
+             devices=None, table=None, diagnostics=False):
     '''Shared host path of MOD16.evapotranspiration and
     evapotranspiration_raster: marshal numpy inputs, run mod16_et_* in HOST
     mode, shape the outputs as the reference does (mod16/__init__.py:789-793).
+    ``devices``: the pixel range dealt over several GPUs (``mod16_amd.multi``);
+    ``table``: the BPLUT every context that takes part is given first;
+    ``diagnostics``: also the vector of ``raster.DIAG_FIELDS`` (per staging
+    tile on the device, folded in tile order).
     '''
-    ctx = _lib.context(device)
+    from . import multi
+    devs = multi.device_list(devices)
     values = list(drivers) + (list(params) if params is not None else [])
     dtype = _result_dtype(values)
     shapes = [np.shape(v) for v in values]
@@ -125,9 +141,11 @@ def _forward(cls, drivers, params, separate, flags, device, pet=False, out=None)
         shapes.append(cls.shape)
     shape = np.broadcast_shapes(*shapes)
     n = int(np.prod(shape, dtype=np.int64))
+    if diagnostics and (pet or separate):
+        raise ValueError('diagnostics come with the (day, night) totals only')
     # (N,) rows and (..., 1) columns against (..., N) drivers are not made dense
     # (reference mod16/__init__.py:180-181): the C ABI takes them as they are
-    two_level = not pet and len(shape) >= 2 and n > 0
+    two_level = not pet and not diagnostics and len(shape) >= 2 and n > 0
     keep_d, dptr, dstride = _marshal(drivers, shape, dtype, kinds=two_level)
     pptr = pstride = cptr = None
     ckind = _lib.BC_DENSE
@@ -142,20 +160,8 @@ def _forward(cls, drivers, params, separate, flags, device, pet=False, out=None)
         keep_p, pptr, pstride = _marshal(params, shape, dtype, kinds=two_level)
     two_level = two_level and (ckind != _lib.BC_DENSE or max(dstride) > 1 or
                                (pstride is not None and max(pstride) > 1))
-    if pet:
-        outs = [_lib.pinned.empty(shape, dtype) for _ in range(4)]
-        if n:
-            fn = ctx.lib.mod16_et_pet_f32 if dtype == np.float32 else ctx.lib.mod16_et_pet_f64
-            ctx.check(fn(
-                ctx.handle, cptr, _lib.ptr_array(dptr), _lib.i64_array(dstride),
-                _lib.ptr_array(pptr) if pptr is not None else None,
-                _lib.i64_array(pstride) if pstride is not None else None, n,
-                outs[0].ctypes.data, outs[1].ctypes.data, outs[2].ctypes.data,
-                outs[3].ctypes.data, int(flags), _lib.HOST, None))
-        if not shape:
-            outs = [o[()] for o in outs]
-        return tuple(outs)
-    nout = 6 if separate else 2
+    inner = shape[-1] if two_level else 1
+    nout = 4 if pet else (6 if separate else 2)
     if out is not None:      # caller's arrays (e.g. memory-mapped files), written in place
         outs = list(out)
         if len(outs) != nout:
@@ -167,22 +173,61 @@ def _forward(cls, drivers, params, separate, flags, device, pet=False, out=None)
                                  % (dtype, shape))
     else:
         outs = [_lib.pinned.empty(shape, dtype) for _ in range(nout)]
-    if separate:
-        day = night = None
-        sep = [o.ctypes.data for o in outs]
+    optr = [o.ctypes.data for o in outs]
+    esz = dtype.itemsize
+    tile = multi.host_tile()
+    tile_diag = np.empty((max(1, -(-n // tile)), 8), np.float64) if diagnostics else None
+
+    def part(ctx, off, m):
+        '''pixels [off, off + m) on the calling thread's context'''
+        if table is not None:
+            ctx.set_bplut(table)
+        if m <= 0:
+            return
+        d = _shift(dptr, dstride, off, inner, esz)
+        p = _shift(pptr, pstride, off, inner, esz)
+        c = _shift([cptr], [ckind], off, inner, 1)[0]
+        o = [a + off * esz for a in optr]
+        if pet:
+            fn = ctx.lib.mod16_et_pet_f32 if dtype == np.float32 else ctx.lib.mod16_et_pet_f64
+            ctx.check(fn(
+                ctx.handle, c, _lib.ptr_array(d), _lib.i64_array(dstride),
+                _lib.ptr_array(p) if p is not None else None,
+                _lib.i64_array(pstride) if pstride is not None else None, m,
+                o[0], o[1], o[2], o[3], int(flags), _lib.HOST, None))
+            return
+        if diagnostics:
+            fn = ctx.lib.mod16_et_hdiag_f32 if dtype == np.float32 else ctx.lib.mod16_et_hdiag_f64
+            ctx.check(fn(
+                ctx.handle, c, _lib.ptr_array(d), _lib.i64_array(dstride),
+                _lib.ptr_array(p) if p is not None else None,
+                _lib.i64_array(pstride) if pstride is not None else None, m,
+                o[0], o[1], int(flags), tile_diag[off // tile:].ctypes.data))
+            return
+        day, night, sep = (None, None, o) if separate else (o[0], o[1], None)
+        if two_level:
+            ctx.et2(dtype, c, ckind, d, dstride, p, pstride, inner, m, day, night,
+                    sep, flags=flags, where=_lib.HOST)
+        else:
+            ctx.et(dtype, c, d, dstride, p, pstride, m, day, night, sep,
+                   flags=flags, where=_lib.HOST)
+
+    if devs is None:
+        part(_lib.context(device), 0, n)
     else:
-        day, night = outs[0].ctypes.data, outs[1].ctypes.data
-        sep = None
-    if n and two_level:
-        ctx.et2(dtype, cptr, ckind, dptr, dstride, pptr, pstride, shape[-1], n, day, night,
-                sep, flags=flags, where=_lib.HOST)
-    elif n:
-        ctx.et(dtype, cptr, dptr, dstride, pptr, pstride, n, day, night, sep,
-               flags=flags, where=_lib.HOST)
+        # whole staging tiles per device (two-level shapes: whole rows), so every tile is the
+        # tile of the undivided call
+        cuts = multi.shards(n, len(devs), inner if two_level else tile)
+        multi.run(devs, lambda i, ctx: part(ctx, *cuts[i]))
     if not shape:      # all-scalar input: numpy scalars, as the reference
         outs = [o[()] for o in outs]
+    if pet:
+        return tuple(outs)
     if separate:
         return (tuple(outs[0:3]), tuple(outs[3:6]))
+    if diagnostics:
+        return (outs[0], outs[1], multi.fold_diag(tile_diag) if n else
+                np.array([0, 0, 0, 0, 0, 0, -np.inf, -np.inf]))
     return (outs[0], outs[1])
 
 
@@ -249,6 +294,11 @@ class MOD16(object):
         against the driver arrays (per-pixel parameters)
     device : int
         (Extension) index of the GPU to run on (Default: 0)
+    devices : sequence of int
+        (Extension) several GPUs for ``evapotranspiration()`` on large arrays: the
+        pixels are dealt over them at staging-tile boundaries, one host thread and
+        PCIe link each (``mod16_amd.multi``); the results are the same bits as on
+        one device. Default: None, the one ``device``.
     '''
     required_parameters = [
         'tmin_close', 'tmin_open', 'vpd_open', 'vpd_close', 'gl_sh', 'gl_wv',
@@ -259,9 +309,10 @@ class MOD16(object):
     #: _lib.MATH_EXACT (reference operation order, IEEE divide and pow)
     math = _lib.MATH_FAST
 
-    def __init__(self, params, device=0):
+    def __init__(self, params, device=0, devices=None):
         self.params = params
         self.device = device
+        self.devices = devices
         for key in self.required_parameters:   # KeyError if one is missing
             setattr(self, key, params[key])
 
@@ -321,7 +372,7 @@ class MOD16(object):
             pressure, fpar, lai)
         return _forward(
             None, drivers, self._param_values(), separate, self.math,
-            self.device)
+            self.device, devices=self.devices)
 
 
     def evapotranspiration_and_pet(
@@ -346,7 +397,7 @@ class MOD16(object):
             temp_day, temp_night, temp_annual, tmin, vpd_day, vpd_night,
             pressure, fpar, lai)
         return _forward(None, drivers, self._param_values(), False, self.math,
-                        self.device, pet=True)
+                        self.device, pet=True, devices=self.devices)
 
     # ---- the rest of the reference's class surface, on the GPU as well
     #      (mod16_method_*: reference operation order, IEEE divide / pow)
@@ -721,7 +772,8 @@ def evapotranspiration_raster(
         bplut, cls, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
         sw_albedo, temp_day, temp_night, temp_annual, tmin, vpd_day,
         vpd_night, pressure, fpar, lai, separate=False, beta=None,
-        math=_lib.MATH_FAST, device=0, pet=False, out=None):
+        math=_lib.MATH_FAST, device=0, pet=False, out=None, devices=None,
+        diagnostics=False):
     r'''
     Forward run over a multi-class raster. Equivalent to the reference idiom
     (forward-run notebook, cell 32)::
@@ -752,6 +804,18 @@ def evapotranspiration_raster(
         (Extension) the 2 (or, with ``separate``, 6) output arrays to write
         into instead of allocating them, e.g. memory-mapped files
         (``mod16_amd.io``)
+    devices : sequence of int
+        (Extension) several GPUs behind this one call: the flattened raster is
+        cut at the boundaries of the HOST mode's staging tiles and dealt over
+        the listed devices in order, one host thread, context and PCIe link per
+        entry (``mod16_amd.multi``; SURVEY.md 8e without a collective). Outputs
+        and diagnostics are bit-identical to ``devices=[0]`` whatever the list;
+        a class code >= 13 anywhere still raises IndexError.
+    diagnostics : bool
+        (Extension) True to return ``(day, night, diag)``: ``diag`` is the
+        float64 vector of ``mod16_amd.raster.DIAG_FIELDS`` (sums, counts of
+        finite / NaN pixels, maxima), reduced on the GPU tile by tile while the
+        results are there and folded in tile order
 
     Returns
     -------
@@ -766,19 +830,19 @@ def evapotranspiration_raster(
         if beta is not None:
             fill = np.isnan(table[:, 10]) & ~np.isnan(table[:, 0])
             table[fill, 10] = beta
-    _lib.context(device).set_bplut(table)
     drivers = (
         lw_net_day, lw_net_night, sw_rad_day, sw_rad_night, sw_albedo,
         temp_day, temp_night, temp_annual, tmin, vpd_day, vpd_night,
         pressure, fpar, lai)
-    return _forward(cls, drivers, None, separate, math, device, pet=pet, out=out)
+    return _forward(cls, drivers, None, separate, math, device, pet=pet, out=out,
+                    devices=devices, table=table, diagnostics=diagnostics)
 
 
 def evapotranspiration_raw(
         bplut, cls, lw_net_day, lw_net_night, sw_rad_day, sw_rad_night,
         sw_albedo, temp_day, temp_night, temp_annual, tmin, qv10m_day,
         qv10m_night, ps_day, ps_night, elevation, fpar_pct, lai_x10,
-        day_hours=None, beta=None, math=_lib.MATH_FAST, device=0):
+        day_hours=None, beta=None, math=_lib.MATH_FAST, device=0, devices=None):
     r'''
     (Extension) Forward run on raw drivers: the
     pre-processing the reference does in front of ``evapotranspiration()``
@@ -794,15 +858,16 @@ def evapotranspiration_raw(
     Returns ``(day, night)`` [kg m-2 s-1] or, with ``day_hours`` (hours of
     daylight), ``(day, night, total8)`` where ``total8 = (day h + night (24 -
     h)) * 8 * 3600`` [kg m-2 (8 d)-1], the MOD16A2 unit
-    (tests/verification/verify2.py:113-115).
+    (tests/verification/verify2.py:113-115). ``devices``: several GPUs behind the
+    one call, as for ``evapotranspiration_raster``.
     '''
+    from . import multi
     from .utils import bplut_table
     table = bplut_table(bplut, beta=beta) if isinstance(bplut, dict) else np.array(bplut, np.float64)
     if not isinstance(bplut, dict) and beta is not None:
         fill = np.isnan(table[:, 10]) & ~np.isnan(table[:, 0])
         table[fill, 10] = beta
-    ctx = _lib.context(device)
-    ctx.set_bplut(table)
+    devs = multi.device_list(devices)
     raw = [lw_net_day, lw_net_night, sw_rad_day, sw_rad_night, sw_albedo,
            temp_day, temp_night, temp_annual, tmin, qv10m_day, qv10m_night,
            ps_day, ps_night, elevation]
@@ -821,13 +886,25 @@ def evapotranspiration_raw(
             a = a.astype(np.uint8)
         bytes_.append(np.ascontiguousarray(np.broadcast_to(a, shape)))
     outs = [_lib.pinned.empty(shape, dtype) for _ in range(3 if hours else 2)]
-    if n:
+    esz = dtype.itemsize
+
+    def part(ctx, off, m):
+        ctx.set_bplut(table)
+        if m <= 0:
+            return
         fn = ctx.lib.mod16_et_raw_f32 if dtype == np.float32 else ctx.lib.mod16_et_raw_f64
         ctx.check(fn(
-            ctx.handle, bytes_[0].ctypes.data, _lib.ptr_array(rptr), _lib.i64_array(rstr),
-            bytes_[1].ctypes.data, bytes_[2].ctypes.data, hptr[0], int(hstr[0]), n,
-            outs[0].ctypes.data, outs[1].ctypes.data,
-            outs[2].ctypes.data if hours else None, int(math), _lib.HOST, None))
+            ctx.handle, bytes_[0].ctypes.data + off, _lib.ptr_array(_shift(rptr, rstr, off, 1, esz)),
+            _lib.i64_array(rstr), bytes_[1].ctypes.data + off, bytes_[2].ctypes.data + off,
+            _shift(hptr, hstr, off, 1, esz)[0], int(hstr[0]), m,
+            outs[0].ctypes.data + off * esz, outs[1].ctypes.data + off * esz,
+            outs[2].ctypes.data + off * esz if hours else None, int(math), _lib.HOST, None))
+
+    if devs is None:
+        part(_lib.context(device), 0, n)
+    else:
+        cuts = multi.shards(n, len(devs), multi.host_tile())
+        multi.run(devs, lambda i, ctx: part(ctx, *cuts[i]))
     if not shape:
         outs = [o[()] for o in outs]
     return tuple(outs)

@@ -75,6 +75,7 @@ struct mod16_ctx {
     bool ws_pending = false;
     double* diag_dev = nullptr;      // device [kDiag]
     double* diag_host = nullptr;     // pinned [kDiag]
+    double* hdiag_dev = nullptr;     // device [kSlots][kDiag]: per-tile diagnostics of the HOST mode (mod16_et_hdiag_*)
     // HOST-mode staging: per slot one device slab + one stream
     void* slab[kSlots] = {};
     size_t slab_bytes = 0;
@@ -164,6 +165,7 @@ extern "C" int mod16_destroy(mod16_ctx* ctx) {
     if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
     if (ctx->diag_dev) (void)hipFree(ctx->diag_dev);
     if (ctx->diag_host) (void)hipHostFree(ctx->diag_host);
+    if (ctx->hdiag_dev) (void)hipFree(ctx->hdiag_dev);
     delete ctx;
     return MOD16_OK;
 }
@@ -234,6 +236,7 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming));
         HIPCHK(ctx, hipMalloc(&ctx->diag_dev, sizeof(double) * kDiag));
         HIPCHK(ctx, hipHostMalloc(&ctx->diag_host, sizeof(double) * kDiag));
+        HIPCHK(ctx, hipMalloc(&ctx->hdiag_dev, sizeof(double) * kDiag * kSlots));
         HIPCHK(ctx, hipMalloc(&ctx->scalars, 32 * sizeof(double)));
         return MOD16_OK;
     }();
@@ -741,7 +744,8 @@ template <typename T> struct BcTable {
 
 template <typename T>
 static int stage_tile(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags, const T* dscal,
-                      size_t per_arr, int slot, int64_t off, int64_t m, const BcTable<T>& bc) {
+                      size_t per_arr, int slot, int64_t off, int64_t m, const BcTable<T>& bc,
+                      double* tile_diag = nullptr) {
     hipStream_t st = ctx->streams[slot];
     char* base = static_cast<char*>(ctx->slab[slot]);
     EtArgs<T> d = h;
@@ -781,19 +785,23 @@ static int stage_tile(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags, const 
     }
     for (int k = 0; k < 10; ++k)
         d.out[k] = h.out[k] ? reinterpret_cast<T*>(base + per_arr * (25 + k)) : nullptr;
+    // tile_diag: the diagnostics vector of THIS tile (host, 8 doubles), reduced on the device
+    // while the tile's outputs are there
+    double* dd = tile_diag ? ctx->hdiag_dev + (size_t)slot * kDiag : nullptr;
     {
         std::lock_guard<std::mutex> lock(ctx->launch_mu);
-        int rc = launch_et<T>(ctx, d, flags, st);
+        int rc = launch_et<T>(ctx, d, flags, st, dd);
         if (rc != MOD16_OK) return rc;
     }
     for (int k = 0; k < 10; ++k)
         if (h.out[k]) HIPCHK(ctx, hipMemcpyAsync(h.out[k] + off, d.out[k], sizeof(T) * m, hipMemcpyDeviceToHost, st));
+    if (dd) HIPCHK(ctx, hipMemcpyAsync(tile_diag, dd, sizeof(double) * kDiag, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));      // the slab of this slot is free again
     return MOD16_OK;
 }
 
 template <typename T>
-static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
+static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags, double* tile_diag = nullptr) {
     const int64_t n = h.n;
     if (n == 0) return MOD16_OK;
     const int64_t tile = std::min<int64_t>(n, kTilePixels);
@@ -869,7 +877,8 @@ static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
     }
     if (nslots == 1) {
         for (int64_t off = 0; off < n; off += tile) {
-            int rc = stage_tile<T>(ctx, h, flags, dscal, per_arr, 0, off, std::min(tile, n - off), bc);
+            int rc = stage_tile<T>(ctx, h, flags, dscal, per_arr, 0, off, std::min(tile, n - off), bc,
+                                   tile_diag ? tile_diag + (off / tile) * kDiag : nullptr);
             if (rc != MOD16_OK) return rc;
         }
     } else {
@@ -879,7 +888,8 @@ static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
             workers.emplace_back([&, s]() {
                 if (hipSetDevice(ctx->device) != hipSuccess) { rcs[s] = MOD16_ERR_HIP; return; }
                 for (int64_t t = s; t < ntiles && rcs[s] == MOD16_OK; t += nslots)
-                    rcs[s] = stage_tile<T>(ctx, h, flags, dscal, per_arr, s, t * tile, std::min(tile, n - t * tile), bc);
+                    rcs[s] = stage_tile<T>(ctx, h, flags, dscal, per_arr, s, t * tile, std::min(tile, n - t * tile), bc,
+                                           tile_diag ? tile_diag + t * kDiag : nullptr);
             });
         for (auto& w : workers) w.join();
         for (int s = 0; s < nslots; ++s)
@@ -943,6 +953,55 @@ extern "C" int mod16_et2_f32(mod16_ctx* ctx, const uint8_t* cls, int cls_kind,
     if (ctx && inner <= 0) return fail(ctx, MOD16_ERR_ARG, "mod16_et2: inner must be positive");
     return et_entry<float>(ctx, cls, drivers, dkind, params, pkind, n, out_day, out_night,
                            out_sep, flags, where, stream, nullptr, nullptr, inner, cls_kind);
+}
+
+// ---- HOST mode with diagnostics (mod16_et_hdiag_*): the forward run of mod16_et_* on host arrays,
+// plus one diagnostics vector PER STAGED TILE of mod16_host_tile_pixels() pixels, reduced on the
+// device while the tile's outputs are there (nothing is uploaded again).
+extern "C" int64_t mod16_host_tile_pixels(void) { return kTilePixels; }
+
+template <typename T>
+static int hdiag_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drivers, const int64_t* dstride,
+                       const T* const* params, const int64_t* pstride, int64_t n, T* out_day, T* out_night,
+                       unsigned flags, double* tile_diag) {
+    if (!ctx) return MOD16_ERR_ARG;
+    if (!out_day || !out_night || !tile_diag)
+        return fail(ctx, MOD16_ERR_ARG, "mod16_et_hdiag: out_day, out_night and tile_diag are required");
+    EtArgs<T> a;
+    int rc = fill_args<T>(ctx, a, cls, drivers, dstride, params, pstride, n, out_day, out_night, nullptr);
+    if (rc != MOD16_OK) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return run_host<T>(ctx, a, flags, tile_diag);
+}
+extern "C" int mod16_et_hdiag_f64(mod16_ctx* ctx, const uint8_t* cls, const double* const* drivers,
+                                  const int64_t* dstride, const double* const* params, const int64_t* pstride,
+                                  int64_t n, double* out_day, double* out_night, unsigned flags,
+                                  double* tile_diag) {
+    MOD16_LOCK(ctx);
+    return hdiag_entry<double>(ctx, cls, drivers, dstride, params, pstride, n, out_day, out_night, flags, tile_diag);
+}
+extern "C" int mod16_et_hdiag_f32(mod16_ctx* ctx, const uint8_t* cls, const float* const* drivers,
+                                  const int64_t* dstride, const float* const* params, const int64_t* pstride,
+                                  int64_t n, float* out_day, float* out_night, unsigned flags,
+                                  double* tile_diag) {
+    MOD16_LOCK(ctx);
+    return hdiag_entry<float>(ctx, cls, drivers, dstride, params, pstride, n, out_day, out_night, flags, tile_diag);
+}
+
+// The fold of `count` diagnostics vectors on the host, in the order given: sums and counts [0..5]
+// added first to last, maxima [6..7] maximised -- mod16_fold_diag's rule (NaN maxima of empty
+// parts are skipped the same way: `o > acc`).
+extern "C" int mod16_fold_diag_host(const double* parts, int64_t count, double* diag) {
+    if (!parts || !diag || count < 1) return MOD16_ERR_ARG;
+    for (int k = 0; k < kDiag; ++k) {
+        double acc = parts[k];
+        for (int64_t r = 1; r < count; ++r) {
+            const double o = parts[r * kDiag + k];
+            acc = k < 6 ? acc + o : (o > acc ? o : acc);
+        }
+        diag[k] = acc;
+    }
+    return MOD16_OK;
 }
 
 template <typename T>

@@ -42,7 +42,7 @@ DRIVER_NAMES = (
 
 
 def evapotranspiration_npy(bplut, cls_path, driver_paths, out_day_path, out_night_path,
-                           beta=None, math=_lib.MATH_FAST, device=0):
+                           beta=None, math=_lib.MATH_FAST, device=0, devices=None):
     '''
     ``evapotranspiration_raster`` on ``.npy`` files.
 
@@ -57,6 +57,8 @@ def evapotranspiration_npy(bplut, cls_path, driver_paths, out_day_path, out_nigh
         of the class raster's shape, all float64 or all float32
     out_day_path, out_night_path : str
         ``.npy`` files to create (same shape and dtype as the drivers)
+    devices : sequence of int
+        Several GPUs behind the call, as for ``evapotranspiration_raster``
 
     Returns
     -------
@@ -80,7 +82,8 @@ def evapotranspiration_npy(bplut, cls_path, driver_paths, out_day_path, out_nigh
             raise ValueError('%s: expected a C-ordered %s array of shape %s' % (name, dtype, cls.shape))
     outs = [np.lib.format.open_memmap(p, mode='w+', dtype=dtype, shape=cls.shape)
             for p in (out_day_path, out_night_path)]
-    evapotranspiration_raster(bplut, cls, *drivers, beta=beta, math=math, device=device, out=outs)
+    evapotranspiration_raster(bplut, cls, *drivers, beta=beta, math=math, device=device, out=outs,
+                              devices=devices)
     for o in outs:
         o.flush()
     return tuple(outs)
@@ -188,7 +191,7 @@ class RasterStore(object):
 
 
 def run_store(bplut, root, tile_pixels=1 << 22, workers=4, beta=None, math=_lib.MATH_FAST,
-              device=0, readers=3):
+              device=0, readers=3, devices=None):
     '''
     Forward run over every step and pixel of the store at ``root``: reads the raw
     fields, writes ``out/ET_daytime`` and ``out/ET_nighttime`` [kg m-2 s-1], tile
@@ -197,7 +200,10 @@ def run_store(bplut, root, tile_pixels=1 << 22, workers=4, beta=None, math=_lib.
     pipeline share the positional reads and writes of a step -- one thread copies
     13-17 GB/s out of the page cache, which was the bound of the single-reader
     pipeline of round 2). Short-wave radiation at night is zero, as in the
-    reference (calibration.py:383).
+    reference (calibration.py:383). ``devices``: several GPUs (``mod16_amd.multi``) --
+    ``workers`` pipelines on EACH listed device, all taking tile jobs from the one
+    queue; a tile's results do not depend on which pipeline ran it, so the files are the
+    same bytes whatever the list.
 
     Returns a report: per stage (``read``, ``h2d``, ``kernel``, ``d2h``,
     ``write``) the bytes moved, the busy seconds summed over the workers and the
@@ -205,8 +211,10 @@ def run_store(bplut, root, tile_pixels=1 << 22, workers=4, beta=None, math=_lib.
     the wall time of the run itself, sustained pixels/s and file bytes/s.
     '''
     import torch
+    from . import multi
     from .raster import RasterEngine
     from .utils import bplut_table
+    devs = multi.device_list(devices) or [int(device)]
     table = bplut_table(bplut, beta=beta) if isinstance(bplut, dict) else np.array(bplut, np.float64)
     store = RasterStore(root)
     T, N, dt = store.n_steps, store.n_pixels, store.dtype
@@ -221,10 +229,11 @@ def run_store(bplut, root, tile_pixels=1 << 22, workers=4, beta=None, math=_lib.
     stats = {k: [0, 0.0] for k in ('read', 'h2d', 'kernel', 'd2h', 'write')}
     errors = []
 
-    ready = threading.Barrier(max(1, min(workers, len(jobs))) + 1)
+    nthreads = max(1, min(max(1, int(workers)) * len(devs), len(jobs)))
+    ready = threading.Barrier(nthreads + 1)
     esz = dt.itemsize
 
-    def worker():
+    def worker(device):
         try:
             torch.cuda.set_device(device)
             eng = RasterEngine(table, device=device, dtype=dt.name, math=math)
@@ -335,7 +344,9 @@ def run_store(bplut, root, tile_pixels=1 << 22, workers=4, beta=None, math=_lib.
                 pass
 
     t_setup = time.perf_counter()
-    threads = [threading.Thread(target=worker) for _ in range(max(1, min(workers, len(jobs))))]
+    # pipeline k runs on devs[k % len(devs)]: with fewer jobs than pipelines every device still
+    # gets its share
+    threads = [threading.Thread(target=worker, args=(devs[k % len(devs)],)) for k in range(nthreads)]
     for th in threads:
         th.start()
     try:
@@ -351,7 +362,7 @@ def run_store(bplut, root, tile_pixels=1 << 22, workers=4, beta=None, math=_lib.
         raise errors[0]
     total_bytes = stats['read'][0] + stats['write'][0]
     report = {'steps': T, 'pixels': N, 'dtype': dt.name, 'tile_pixels': tile,
-              'workers': len(threads), 'readers_per_worker': max(1, int(readers)), 'setup_s': setup, 'wall_s': wall,
+              'workers': len(threads), 'devices': devs, 'readers_per_worker': max(1, int(readers)), 'setup_s': setup, 'wall_s': wall,
               'pixels_per_s': T * N / wall, 'file_GBps': total_bytes / wall / 1e9,
               'stages': {k: {'bytes': v[0], 'busy_s_sum_over_workers': v[1],
                              'GBps_while_busy': (v[0] / v[1] / 1e9) if v[1] else None}

@@ -747,3 +747,100 @@ class RasterEngine(object):
             self._check_tensor(diag, torch.float64, 8, 'diag') if diag is not None else None,
             int(launches), self._stream(), C.byref(ms)))
         return ms.value
+
+
+class ShardedSeries(object):
+    '''
+    ``RasterEngine.run_series_host`` over several GPUs of one node, in one process
+    (``mod16_amd.multi``; SURVEY.md 8e for the PCIe-bound ingest: N links instead of one,
+    no collective). The tiles of the raster are dealt over ``devices`` in order --
+    device ``i`` holds tiles ``[t0_i, t1_i)`` in a two-slot ring of ``TiledRaster`` of
+    its own, fed by its own host thread, ingest stream and engine -- and every step's
+    kernel runs on each device over its tiles only. A pixel's result does not depend on
+    the device list (``devices=[0]`` and ``[0, 0]`` give the same bits).
+
+    Parameters
+    ----------
+    table : numpy.ndarray
+        (13, 11) BPLUT table
+    n : int
+        Pixels of the raster (a multiple of the 16-byte vector width)
+    devices : sequence of int
+        GPU indices; one may be listed more than once
+    form, dtype, math, trusted, tile
+        As for ``RasterEngine`` / ``RasterEngine.alloc_tiled``; the defaults are the light
+        input form (``FORM_RAW`` on float32: 58 bytes per pixel and step over PCIe)
+    '''
+
+    def __init__(self, table, n, devices, form=_lib.FORM_RAW, dtype='float32',
+                 math=_lib.MATH_FAST, trusted=False, tile=None):
+        from . import multi
+        torch = _torch()
+        devs = multi.device_list(devices)
+        if devs is None:
+            raise ValueError('devices is required')
+        self.n, self.form = int(n), int(form)
+        self.parts = []             # per device that holds tiles: dict(device, engine, ring, t0, t1, offset, n)
+        probe = RasterEngine(table, device=devs[0], dtype=dtype, math=math, trusted=trusted)
+        self.tile = int(tile) if tile else probe.TILE_BYTES // probe.np_dtype.itemsize
+        self.ntiles = max(1, -(-self.n // self.tile))
+        for i, (t0, count) in enumerate(multi.shards(self.ntiles, len(devs), 1)):
+            if not count:
+                continue
+            lo, hi = t0 * self.tile, min(self.n, (t0 + count) * self.tile)
+            with torch.cuda.device(devs[i]):
+                eng = probe if (i == 0) else RasterEngine(table, device=devs[i], dtype=dtype, math=math,
+                                                           trusted=trusted)
+                ring = [eng.alloc_tiled(hi - lo, self.tile, self.form) for _ in range(2)]
+                stream = torch.cuda.Stream(device=eng._dev())
+            self.parts.append(dict(device=devs[i], engine=eng, ring=ring, stream=stream,
+                                   t0=t0, t1=t0 + count, offset=lo, n=hi - lo))
+
+    def run_host(self, host_steps, steps, day_hours=None, on_step=None):
+        '''``run_series_host`` on every device at once. ``host_steps``: as there, records of
+        page-locked CPU tensors covering the WHOLE raster (``ntiles * tile`` elements; ``None`` = the
+        field stays as it is); each device copies its tiles' part. ``on_step(part, s, slot)``
+        is called on the device's own host thread (compute stream current) behind step ``s``'s
+        kernel, ``part`` being the entry of ``self.parts`` (``part['offset']`` = first pixel of
+        the slot in the raster). Returns the slots of the last step, one per part. Errors of any
+        device are raised here (first in device order) after all of them have finished.'''
+        import threading
+        torch = _torch()
+        P = self.tile
+        results, errors = [None] * len(self.parts), [None] * len(self.parts)
+
+        def cut(rec, part):
+            a, b = part['t0'] * P, part['t1'] * P
+            return {key: [None if t is None else t[a:b] for t in rec.get(key, [])] for key in ('wide', 'bytes')}
+
+        def work(k, part):
+            try:
+                torch.cuda.set_device(part['device'])
+                mine = [cut(rec, part) for rec in host_steps]
+                with torch.cuda.stream(part['stream']):
+                    hook = (lambda s, slot: on_step(part, s, slot)) if on_step is not None else None
+                    results[k] = part['engine'].run_series_host(part['ring'], mine, steps, day_hours, hook)
+                    part['engine'].check()
+            except BaseException as exc:
+                errors[k] = exc
+
+        threads = [threading.Thread(target=work, args=(k, p)) for k, p in enumerate(self.parts)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for e in errors:
+            if e is not None:
+                raise e
+        return results
+
+    def read(self, slots, out_index, into):
+        '''Copies output ``out_index`` of the per-device ``slots`` (what ``run_host`` returned)
+        into the 1-D CPU tensor ``into`` (n elements, ideally page-locked), every part at its
+        pixel offset; synchronous.'''
+        torch = _torch()
+        for part, slot in zip(self.parts, slots):
+            with torch.cuda.device(part['device']):
+                flat = slot.flat(slot.outs[out_index], 0, part['n'])
+                into[part['offset']:part['offset'] + part['n']].copy_(flat)
+        return into
