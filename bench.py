@@ -247,12 +247,18 @@ def device_sensors(torch):
 
 def device_under_load(torch, step, nsteps, sample):
     """Shader clock and package power while the timed step runs, OUTSIDE the timed region:
-    `nsteps` more steps are enqueued and the sensors read until they are done (the first 40 %
-    skipped: the power figure is an average). Every rank runs the steps (they hold the
-    collective); `sample` says whether this rank reads the sensors. Why it is in the line: the
-    float64 step runs the chip into its package power cap and the shader clock comes down to
-    ~1.7 GHz (profiles/r03_power_probe.jsonl) -- the step time follows
-    that clock, and it differs from device to device."""
+    `nsteps` more steps are enqueued and the sensors read until they are done. Every rank runs
+    the steps (they hold the collective); `sample` says whether this rank reads the sensors. Why
+    it is in the line: the float64 step runs the chip into its package power cap and the shader
+    clock comes down to ~1.7 GHz (profiles/r03_power_probe.jsonl) -- the step
+    time follows that clock, and it differs from device to device.
+
+    Order (round 5): the steps are enqueued FIRST and the watcher thread opens the sensor files
+    only once 40 % of them have run, so the load is steady when the first read arrives. Round 4
+    started the thread in front of the steps; its rocprofv3 trace has a 3.4 ms idle gap in front of
+    the first extra launch (eng.check(), reading the step times back, starting the thread) and the
+    two launches behind it at 21.4 and 27.4 ms against 20.1: with the reads
+    moved away from the gap the next trace tells the two suspects apart."""
     hw = device_sensors(torch) if sample else None
 
     def read(name):
@@ -263,34 +269,40 @@ def device_under_load(torch, step, nsteps, sample):
             return None
     clocks, stop = [], threading.Event()
     t0 = time.perf_counter()
+    lead = max(1, int(0.4 * nsteps))
+    ready = torch.cuda.Event()
 
     def watch():        # a thread: with N > 1 a step may block in its collective
+        ready.synchronize()             # the first `lead` steps are done: the load is steady
         while not stop.is_set():
             c, w = read('freq1_input'), read('power1_input')
             if c is not None and w is not None:
                 clocks.append((time.perf_counter() - t0, c * 1e-6, w * 1e-6))
             time.sleep(0.02)
+    for k in range(nsteps):
+        step()
+        if k + 1 == lead:
+            ready.record()
     watcher = threading.Thread(target=watch, daemon=True) if hw is not None else None
     if watcher is not None:
         watcher.start()
-    for _ in range(nsteps):
-        step()
     torch.cuda.synchronize()
     stop.set()
     if watcher is None:
         return None
     watcher.join()
     total = time.perf_counter() - t0
-    kept = [x for x in clocks if x[0] >= 0.4 * total]
+    kept = clocks
     if not kept:
         return None
     cap = read('power1_cap')
     return {'sclk_mhz': sum(x[1] for x in kept) / len(kept), 'sclk_mhz_min': min(x[1] for x in kept),
             'sclk_mhz_max': max(x[1] for x in kept), 'power_w': sum(x[2] for x in kept) / len(kept),
             'power_cap_w': cap * 1e-6 if cap else None, 'samples': len(kept), 'seconds': total,
-            'source': hw,
-            'note': 'hwmon sensors of this device read while %d more steps run behind the timed region; '
-                    'a float64 step at the power cap runs at the clock the cap leaves' % nsteps}
+            'first_sample_s': kept[0][0], 'source': hw,
+            'note': 'hwmon sensors of this device read while %d more steps run behind the timed region '
+                    '(first read after %d of them); a float64 step at the power cap runs at the clock the cap leaves'
+                    % (nsteps, lead)}
 
 
 def pmc_traffic(pixels_per_launch, dtype, layout, build_id, profiles_dir=None):
@@ -408,6 +420,8 @@ def main():
                     help='skip the other BASELINE.json configurations (1200x1200 tile, series, float32)')
     ap.add_argument('--no-ingest', action='store_true',
                     help='N > 1: skip the host-ingest series every rank streams beside its band')
+    ap.add_argument('--no-host-call', action='store_true',
+                    help='skip the numpy-in / numpy-out call over the GPUs of the run (rank 0, devices=range(N))')
     ap.add_argument('--cpu-workers', type=int, default=16)
     ap.add_argument('--series-steps', type=int, default=46)
     args = ap.parse_args()
@@ -694,6 +708,23 @@ def main():
         ingest = dict(mine, pixels_per_s=float(rates[:, 0].sum()), h2d_GBps=float(rates[:, 1].sum()),
                       pixels_per_s_by_rank=rates[:, 0].tolist(), h2d_GBps_by_rank=rates[:, 1].tolist(),
                       note='every rank streams its own series at the same time; sums over the ranks')
+    # the numpy drop-in itself over the GPUs of this run (mod16_amd.multi: one host thread, context
+    # and PCIe link per device, no collective): rank 0 alone calls it with devices=range(N) while
+    # the other ranks wait at the fence. A failure here is recorded, never raised: the scaling
+    # line of an 8-GPU run must not depend on it.
+    host_call = None
+    if not args.no_host_call and not args.no_configs:
+        fence()
+        if rank == 0:
+            try:
+                if bplut is None and not args.no_parity:
+                    from oracle import mod16_oracle as oracle
+                    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+                devs = [0] * world if rehearsal else list(range(world))
+                host_call = numpy_in_numpy_out(np, torch, eng, table, devs, bplut)
+            except Exception as exc:        # noqa: BLE001 -- recorded in the line
+                host_call = {'error': '%s: %s' % (type(exc).__name__, str(exc)[:300])}
+        fence()
     configs = None
     if rank == 0 and world == 1 and not args.no_configs and args.dtype == 'float64':
         # the other configurations need the whole card: drop this raster first
@@ -726,6 +757,14 @@ def main():
                         'reduced in rank order, overlapped with the next step on a side stream',
                 'raster_layout': layout_info,
             },
+            # (order: the long per-configuration objects first, what the contract asks for last --
+            # the driver's record keeps the tail of stdout)
+            'configs': configs,
+            'ingest': ingest,
+            'numpy_in_numpy_out': host_call,
+            'diagnostics': dict(zip(DIAG_NAMES, [float(v) for v in diag_host])),
+            'parity': parity,
+            'cpu_baseline': cpu,
             'roofline': {
                 'bound': 'hbm', 'kernel': 'et_stream_kernel<%s, %s> (LDS-DMA, dynamic runs, in-kernel diagnostics)'
                                           % (args.dtype, 'totals, mixed precision' if args.math == 'mixed' else 'totals'),
@@ -747,18 +786,144 @@ def main():
                                and under_load['power_w'] >= 0.97 * under_load['power_cap_w'] else None),
                 'plain_arrays': plain,
             },
-            'cpu_baseline': cpu,
-            'parity': parity,
-            'configs': configs,
-            'ingest': ingest,
-            'diagnostics': dict(zip(DIAG_NAMES, [float(v) for v in diag_host])),
         }
         if census is not None:
             line['gpu_process_census'] = census
+        # the scalars the driver's record must carry, repeated flat: in `roofline` (the driver keeps
+        # its scalars) and as the LAST key of the line (the driver keeps the tail of stdout)
+        line['roofline'].update(roofline_scalars(line))
+        line['summary'] = build_summary(line)
         print(json.dumps(line), flush=True)
     if grouped:
         dist.destroy_process_group()
     return 0
+
+
+def _dig(d, *path):
+    for key in path:
+        if not isinstance(d, dict) or d.get(key) is None:
+            return None
+        d = d[key]
+    return d
+
+
+def roofline_scalars(line):
+    """plain_frac, sclk_mhz, power_w, cycles_per_step as scalars of `roofline`. cycles_per_step
+    = kernel_ms x shader clock under load: the device-independent cost of the step (a build that
+    needs fewer cycles is faster on every device; the clock is what the power cap leaves)."""
+    roof = line.get('roofline') or {}
+    sclk = _dig(roof, 'device_under_load', 'sclk_mhz')
+    kms = roof.get('kernel_ms')
+    return {'plain_frac': _dig(roof, 'plain_arrays', 'frac'), 'plain_ms': _dig(roof, 'plain_arrays', 'kernel_ms'),
+            'sclk_mhz': sclk, 'power_w': _dig(roof, 'device_under_load', 'power_w'),
+            'cycles_per_step': kms * sclk * 1e3 if kms and sclk else None}
+
+
+def build_summary(line):
+    """Flat object of scalars, the LAST key of the line: every configuration's headline number
+    in a few hundred bytes, so that the tail of stdout the driver keeps carries them all
+    (tests/test_host_logic.py parses the last 6000 bytes of a full line)."""
+    roof, cfg = line.get('roofline') or {}, line.get('configs') or {}
+    c2, c4, c5 = (cfg.get(k) or {} for k in ('c2_1200x1200_float64', 'c4_series_float64', 'c5_global_grid_float32'))
+    f64, f32 = cfg.get('forms_float64') or {}, cfg.get('forms_float32_mixed') or {}
+    par = line.get('parity') or {}
+    full = par.get('full_grid_fast_vs_exact_kernel') or par.get('full_grid_mixed_vs_float64_arithmetic') or {}
+    host = line.get('numpy_in_numpy_out') or {}
+    out = {
+        'n_gpus': line.get('n_gpus'), 'ranks_seen': line.get('ranks_seen'), 'ms_per_step': line.get('ms_per_step'),
+        'gpx_s': line['value'] / 1e9 if line.get('value') else None,
+        'kernel_ms': roof.get('kernel_ms'), 'kernel_ms_min': roof.get('kernel_ms_min'), 'frac': roof.get('frac'),
+        'traffic_bytes_per_pixel': roof['traffic'] / roof['pixels_per_launch'] if roof.get('traffic') else None,
+        'copy_GBps': roof.get('measured_copy_GBps'),
+        'sclk_mhz': roof.get('sclk_mhz'), 'power_w': roof.get('power_w'), 'cycles_per_step': roof.get('cycles_per_step'),
+        'plain_ms': roof.get('plain_ms'), 'plain_frac': roof.get('plain_frac'),
+        'c2_us': c2.get('tile_us_per_launch'), 'c2_us_no_diag': c2.get('tile_us_per_launch_without_diagnostics'),
+        'c2_batch64_us_per_tile': c2.get('batch64_us_per_tile'),
+        'c4_ms_per_step': c4.get('ms_per_step'),
+        'c4_gpx_s': c4['pixels_per_s'] / 1e9 if c4.get('pixels_per_s') else None,
+        'c5_mixed_ms': c5.get('mixed_ms'), 'c5_mixed_frac': c5.get('mixed_frac'),
+        'c5_fast_ms': c5.get('fast_float64_arithmetic_ms'), 'c5_fast_frac': c5.get('fast_float64_arithmetic_frac'),
+        'c5_masks_equal': _dig(c5, 'mixed_vs_float64_arithmetic_full_grid', 'nan_masks_equal'),
+        'c5_max_abs_err_over_max': _dig(c5, 'mixed_vs_float64_arithmetic_full_grid', 'max_abs_err_over_max_value'),
+        'pet_f64_frac': _dig(f64, 'potential_et', 'frac'), 'sep_f64_frac': _dig(f64, 'components', 'frac'),
+        'raw_f64_frac': _dig(f64, 'raw_drivers', 'frac'), 'raw8_f64_frac': _dig(f64, 'raw_drivers_total8', 'frac'),
+        'raw_mixed_frac': _dig(f32, 'raw_drivers', 'frac'), 'raw8_mixed_frac': _dig(f32, 'raw_drivers_total8', 'frac'),
+        'raw_f64_max_rel': _dig(f64, 'raw_drivers', 'parity', 'max_rel_err_vs_oracle'),
+        'ingest_gpx_s': _dig(line, 'ingest', 'pixels_per_s') / 1e9 if _dig(line, 'ingest', 'pixels_per_s') else None,
+        'ingest_h2d_GBps': _dig(line, 'ingest', 'h2d_GBps'),
+        'host_call_gpx_s': host['pixels_per_s'] / 1e9 if host.get('pixels_per_s') else None,
+        'host_call_devices': host.get('n_devices'), 'host_call_one_device_gpx_s':
+            host['one_device_pixels_per_s'] / 1e9 if host.get('one_device_pixels_per_s') else None,
+        'host_call_bits_equal_one_device': host.get('bits_equal_one_device'), 'host_call_error': host.get('error'),
+        'n2_resident_frac': _dig(cfg, 'n2_calibration', 'fast_resident', 'frac_of_valu_issue_peak'),
+        'n2_resident_gpu_frac': _dig(cfg, 'n2_calibration', 'fast_resident', 'frac_of_valu_issue_peak_gpu_part'),
+        'parity_max_rel': par.get('max_rel_err'), 'parity_masks_equal': par.get('masks_equal'),
+        'full_grid_max_rel': full.get('max_rel_err'), 'full_grid_masks_equal': full.get('nan_masks_equal'),
+        'full_grid_n_gt_1e-5': full.get('n_rel_err_gt_1e-5'),
+        'cpu_px_s_1core': _dig(line, 'cpu_baseline', 'value'),
+        'build_id': roof.get('library_build_id'),
+    }
+    return out
+
+
+def numpy_in_numpy_out(np, torch, eng, table, devices, bplut, tiles_per_device=16):
+    """The numpy drop-in over the GPUs of the run: evapotranspiration_raster(..., devices=range(N),
+    diagnostics=True) on host arrays of `tiles_per_device` staging tiles per device (weak scaling:
+    33.5 M float64 pixels = 4.3 GB of drivers per device), wall time of the whole call -- every
+    byte crosses PCIe, one link per device. Beside it the same call on ONE device over one
+    device's share (the one-link rate), the bit-equality of the two on that share, and with
+    `bplut` the oracle on a 320 k-pixel window across the first cut."""
+    import mod16_amd
+    from mod16_amd import multi
+    tile = multi.host_tile()
+    per_dev = tiles_per_device * tile
+    n = per_dev * len(devices)
+    h_cls = np.empty(n, np.uint8)
+    h_drv = [np.empty(n, np.float64) for _ in range(14)]
+    for lo in range(0, n, 1 << 24):         # generated on the device chunk by chunk, copied down
+        m = min(1 << 24, n - lo)
+        c, d = eng.synth(m, seed=SEED, step=3, pixel_offset=lo)
+        h_cls[lo:lo + m] = c.cpu().numpy()
+        for k in range(14):
+            h_drv[k][lo:lo + m] = d[k].cpu().numpy()
+        del c, d
+    torch.cuda.empty_cache()
+    call = lambda hi, devs: mod16_amd.evapotranspiration_raster(
+        table, h_cls[:hi], *[x[:hi] for x in h_drv], devices=devs, diagnostics=True)
+    call(min(n, 2 * tile * len(devices)), devices)          # contexts, slabs, pinned result blocks
+    best, res = 1e30, None
+    for _ in range(2):
+        res = None                                           # (its blocks go back to the pool)
+        t0 = time.perf_counter()
+        res = call(n, devices)
+        best = min(best, time.perf_counter() - t0)
+    out = {'pixels': n, 'n_devices': len(devices), 'devices': list(devices), 'seconds': best,
+           'pixels_per_s': n / best, 'pcie_GBps_both_directions': 129.0 * n / best / 1e9,
+           'diagnostics': [float(v) for v in res[2]],
+           'note': 'mod16_amd.evapotranspiration_raster(table, cls, *drivers, devices=range(N), diagnostics=True) '
+                   'on host float64 arrays, %d staging tiles of %d pixels per device; best of 2 calls' % (tiles_per_device, tile)}
+    if len(devices) > 1:
+        call(2 * tile, devices[:1])
+        t0 = time.perf_counter()
+        one = call(per_dev, devices[:1])
+        out['one_device_pixels_per_s'] = per_dev / (time.perf_counter() - t0)
+        out['bits_equal_one_device'] = bool(np.array_equal(one[0], res[0][:per_dev], equal_nan=True)
+                                            and np.array_equal(one[1], res[1][:per_dev], equal_nan=True))
+        del one
+    if bplut is not None:
+        from oracle import mod16_oracle as oracle
+        lo = max(0, per_dev - 160000) if len(devices) > 1 else n // 2
+        hi = min(n, lo + 320000)
+        with np.errstate(all='ignore'):
+            want = oracle.evapotranspiration_raster(bplut, h_cls[lo:hi], *[x[lo:hi] for x in h_drv])
+        worst, masks = 0.0, True
+        for got, ref in zip(res[:2], want):
+            got = got[lo:hi]
+            masks = masks and bool(np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(got == 0, ref == 0))
+            ok = np.isfinite(ref) & (ref != 0)
+            worst = max(worst, float(np.max(np.abs(got[ok] - ref[ok]) / np.abs(ref[ok]))))
+        out['parity'] = {'pixels': hi - lo, 'window_start': lo, 'max_rel_err_vs_oracle': worst, 'masks_equal': masks}
+    return out
 
 
 def other_configs(args, torch, np, _lib, RasterEngine, table, bplut):
@@ -1155,7 +1320,7 @@ def n2_config(np, _lib):
     obs = want[0] + rng.normal(0, 5, n)
     res = {'pixels': n, 'draws': ndraw, 'valu_peak_lane_instructions_per_s': 256 * 4 * 16 * 2.4e9}
     for name, math, per_draw in (('reference_order', _lib.MATH_EXACT, N2_INSTR['reference_order']),
-                                 ('fast', _lib.MATH_FAST, N2_INSTR['fast'])):
+                                 ('fast_unbound', _lib.MATH_FAST, N2_INSTR['fast'])):
         M._et_batch(params[:4], *drv, observed=obs, math=math)
         best = 1e30
         for _ in range(3):
@@ -1173,7 +1338,11 @@ def n2_config(np, _lib):
                      'valu_instructions_per_pixel_draw': per_draw,
                      'frac_of_valu_issue_peak': rate * per_draw / res['valu_peak_lane_instructions_per_s'] if per_draw else None,
                      'parity': {'max_rel_err_vs_oracle': worst, 'masks_equal': masks, 'draws_checked': 3},
-                     'objective_first_draw': float(sse[0] / cnt[0])}
+                     'objective_first_draw': float(sse[0] / cnt[0]),
+                     'role': ('the bit-identical path: the reference\'s operation order, IEEE divide and pow' if math == _lib.MATH_EXACT else
+                              'the ONE-SHOT call (drivers uploaded, workspace sized and the kernels launched one by one on '
+                              'every call): kept as the comparison point -- a loop over parameter vectors uses '
+                              'fast_resident (MOD16._et_bind), which is the product number')}
     # the same problem RESIDENT on the device (MOD16._et_bind): drivers up once, per evaluation the
     # parameters up and (sse, count) down around one graph launch -- what an MCMC chain would hold
     prob = M._et_bind(*drv, observed=obs, max_draws=ndraw)
@@ -1217,7 +1386,7 @@ def n2_config(np, _lib):
 
 # VALU instructions per pixel-draw of the batched calibration kernels' inner loop (static count of
 # the gfx950 listing, tools/isa_count.py; profiles/r03_isa_mix_calibration_kernels.txt)
-N2_INSTR = {'reference_order': 2325, 'fast': 180, 'fast_resident': 180}   # (resident: 166 in the draw loop + 21 / 16 per reduction pass + ~380 / 32 of per-pixel preparation)
+N2_INSTR = {'reference_order': 2325, 'fast': 180, 'fast_resident': 180}   # ('fast': the one-shot call, key fast_unbound in the line)   # (resident: 166 in the draw loop + 21 / 16 per reduction pass + ~380 / 32 of per-pixel preparation)
 
 
 if __name__ == '__main__':

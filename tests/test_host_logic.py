@@ -176,3 +176,49 @@ def test_pmc_traffic_belongs_to_the_build(tmp_path):
     # the committed records (older rounds carry no build id): never reported for this build unless measured on it
     t, src, note = bench.pmc_traffic(933120000, 'float64', 'tiled', mine)
     assert (t is None) == (src is None) and note
+
+
+def test_summary_is_the_tail_of_the_line():
+    """The driver's record keeps the last 8 KB of stdout and only the scalars of `roofline`: the
+    line ends in a flat `summary` object of scalars (every configuration's headline number, the
+    clock, the power and cycles_per_step = kernel_ms x shader clock) that the last 6000 bytes of
+    a FULL line still carry, and `roofline` repeats plain_frac / sclk_mhz / power_w /
+    cycles_per_step as scalars. Input: last round's complete line (profiles/r04b_bench_line.json),
+    put through this round's build_summary()."""
+    import json
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    line = json.load(open(os.path.join(ROOT, 'profiles', 'r04b_bench_line.json')))
+    line.pop('summary', None)
+    line['numpy_in_numpy_out'] = {'pixels': 33554432, 'n_devices': 2, 'pixels_per_s': 1.0e9,
+                                  'one_device_pixels_per_s': 0.5e9, 'bits_equal_one_device': True}
+    line['roofline'].update(bench.roofline_scalars(line))
+    line['summary'] = bench.build_summary(line)
+    text = json.dumps(line)
+    assert len(text) > 12000                              # a full line: well beyond what the record keeps
+    tail = text[-6000:]
+    at = tail.index('"summary": ')
+    summary = json.loads(tail[at + len('"summary": '):-1])
+    assert text.endswith(json.dumps(summary) + '}')        # the LAST key
+    for v in summary.values():
+        assert v is None or isinstance(v, (bool, int, float, str)), v      # scalars only
+    want = ('c2_us', 'c2_us_no_diag', 'c4_ms_per_step', 'c4_gpx_s', 'c5_mixed_ms', 'c5_fast_ms', 'plain_ms',
+            'plain_frac', 'raw_f64_frac', 'raw_mixed_frac', 'ingest_gpx_s', 'n2_resident_frac', 'parity_max_rel',
+            'parity_masks_equal', 'sclk_mhz', 'power_w', 'cycles_per_step', 'kernel_ms', 'frac', 'host_call_gpx_s')
+    for k in want:
+        assert summary.get(k) is not None, k
+    roof = line['roofline']
+    assert summary['cycles_per_step'] == roof['kernel_ms'] * roof['device_under_load']['sclk_mhz'] * 1e3
+    assert 30e6 < summary['cycles_per_step'] < 40e6
+    for k in ('plain_frac', 'sclk_mhz', 'power_w', 'cycles_per_step'):
+        assert isinstance(roof[k], float) and roof[k] == summary[k]
+    assert summary['c2_us'] == line['configs']['c2_1200x1200_float64']['tile_us_per_launch']
+    assert summary['host_call_gpx_s'] == 1.0 and summary['host_call_devices'] == 2
+    # a line without the optional legs (N > 1, --no-configs ...) still has a summary of nulls
+    bare = {'value': 1e9, 'roofline': {'kernel_ms': 2.5, 'frac': 0.7}, 'configs': None, 'parity': None}
+    bare['roofline'].update(bench.roofline_scalars(bare))
+    s = bench.build_summary(bare)
+    assert s['c2_us'] is None and s['cycles_per_step'] is None and s['kernel_ms'] == 2.5

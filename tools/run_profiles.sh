@@ -15,7 +15,11 @@ fi
 timeout -k 10 500 python bench.py "$@" > $O/bench_line.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
 cat $O/bench_line.json
 # profiled runs: one raster layout per kernel symbol (--no-plain), nothing but the headline configuration (--no-configs)
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py "$@" --no-cpu-baseline --no-plain --no-configs --steps 40 > $O/bench_line_under_rocprof.json 2> $O/rocprof_stats.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py "$@" --no-cpu-baseline --no-plain --no-configs --steps 40 --warmup 5 > $O/bench_line_under_rocprof.json 2> $O/rocprof_stats.err
+# the dominant kernel over the TIMED dispatches only (the stats file averages every call of the symbol:
+# warm-up, the extra steps of the sensor leg, ...): tools/timed_dispatches.py names what it leaves out
+find $O/stats -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/timed_dispatches.py {} 5 40 > $O/kernel_timed_dispatches.json || true
+cat $O/kernel_timed_dispatches.json
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py "$@" --no-cpu-baseline --no-parity --no-plain --no-configs --steps 3 --warmup 1 > $O/pmc_fetch.out 2> $O/pmc_fetch.err
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py "$@" --no-cpu-baseline --no-parity --no-plain --no-configs --steps 3 --warmup 1 > $O/pmc_write.out 2> $O/pmc_write.err
 find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
