@@ -135,6 +135,21 @@ template <> struct FastMath<double> {
         return (y4 * y2) * y;
     }
 
+    // x^(-7/4) and x^-1 from the same seed and Newton step (round 5): after the step y = x^(-1/4)
+    // to 7e-15, so y^4 is 1 / x to 2.8e-14 -- the forward run's period needs 1 / t for the air
+    // density next to t^(-7/4) for r_corr, and gets it here for nothing (a reciprocal with its
+    // Newton step and two products less per period than 1 / (N t) did).
+    static __device__ __forceinline__ T pow_m1p75_rcp(T x, T& rx) {
+        T y = __builtin_amdgcn_sqrt(__builtin_amdgcn_rsq(x));
+        T y2 = y * y;
+        T t = x * (y2 * y2);
+        y = y * fma_kk(t, -0.25, 1.25);
+        y2 = y * y;
+        T y4 = y2 * y2;
+        rx = y4;
+        return (y4 * y2) * y;
+    }
+
     // ---- table-driven exp / log (tables in LDS, filled by the library)
     // tb[0..63]      = 2^(j/64)
     // tb[64 + 2j..]  = { 1/c_j rounded, -log(1/c_j) },  c_j = 1 + (j + 1/2)/128
@@ -181,6 +196,40 @@ template <> struct FastMath<double> {
         return __builtin_amdgcn_ldexp(tb[ki & 63] * p, ki >> 6);
     }
 
+    // quartic, and the argument reduced with ONE constant (round 5): r = x - k ln2/64 with ln2/64
+    // rounded to float64 is off by |k| 1.2e-18 -- for the forward run's two exponentials (the
+    // saturation pressure: |x| < 20, k < 2000: 2e-15 relative; rh^(vpd/beta): x in [-746, 0], where
+    // the error grows only as the value vanishes) that is the size of the result's own rounding.
+    // Two float64 operations less than exp_tab.
+    static __device__ __forceinline__ T exp_tab4s(T x, const T* tb) {
+        T km = __builtin_fma(x, 92.33248261689366, kRintShift);
+        T kf = km - kRintShift;
+        T r = __builtin_fma(kf, -0.010830424696249145, x);          // ln 2 / 64
+        T p = fma_kk(r, 1.0 / 24.0, 1.0 / 6.0);
+        p = __builtin_fma(p, r, 0.5);
+        p = __builtin_fma(p, r, 1.0);
+        p = __builtin_fma(p, r, 1.0);
+        int ki = __double2loint(km);
+        return __builtin_amdgcn_ldexp(tb[ki & 63] * p, ki >> 6);
+    }
+
+    // exp_tab with the one-constant reduction (quintic as there: the saturation pressure feeds
+    // differences -- esat - vpd, s A + rho Cp vpd / r_a at night -- that amplify its error 1e5-fold
+    // in the worst pixels of a global grid; a quartic's 4e-14 showed there as 1.3e-9 against the
+    // reference-order kernel where 1e-9 is promised)
+    static __device__ __forceinline__ T exp_tab5s(T x, const T* tb) {
+        T km = __builtin_fma(x, 92.33248261689366, kRintShift);
+        T kf = km - kRintShift;
+        T r = __builtin_fma(kf, -0.010830424696249145, x);          // ln 2 / 64
+        T p = fma_kk(r, 1.0 / 120.0, 1.0 / 24.0);
+        p = __builtin_fma(p, r, 1.0 / 6.0);
+        p = __builtin_fma(p, r, 0.5);
+        p = __builtin_fma(p, r, 1.0);
+        p = __builtin_fma(p, r, 1.0);
+        int ki = __double2loint(km);
+        return __builtin_amdgcn_ldexp(tb[ki & 63] * p, ki >> 6);
+    }
+
     // the same to 4e-11 (cubic): for results that end up in float32 (mod16_mixed.hpp)
     static __device__ __forceinline__ T exp_tab3(T x, const T* tb) {
         T km = __builtin_fma(x, 92.33248261689366, kRintShift);
@@ -212,6 +261,19 @@ template <> struct FastMath<double> {
         v = __builtin_fma(ed, 7.371002565167799e-13, v);
         return (x == 0.0) ? -__builtin_huge_val() : v;
     }
+    // the same with ln 2 as ONE constant: e (ln 2 - fl(ln 2)) = e 2.3e-17 absolute -- for the
+    // relative humidities of the forward run (e = -1 ... -10; below, rh^y is vanishing anyway)
+    static __device__ __forceinline__ T log_tab1(T x, const T* tb) {
+        const unsigned hi = (unsigned)__double2hiint(x);
+        const int e = (int)(hi >> 20) - 1023;
+        const unsigned j = (hi >> 13) & 127u;
+        const T m = __hiloint2double((int)((hi & 0x000fffffu) | 0x3ff00000u), __double2loint(x));
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2 ent = *reinterpret_cast<const d2*>(tb + 64 + 2 * j);
+        T r = __builtin_fma(m, ent[0], -1.0);
+        T v = __builtin_fma((T)e, 0.6931471805599453, ent[1]) + log1p_poly(r);
+        return (x == 0.0) ? -__builtin_huge_val() : v;
+    }
     // r - r^2/2 + ... + r^5/5 on |r| <= 1/256: the next term, r^6/6, is below 6e-16 (the
     // exponent vpd / beta reaches thousands on the calibration path, where beta is sampled
     // down to ~1: a quartic's 1.9e-13 showed as 1e-9 there); the host evaluates the same
@@ -234,6 +296,12 @@ template <> struct FastMath<double> {
         T yc = vmin_k(y, 1e300);
         T t = vmax_k(yc * log_tab(x, tb), -746.0);
         return exp_tab4(t, tb);
+    }
+    // the forward run's form (round 5): one-constant reductions in the log and the exp
+    static __device__ __forceinline__ T pow01_tab1(T x, T y, const T* tb) {
+        T yc = vmin_k(y, 1e300);
+        T t = vmax_k(yc * log_tab1(x, tb), -746.0);
+        return exp_tab4s(t, tb);
     }
 };
 

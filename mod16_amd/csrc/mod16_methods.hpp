@@ -770,7 +770,9 @@ __global__ void __launch_bounds__(kBlock) et_raw_kernel(const RawArgs<T> a) {
         p.rbl_slope = l[13 * kLutCols]; p.inv_beta = l[14 * kLutCols];
         PixelOut<C> o;
         if constexpr (FAST) {
-            o = et_pixel_fast<double>(raw_to_pixel_fast(r, tab), p, tab);
+            double dav_d, dav_n;
+            const PixelIn<double> x = raw_to_pixel_fast(r, tab, dav_d, dav_n);
+            o = et_pixel_fast<double, false, KLit, true>(x, p, tab, dav_d, dav_n);
             // outside the domain of the fast forms: the reference's operation order
             // (mod16_physics.hpp, "domain guard")
             if (raw_out_of_domain(r)) o = et_pixel_exact<double, false, true>(raw_to_pixel_exact<double, true>(r), p);

@@ -564,9 +564,9 @@ template <int LEVEL> struct KPin {
 template <typename T> struct PixelShared {
     T oma;        // 1 - albedo
     T omf;        // 1 - fpar
-    T p_rel;      // pressure / 101300
+    T p_rel;      // pressure 293.15^1.75 / 101300  (1 / r_corr = p_rel t^-1.75)
     T k_p;        // Cp * pressure / eps  (= gamma * lhv)
-    T p_mbar_k;   // 0.348444 * pressure / 100
+    T p_mbar_k;   // Cp 0.348444 * pressure / 100  (round 5: the air-density numerator N carries Cp)
     T l_wet;      // lai with 0 -> tiny (wet canopy, :935)
     T glsh_l, glwv_l;   // gl_sh * l_wet, gl_wv * l_wet
     T glsh_lai;   // gl_sh * lai (transpiration, :1242)
@@ -579,17 +579,23 @@ template <typename T> struct PixelShared {
 // evaporation without the soil-moisture constraint + Priestley-Taylor
 // potential transpiration (MOD16.potential_transpiration, :546-602), as a mass
 // flux like the other outputs.
-template <typename T, bool DAY, bool PET = false, typename KP = KLit>
+// RAW (the raw-driver forms, round 5): `vpd` arrives as the humidity quotient's numerator q p
+// (specific humidity x surface pressure) and `dav` as its denominator 0.622 + 0.379 q; the period
+// forms MOD16.vpd (mod16/__init__.py:604-644) itself, with the exponential it SHARES with the
+// saturation pressure: 610.7 exp(17.38 tc / (239 + tc)) = 610.7 exp(17.27 tc / (237.3 + tc)) exp(delta),
+// delta = tc (0.11 tc - 3.256) / ((tc + 239)(tc + 237.3)) -- |delta| < 0.043 on 190 K .. 360 K (the
+// raw forms' temperature domain, raw_guard_value), so exp(delta) is six fused multiply-adds and
+// the second table exponential of the period, its range reduction and its reciprocal are gone.
+template <typename T, bool DAY, bool PET = false, typename KP = KLit, bool RAW = false>
 __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<T>& p,
                                             const PixelShared<T>& sh, const T* tb, T t, T vpd,
                                             T rad_net, T rad_soil, T& canopy, T& soil,
-                                            T& trans, T* pet = nullptr) {
+                                            T& trans, T* pet = nullptr, T dav = T(1)) {
     // No implicit contraction: every fma of this function is written out, so that all
     // kernels instantiated from it round alike (hipcc contracts a * b + c by context).
 #pragma clang fp contract(off)
     typedef FastMath<T> M;
     const T tiny = K<T>::tiny;
-    const T cp = K<T>::cp;
     // -- humidity, :646-673 and :763-764
     T tc = t - K<T>::t0;
     // the two reciprocals of the temperature terms -- 1 / (tc + 237.3) for esat and
@@ -597,11 +603,35 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     // (a quarter-rate instruction and its Newton step against two multiplications)
     T d_es = tc + KP::per_period(237.3);
     T ta = tc + KP::per_period(239.0);                                          // (239 + T) - 273.15 to 1 ulp, :1395
-    T r_both = M::rcp(d_es * ta);
+    T dd = d_es * ta;
+    T r_both, r_av = T(0);
+    if constexpr (RAW) {
+        // ... and the humidity quotient's reciprocal from the same v_rcp_f64 (0.243 < dav < 1.001
+        // inside the raw forms' domain)
+        T r3 = M::rcp(dd * dav);
+        r_both = r3 * dav;
+        r_av = r3 * dd;
+    } else {
+        r_both = M::rcp(dd);
+    }
     T r_es = r_both * ta, rta = r_both * d_es;
-    // (a NaN temperature stays NaN through exp_tab: rint, the fmas and the table product
+    // (a NaN temperature stays NaN through the table exp: rint, the fmas and the table product
     // all propagate it; an infinite one gives inf * 0 in r_es)
-    T esat = T(1e3 * 0.6108) * M::exp_tab((KP::per_period(17.27) * tc) * r_es, tb);
+    T e_es = M::exp_tab5s((KP::per_period(17.27) * tc) * r_es, tb);
+    T esat = T(1e3 * 0.6108) * e_es;
+    if constexpr (RAW) {
+        // 17.38 * 237.3 - 17.27 * 239 and 17.38 - 17.27, exact differences of the float64 constants
+        T delta = (tc * M::fma_kk(tc, 0x1.c28f5c28f5c00p-4, -0x1.a0c49ba5e34b1p+1)) * r_both;
+        T q = M::fma_kk(delta, 1.0 / 720.0, 1.0 / 120.0);
+        q = __builtin_fma(q, delta, 1.0 / 24.0);
+        q = __builtin_fma(q, delta, 1.0 / 6.0);
+        q = __builtin_fma(q, delta, 0.5);
+        q = __builtin_fma(q, delta, 1.0);
+        q = __builtin_fma(q, delta, 1.0);
+        T sv = (T(610.7) * e_es) * q;                              // :640-642
+        vpd = __builtin_fma(-vpd, r_av, sv);                       // sv - q p / (0.622 + 0.379 q)
+        if constexpr (!DAY) vpd = (vpd < T(0)) ? T(0) : vpd;       // calibration.py:401
+    }
     T avp = esat - vpd;
     // rh drives the thresholds (rh < 0.7, 1 - fwet > 0), so this one quotient is
     // finished like an IEEE division (residual correction): x / x = 1 exactly
@@ -620,25 +650,29 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     T s = (KP::per_period(17.38 * 239.0) * esat) * (rta * rta);
     T lhv = M::fma_kk(tc, T(-0.002361e6), T(2.501e6));         // (2.501 - 0.002361 tc) 1e6, :121
     T slhv = s * lhv;
-    // -- 1 / r_corr = (P / 101300) (T / 293.15)^-1.75, :771
-    T inv_rcorr = sh.p_rel * M::pow_m1p75(t * KP::per_period(1.0 / 293.15));
-    // -- air density (:408-412) and radiative conductance 1/r_r (:947) from
-    //    one reciprocal: rho = N / T, 1/r_r = 4 sigma T^4 / (Cp N)
+    // -- 1 / r_corr = (P / 101300) (T / 293.15)^-1.75, :771; 1 / T comes with it
+    T rt;
+    T inv_rcorr = sh.p_rel * M::pow_m1p75_rcp(t, rt);
+    // -- air density (:408-412) and radiative conductance 1/r_r (:947):
+    //    rho = N / T, 1/r_r = 4 sigma T^4 / (Cp N)
     // p_mbar_k - (rh 100)(0.00252 tc - 0.020582); the contraction is written out so that
     // every kernel built from this function rounds alike
-    T nn = __builtin_fma(-rh, M::fma_kk(tc, T(0.252), T(-2.0582)), sh.p_mbar_k);
-    T u = M::rcp(nn * t);
-    T rho_cp = cp * ((nn * nn) * u);
+    // (N carries the factor Cp: rho Cp = N / T and 1/r_r = 4 sigma T^4 / N without a product by Cp)
+    T nn = __builtin_fma(-rh, M::fma_kk(tc, T(0.252 * 1013.0), T(-2.0582 * 1013.0)), sh.p_mbar_k);
+    T rho_cp = nn * rt;
     T t2 = t * t;
-    T g_rr = (K<T>::sigma4 / cp) * ((t2 * t2) * t) * u;
+    T g_rr = (K<T>::sigma4 * (t2 * t2)) * M::rcp(nn);
     T rcfv = rho_cp * vpd;             // rho Cp vpd
 
     // -- wet canopy, :866-961 in conductances:
     //    1/r_a = g_h + 1/r_r ; evap = numer g_e / ((s lhv) g_e + k_p / r_a)
     {
         // fwet is 0 exactly when rh < 0.7 (else rh^4 >= 0.24, or NaN), so the three
-        // tests on it -- fwet == 0 (:934), fw <= tiny (:961) -- are that one mask
-        T fw = dry ? tiny : fwet;                                  // :934
+        // tests on it -- fwet == 0 (:934), fw <= tiny (:961) -- are that one mask; the reference
+        // replaces a zero by `tiny` only to keep 1 / (gl fwet) finite (:934), and the dry pixel's
+        // result is the 0 of :961 whatever its quotient -- in conductances nothing divides by
+        // fwet, so the replacement itself is not needed (two selects per period less, round 5)
+        T fw = fwet;
         T g_e = sh.glwv_l * fw;
         T g_a = __builtin_fma(sh.glsh_l, fw, g_rr);                // g_h + 1/r_r
         T numer = fw * __builtin_fma(rcfv * x.fpar, g_a, s * (x.fpar * rad_net));
@@ -657,7 +691,7 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
         T num = __builtin_fma((s * rad_soil), r_tot, (rcfv * sh.omf) * w);
         T den = r_tot * __builtin_fma(sh.k_p, w, slhv);
         T q = num * M::rcp_quotient(den);                                   // numer/denom/lhv
-        T pw = M::pow01_tab(rh, vpd * p.inv_beta, tb);             // :861
+        T pw = M::pow01_tab1(rh, vpd * p.inv_beta, tb);            // :861
         // sat = q fwet and unsat = q (1 - fwet) with 0 <= fwet <= 1: both
         // clamps of :858-861 fire exactly when q < 0 (NaN falls through)
         T e = q * __builtin_fma(omw, pw, fwet);
@@ -698,9 +732,10 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     }
 }
 
-template <typename T, bool PET = false, typename KP = KLit>
+// RAW: x.vpd_d / x.vpd_n hold q p of the period and dav_d / dav_n its 0.622 + 0.379 q (see period_fast)
+template <typename T, bool PET = false, typename KP = KLit, bool RAW = false>
 __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const ClassPar<T>& p,
-                                                     const T* tb) {
+                                                     const T* tb, T dav_d = T(1), T dav_n = T(1)) {
 #pragma clang fp contract(off)
     PixelOut<T> o;
 #ifdef MOD16_TRIVIAL_BODY   // measurement aid (-DMOD16_TRIVIAL_BODY): memory pattern only, no arithmetic
@@ -721,18 +756,20 @@ __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const 
     const T k473 = KP::per_pixel(4.73), k2087 = KP::per_pixel(-20.87), k039 = KP::per_pixel(0.39);
     const T t_ann_max = KP::per_pixel(273.15 + 25.0), dt_min = KP::per_pixel(5.0);
     bool cond = (x.t_ann < t_ann_max) & (x.t_ann >= (K<T>::t0 + p.tmin_close)) & ((x.t_d - x.t_n) >= dt_min);
+    // (0.39 |A| = |0.39 A| exactly: one product serves the test and the cap, :1112)
+    const T cap_d = k039 * a_d, cap_n = k039 * a_n;
     T g_d = cond ? __builtin_fma(k473, x.t_d - K<T>::t0, k2087) : T(0);
-    g_d = (__builtin_fabs(g_d) > (k039 * __builtin_fabs(a_d))) ? k039 * a_d : g_d;
+    g_d = (__builtin_fabs(g_d) > __builtin_fabs(cap_d)) ? cap_d : g_d;
     T g_n = cond ? __builtin_fma(k473, x.t_n - K<T>::t0, k2087) : T(0);
-    g_n = (__builtin_fabs(g_n) > (k039 * __builtin_fabs(a_n))) ? k039 * a_n : g_n;
+    g_n = (__builtin_fabs(g_n) > __builtin_fabs(cap_n)) ? cap_n : g_n;
     g_d = ((a_d - g_d < T(0)) & (a_d > T(0))) ? a_d : g_d;
     g_n = ((a_d > T(0)) & ((a_n - g_n) < (T(-0.5) * a_d))) ? __builtin_fma(T(0.5), a_d, a_n) : g_n;
     T rs_d = sh.omf * (a_d - g_d);
     T rs_n = sh.omf * (a_n - g_n);
     // -- period-independent terms
-    sh.p_rel = x.pa * KP::per_pixel(1.0 / 101300.0);
+    sh.p_rel = x.pa * KP::per_pixel(0.2050207779207528);        // 293.15^1.75 / 101300
     sh.k_p = x.pa * KP::per_pixel(1013.0 / 0.622);
-    sh.p_mbar_k = x.pa * KP::per_pixel(0.348444 / 100.0);
+    sh.p_mbar_k = x.pa * KP::per_pixel(1013.0 * 0.348444 / 100.0);
     sh.l_wet = (x.lai == T(0)) ? K<T>::tiny : x.lai;
     sh.lai_tiny = sh.l_wet <= K<T>::tiny;
     sh.lai_pos = x.lai > T(0);
@@ -743,11 +780,11 @@ __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const 
     sh.m_tmin = (tm - p.tmin_close) * p.inv_dtmin;
     sh.m_tmin = (tm < p.tmin_close) ? T(0) : sh.m_tmin;
     sh.m_tmin = (tm >= p.tmin_open) ? T(1) : sh.m_tmin;
-    period_fast<T, true, PET, KP>(x, p, sh, tb, x.t_d, x.vpd_d, a_d, rs_d, o.canopy_d, o.soil_d, o.trans_d,
-                              &o.pet_d);
+    period_fast<T, true, PET, KP, RAW>(x, p, sh, tb, x.t_d, x.vpd_d, a_d, rs_d, o.canopy_d, o.soil_d, o.trans_d,
+                                       &o.pet_d, dav_d);
     T rn_n = __builtin_fma(x.sw_n, sh.oma, x.lw_n);
-    period_fast<T, false, PET, KP>(x, p, sh, tb, x.t_n, x.vpd_n, rn_n, rs_n, o.canopy_n, o.soil_n, o.trans_n,
-                               &o.pet_n);
+    period_fast<T, false, PET, KP, RAW>(x, p, sh, tb, x.t_n, x.vpd_n, rn_n, rs_n, o.canopy_n, o.soil_n, o.trans_n,
+                                        &o.pet_n, dav_n);
     return o;
 }
 
@@ -883,25 +920,20 @@ __device__ __forceinline__ PixelIn<T> raw_to_pixel_exact(const RawIn<T>& r) {
 }
 
 constexpr double kElevMid = 5000.0, kElevHalf = 7000.0;   // the fast form's elevations: -2000 m .. 12000 m
+// -> the pixel of the fast forward run, with the humidity left in its raw terms: x.vpd_d / x.vpd_n
+// hold q p (specific humidity x surface pressure) and dav_d / dav_n the quotient's denominator
+// 0.622 + 0.379 q -- period_fast<..., RAW> forms MOD16.vpd from them next to the saturation
+// pressure, whose exponential and reciprocal it shares (round 5).
 __device__ __forceinline__ PixelIn<double> raw_to_pixel_fast(const RawIn<double>& r,
-                                                             const double* tb) {
+                                                             const double* tb, double& dav_d, double& dav_n) {
     typedef FastMath<double> M;
     PixelIn<double> x;
     x.lw_d = r.lw_d; x.lw_n = r.lw_n; x.sw_d = r.sw_d; x.sw_n = r.sw_n; x.alb = r.alb;
     x.t_d = r.t_d; x.t_n = r.t_n; x.t_ann = r.t_ann; x.tmin = r.tmin;
-    auto vpd = [&](double qv, double ps, double t) {
-        double tc = t - 273.15;
-        // both quotients from one reciprocal (of the product of the denominators); a NaN
-        // temperature stays NaN through exp_tab
-        double d_avp = __builtin_fma(0.379, qv, 0.622), d_sv = 239.0 + tc;
-        double r = M::rcp(d_avp * d_sv);
-        double avp = (qv * ps) * (r * d_sv);
-        double sv = 610.7 * M::exp_tab((17.38 * tc) * (r * d_avp), tb);
-        return sv - avp;
-    };
-    x.vpd_d = vpd(r.qv_d, r.ps_d, r.t_d);
-    double vn = vpd(r.qv_n, r.ps_n, r.t_n);
-    x.vpd_n = (vn < 0.0) ? 0.0 : vn;
+    x.vpd_d = r.qv_d * r.ps_d;                                     // :638-639
+    x.vpd_n = r.qv_n * r.ps_n;
+    dav_d = M::fma_kk(r.qv_d, 0.379, 0.622);
+    dav_n = M::fma_kk(r.qv_n, 0.379, 0.622);
     // 101325 (1 - 0.0065 z / 288.15)^5.2559 as a polynomial of degree 9 in u = (z - 5000) / 7000
     // (coefficients in LDS behind the exp / log tables: 3.7e-14 relative on -2000 m .. 12000 m, the
     // interval the guard below admits; a log + an exp before -- 20 float64 instructions more). A NaN
@@ -920,6 +952,15 @@ __device__ __forceinline__ PixelIn<double> raw_to_pixel_fast(const RawIn<double>
     return x;
 }
 
+// The raw forms' temperature interval: 190 K .. 360 K (-83 C .. +87 C; the coldest 10-m air of a
+// reanalysis is ~195 K, the hottest ~330 K). On it the two saturation formulas' exponents differ by
+// |delta| < 0.043 and exp(delta) is a degree-6 polynomial to 5e-14 (period_fast<..., RAW>); a
+// temperature outside goes the reference's way like every other pixel outside the domain.
+constexpr double kRawTmin = 190.0, kRawTmax = 360.0;
+__device__ __forceinline__ GuardConsts raw_guard_consts() {
+    constexpr double mid = 0.5 * (kRawTmin + kRawTmax), k = kGuardHuge / (0.5 * (kRawTmax - kRawTmin));
+    return GuardConsts{in_vgpr(k), in_vgpr(-mid * k), in_vgpr(kGuardHuge)};
+}
 // Domain of raw_to_pixel_fast + et_pixel_fast on raw drivers: as above for the fields that
 // pass through, plus what the fused pre-processing assumes: a specific humidity below 1 kg/kg
 // (0.379 qv + 0.622 > 0: one reciprocal serves both quotients), a finite surface pressure, an
@@ -946,7 +987,7 @@ __device__ __forceinline__ double raw_guard_value(const RawIn<double>& r, const 
 #endif
 }
 __device__ __forceinline__ bool raw_out_of_domain(const RawIn<double>& r) {
-    const GuardConsts gc = guard_consts();
+    const GuardConsts gc = raw_guard_consts();
     return raw_guard_value(r, gc) >= gc.huge;
 }
 

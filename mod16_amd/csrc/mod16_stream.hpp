@@ -306,7 +306,12 @@ constexpr int kFlagBits = 52;        // ... as an exact integer in a double
 // schedule 1.2 % slower for the same 188 registers -- profiles/r03_ab_bisect.txt)
 // GUARD = false (MOD16_DOMAIN_TRUSTED, totals forms only): the caller vouches for the drivers; no
 // domain test, no flag record, nothing revisited -- the loop of round 2.
-#define MOD16_STREAM_BOUNDS __launch_bounds__(kBlock)
+// (the one exception, round 5: the raw-driver instances with per-pixel hours of daylight -- 15 wide
+// inputs -- came out at 258 / 260 registers once the humidity moved into the period, i.e. ONE wave
+// per SIMD; they alone are told to stay within two)
+constexpr int stream_min_waves(int mode) { return mode == kStreamRawTotalHours ? 2 : 1; }
+#define MOD16_STREAM_BOUNDS __launch_bounds__(kBlock) \
+    __attribute__((amdgpu_waves_per_eu(stream_min_waves(MODE), 8)))
 template <typename T, int MODE, bool PITCHED = false, bool GUARD = true>
 __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     typedef StreamSpec<MODE> S;
@@ -467,7 +472,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     for (int i = threadIdx.x; i < kTab; i += kBlock) tab[i] = a.tab[i];
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const GuardConsts gc = guard_consts();      // (three register pairs held through the loop)
+    const GuardConsts gc = RAW ? raw_guard_consts() : guard_consts();      // (three register pairs held through the loop)
     bool flushed = false;
 #pragma nounroll
     for (; cbase + run < npiece; ) {
@@ -612,6 +617,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 PixelIn<double> x;
+                double dav_d = 1.0, dav_n = 1.0;       // raw forms: the humidity quotients' denominators
                 if constexpr (RAW) {
                     RawIn<double> r = {(double)in[0][j], (double)in[1][j], (double)in[2][j],
                                        (double)in[3][j], (double)in[4][j], (double)in[5][j],
@@ -623,7 +629,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                     // instances have no vector registers to spare)
                     const bool out = raw_guard_value(r, gc) >= gc.huge;
                     bad |= out;
-                    x = raw_to_pixel_fast(r, tab);
+                    x = raw_to_pixel_fast(r, tab, dav_d, dav_n);
                     x.fpar = out ? __builtin_nan("") : x.fpar;
                 } else {
                     x = PixelIn<double>{(double)in[0][j], (double)in[1][j], (double)in[2][j],
@@ -661,7 +667,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                 p.inv_beta = l[14 * kLutCols];
                 // (the totals instances hold the pixel function's busiest constants in vector registers)
                 typedef typename std::conditional<MODE == kStreamTotals && std::is_same<T, double>::value, KPin<kPinLevel>, KLit>::type KP;
-                PixelOut<double> o = et_pixel_fast<double, MODE == kStreamPet, KP>(x, p, tab);
+                PixelOut<double> o = et_pixel_fast<double, MODE == kStreamPet, KP, RAW>(x, p, tab, dav_d, dav_n);
                 const double day = (o.canopy_d + o.soil_d) + o.trans_d;      // :792
                 const double night = (o.canopy_n + o.soil_n) + o.trans_n;
                 if constexpr (MODE == kStreamSep6) {
