@@ -243,6 +243,18 @@ template <> struct FastMath<double> {
         return __builtin_amdgcn_ldexp(tb[ki & 63] * p, ki >> 6);
     }
 
+    // ... and with the one-constant reduction (mixed form, round 5)
+    static __device__ __forceinline__ T exp_tab3s(T x, const T* tb) {
+        T km = __builtin_fma(x, 92.33248261689366, kRintShift);
+        T kf = km - kRintShift;
+        T r = __builtin_fma(kf, -0.010830424696249145, x);
+        T p = fma_kk(r, 1.0 / 6.0, 0.5);
+        p = __builtin_fma(p, r, 1.0);
+        p = __builtin_fma(p, r, 1.0);
+        int ki = __double2loint(km);
+        return __builtin_amdgcn_ldexp(tb[ki & 63] * p, ki >> 6);
+    }
+
     // ln(x) for x > 0 normal (x is a relative humidity in (0, 1] here);
     // log(1) is exactly 0 by construction of table entry 0; x = 0 -> -inf.
     // Absolute error ~1e-15 (what matters: the result feeds exp(y log x)).

@@ -76,6 +76,8 @@ struct Humid2 {
 };
 
 // esat, rh, fwet, 1 - fwet of one pixel and period in float64, as in period_fast
+__device__ __forceinline__ void humid64_tail(double esat, double vpd, float& esat_f, float& rh_f,
+                                             float& fwet_f, float& omw_f, bool& dry, bool& open_w);
 __device__ __forceinline__ void humid64(double t, double vpd, const double* tb, float& esat_f,
                                         float& rh_f, float& fwet_f, float& omw_f, bool& dry,
                                         bool& open_w) {
@@ -83,7 +85,39 @@ __device__ __forceinline__ void humid64(double t, double vpd, const double* tb, 
     double tc = t - K<double>::t0;
     // exp to 4e-11 (cubic on the table's |r| <= ln2/128): the float32 results below keep 6e-8.
     // (A NaN temperature stays NaN through exp_tab3; an infinite one through the reciprocal.)
-    double esat = (1e3 * 0.6108) * M::exp_tab3((17.27 * tc) * M::rcp(tc + 237.3), tb);
+    double esat = (1e3 * 0.6108) * M::exp_tab3s((17.27 * tc) * M::rcp(tc + 237.3), tb);
+    humid64_tail(esat, vpd, esat_f, rh_f, fwet_f, omw_f, dry, open_w);
+}
+// Raw drivers (round 5): MOD16.vpd (mod16/__init__.py:604-644; the night value clamped at 0,
+// calibration.py:401) and the humidity of one pixel and period in ONE float64 section -- the two
+// saturation formulas share their exponential (exp(delta) as a quartic: |delta| < 0.043 on the raw
+// forms' 190 K .. 360 K, 1e-9 at the cold end, 1e-13 in ordinary air) and the three quotients one
+// reciprocal, as in period_fast<..., RAW>.
+template <bool NIGHT>
+__device__ __forceinline__ double humid64_raw(double t, double qv, double ps, const double* tb, float& esat_f,
+                                              float& rh_f, float& fwet_f, float& omw_f, bool& dry,
+                                              bool& open_w) {
+    typedef FastMath<double> M;
+    const double tc = t - K<double>::t0;
+    const double d_es = tc + 237.3, ta = tc + 239.0, dav = __builtin_fma(0.379, qv, 0.622);
+    const double dd = d_es * ta;
+    const double r3 = M::rcp(dd * dav);
+    const double r_both = r3 * dav, r_av = r3 * dd;
+    const double e_es = M::exp_tab3s((17.27 * tc) * (r_both * ta), tb);
+    const double esat = (1e3 * 0.6108) * e_es;
+    const double delta = (tc * __builtin_fma(tc, 0x1.c28f5c28f5c00p-4, -0x1.a0c49ba5e34b1p+1)) * r_both;
+    double q = __builtin_fma(delta, 1.0 / 24.0, 1.0 / 6.0);
+    q = __builtin_fma(q, delta, 0.5);
+    q = __builtin_fma(q, delta, 1.0);
+    q = __builtin_fma(q, delta, 1.0);
+    double vpd = __builtin_fma(-(qv * ps), r_av, (610.7 * e_es) * q);
+    if (NIGHT) vpd = (vpd < 0.0) ? 0.0 : vpd;
+    humid64_tail(esat, vpd, esat_f, rh_f, fwet_f, omw_f, dry, open_w);
+    return vpd;
+}
+__device__ __forceinline__ void humid64_tail(double esat, double vpd, float& esat_f, float& rh_f,
+                                             float& fwet_f, float& omw_f, bool& dry, bool& open_w) {
+    typedef FastMath<double> M;
     // rh = avp / esat = 1 - vpd / esat in one fma: exactly 1 for vpd = 0 (fwet = 1 and the
     // 1 - fwet > 0 decision depend on it), 3e-14 absolute otherwise (the reciprocal's) -- the
     // results are float32. The two clamps test the inputs themselves, as the reference's
@@ -110,24 +144,29 @@ __device__ __forceinline__ Parts2 period_mixed(const ClassPar2& p, const Shared2
                                                f2 t, f2 vpd, f2 rad_net, f2 rad_soil) {
     const f2 zero = splat(0.f), one = splat(1.f), tiny = splat(1e-7f);
     f2 tc = t - splat(273.15f);
-    f2 ta = (splat(239.0f) + t) - splat(273.15f);
+    f2 ta = t - splat(34.15f);                                              // (239 + T) - 273.15, :1395
     f2 rta = rcp2(ta);
     f2 s = (splat((float)(17.38 * 239.0)) * h.esat) * (rta * rta);          // :1395-1397
     f2 lhv = __builtin_elementwise_fma(tc, splat(-0.002361e6f), splat(2.501e6f));   // (2.501 - 0.002361 tc) 1e6, :121
     f2 slhv = s * lhv;
     // 1 / r_corr = (P / 101300) (T / 293.15)^-1.75, :771
+    // (the argument near 1: v_log_f32's error is absolute, ~1 ulp of the RESULT -- log2 of t itself,
+    // ~8, would cost 1e-6 relative in the power)
     f2 inv_rcorr = sh.p_rel * exp2_2(splat(-1.75f) * log2_2(t * splat((float)(1.0 / 293.15))));
     // rho Cp and 4 sigma T^3 / (rho Cp) from one reciprocal, :408-412, :947
-    f2 nn = sh.p_mbar_k - h.rh * __builtin_elementwise_fma(tc, splat(0.252f), splat(-2.0582f));   // (rh 100)(0.00252 tc - 0.020582)
+    // (N carries the factor Cp, as in period_fast: rho Cp = N / T, 1/r_r = 4 sigma T^4 / N)
+    f2 nn = sh.p_mbar_k - h.rh * __builtin_elementwise_fma(tc, splat((float)(0.252 * 1013.0)), splat((float)(-2.0582 * 1013.0)));   // Cp (rh 100)(0.00252 tc - 0.020582)
     f2 u = rcp2(nn * t);
-    f2 rho_cp = splat(1013.0f) * ((nn * nn) * u);
+    f2 rho_cp = (nn * nn) * u;
     f2 t2 = t * t;
-    f2 g_rr = splat((float)(4.0 * 5.67e-8 / 1013.0)) * ((t2 * t2) * t) * u;
+    f2 g_rr = splat((float)(4.0 * 5.67e-8)) * ((t2 * t2) * t) * u;
     f2 rcfv = rho_cp * vpd;
     f2 radc_raw = sh.fpar * rad_net;
 
     // wet canopy, :866-961
-    f2 fw = sel(h.dry[0], h.dry[1], tiny, h.fwet);                                          // :934 (fwet == 0 <=> dry)
+    // (:934 replaces fwet = 0 by `tiny` to keep 1 / (gl fwet) finite; nothing divides by fwet here and
+    // the dry pixel's result is the 0 of :961 whatever its quotient: no replacement, as in period_fast)
+    f2 fw = h.fwet;
     f2 g_h = sh.glsh_l * fw, g_e = sh.glwv_l * fw, g_a = g_h + g_rr;
     f2 numer = fw * ((rcfv * sh.fpar) * g_a + s * radc_raw);
     f2 den = slhv * g_e + sh.k_p * g_a;
@@ -195,7 +234,8 @@ __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], co
                                                     const double* l1, int ls, const double* tb,
                                                     Parts2& day, Parts2& night,
                                                     const double (*vpd64)[2] = nullptr,
-                                                    const float* f0 = nullptr, const float* f1 = nullptr) {
+                                                    const float* f0 = nullptr, const float* f1 = nullptr,
+                                                    const Humid2* hraw = nullptr) {
     const f2 zero = splat(0.f);
     auto col = [&](int k) { return f2{in[k][0], in[k][1]}; };
     auto par = [&](int row) {
@@ -216,10 +256,12 @@ __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], co
     // t - 273.15 as (t - 273) - 0.15: both differences are exact or correctly rounded
     const f2 gd0 = sel(cond0, cond1, __builtin_elementwise_fma(splat(4.73f), (t_d - splat(273.f)) - splat(0.15f), splat(-20.87f)), zero);
     const f2 gn0 = sel(cond0, cond1, __builtin_elementwise_fma(splat(4.73f), (t_n - splat(273.f)) - splat(0.15f), splat(-20.87f)), zero);
-    const f2 lim_d = splat(0.39f) * __builtin_elementwise_abs(a_d), lim_n = splat(0.39f) * __builtin_elementwise_abs(a_n);
+    // (0.39 |A| = |0.39 A| exactly: one product serves the test and the cap, :1112)
+    const f2 cap_d = splat(0.39f) * a_d, cap_n = splat(0.39f) * a_n;
+    const f2 lim_d = __builtin_elementwise_abs(cap_d), lim_n = __builtin_elementwise_abs(cap_n);
     const f2 agd = __builtin_elementwise_abs(gd0), agn = __builtin_elementwise_abs(gn0);
-    const f2 gd1 = sel(agd.x > lim_d.x, agd.y > lim_d.y, splat(0.39f) * a_d, gd0);
-    const f2 gn1 = sel(agn.x > lim_n.x, agn.y > lim_n.y, splat(0.39f) * a_n, gn0);
+    const f2 gd1 = sel(agd.x > lim_d.x, agd.y > lim_d.y, cap_d, gd0);
+    const f2 gn1 = sel(agn.x > lim_n.x, agn.y > lim_n.y, cap_n, gn0);
     const f2 dd = a_d - gd1;
     const f2 gd2 = sel((dd.x < 0.f) & (a_d.x > 0.f), (dd.y < 0.f) & (a_d.y > 0.f), a_d, gd1);
     const f2 dn = (a_n - gn1) + splat(0.5f) * a_d;
@@ -265,7 +307,10 @@ __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], co
     // per two pixels and period against 2 x 45 here: same error table, same kernel time;
     // profiles/r02_experiments_not_kept.txt)
     Humid2 hd, hn;
-    {
+    if (hraw) {             // raw drivers: the humidity came with the VPD (raw_pair_mixed)
+        hd = hraw[0];
+        hn = hraw[1];
+    } else {
         float esat_d[2], rh_d[2], fwet_d[2], omw_d[2], esat_n[2], rh_n[2], fwet_n[2], omw_n[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -290,7 +335,7 @@ __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], co
     sh.omf = omf;
     sh.p_rel = pa * splat((float)(1.0 / 101300.0));
     sh.k_p = pa * splat((float)(1013.0 / 0.622));
-    sh.p_mbar_k = pa * splat((float)(0.348444 / 100.0));
+    sh.p_mbar_k = pa * splat((float)(1013.0 * 0.348444 / 100.0));
     const f2 l_wet = sel(lai.x == 0.f, lai.y == 0.f, splat(1e-7f), lai);              // :935
     // lai <= tiny (:961) is asked in float64 of the float32 value: float32(1e-7) is ABOVE 1e-7,
     // so a LAI of exactly that float is not masked by the reference (pair fuzz, round 3):
@@ -318,29 +363,25 @@ __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], co
 // decodings are float32.
 __device__ __forceinline__ void raw_pair_mixed(const float (&raw)[14][2], const unsigned (&fpar_pct)[2],
                                                const unsigned (&lai_x10)[2], const double* tb,
-                                               float (&in)[14][2], double (&vpd64)[2][2]) {
-    typedef FastMath<double> M;
+                                               float (&in)[14][2], Humid2 (&hum)[2]) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) { in[k][0] = raw[k][0]; in[k][1] = raw[k][1]; }
+    float esat[2][2], rh[2][2], fwet[2][2], omw[2][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        auto vpd = [&](double qv, double ps, double t) {                     // MOD16.vpd, :604-644
-            const double tc = t - 273.15;
-            // one reciprocal for both quotients; the cubic exp (4e-11) is what the humidity
-            // section uses on the same quantity
-            const double d_avp = __builtin_fma(0.379, qv, 0.622), d_sv = 239.0 + tc;
-            const double r = M::rcp(d_avp * d_sv);
-            const double avp = (qv * ps) * (r * d_sv);
-            const double sv = 610.7 * M::exp_tab3((17.38 * tc) * (r * d_avp), tb);
-            return sv - avp;
-        };
-        vpd64[0][j] = vpd(raw[9][j], raw[11][j], raw[5][j]);
-        const double vn = vpd(raw[10][j], raw[12][j], raw[6][j]);
-        vpd64[1][j] = (vn < 0.0) ? 0.0 : vn;                                 // calibration.py:401
-        in[9][j] = (float)vpd64[0][j];
-        in[10][j] = (float)vpd64[1][j];
+        const double vd = humid64_raw<false>(raw[5][j], raw[9][j], raw[11][j], tb, esat[0][j], rh[0][j], fwet[0][j],
+                                             omw[0][j], hum[0].dry[j], hum[0].open_w[j]);
+        const double vn = humid64_raw<true>(raw[6][j], raw[10][j], raw[12][j], tb, esat[1][j], rh[1][j], fwet[1][j],
+                                            omw[1][j], hum[1].dry[j], hum[1].open_w[j]);
+        in[9][j] = (float)vd;
+        in[10][j] = (float)vn;
         in[12][j] = (fpar_pct[j] >= 249u) ? __builtin_nanf("") : (float)fpar_pct[j] * 0.01f;
         in[13][j] = (lai_x10[j] >= 249u) ? __builtin_nanf("") : (float)lai_x10[j] * 0.1f;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        hum[e].esat = f2{esat[e][0], esat[e][1]}; hum[e].rh = f2{rh[e][0], rh[e][1]};
+        hum[e].fwet = f2{fwet[e][0], fwet[e][1]}; hum[e].omw = f2{omw[e][0], omw[e][1]};
     }
     // 101325 (1 - 0.0065 z / 288.15)^5.2559, MOD16.air_pressure :414-447
     const f2 ratio = __builtin_elementwise_fma(f2{raw[13][0], raw[13][1]}, splat((float)(-0.0065 / 288.15)), splat(1.f));
@@ -401,11 +442,17 @@ __device__ __forceinline__ unsigned pair_out_of_domain(const float (&in)[14][2])
 // raw drivers (raw_pair_mixed): the fields that pass through as above; specific humidity
 // below 1 kg/kg, the surface pressures like the air pressure, |elevation| below 25 km (the air
 // pressure computed from it then stays inside 1e3 .. 1e7 Pa: 1.1e3 Pa at 25 km, 1.1e6 at -25 km)
+// ... and the raw forms' temperature interval, 190 K < T < 360 K (kRawTmin / kRawTmax, mod16_physics.hpp:
+// where the shared exponential of the two saturation formulas holds)
+__device__ __forceinline__ f2 guard_scale_traw(f2 t) {
+    constexpr float mid = 0.5f * (float)(kRawTmin + kRawTmax), half = 0.5f * (float)(kRawTmax - kRawTmin);
+    return __builtin_elementwise_fma(t, splat(kGuardMixed / half), splat(-mid * (kGuardMixed / half)));
+}
 __device__ __forceinline__ unsigned raw_pair_out_of_domain(const float (&raw)[14][2]) {
     auto col = [&](int k) { return f2{raw[k][0], raw[k][1]}; };
     const f2 y[12] = {col(0), col(1), col(2), col(3), col(4), col(9) * splat(kGuardMixed),
                       col(10) * splat(kGuardMixed), col(13) * splat(4.f),
-                      guard_scale_t(col(5)), guard_scale_t(col(6)), guard_scale_p(col(11)),
+                      guard_scale_traw(col(5)), guard_scale_traw(col(6)), guard_scale_p(col(11)),
                       guard_scale_p(col(12))};
     return pair_guard<12>(y);
 }
@@ -424,6 +471,10 @@ __device__ __forceinline__ float guard_scale_t1(float t) {
 __device__ __forceinline__ float guard_scale_p1(float p) {
     return __builtin_fmaf(p, kGuardMixed / 4.9995e6f, -5.0005e6f * (kGuardMixed / 4.9995e6f));
 }
+__device__ __forceinline__ float guard_scale_traw1(float t) {
+    constexpr float mid = 0.5f * (float)(kRawTmin + kRawTmax), half = 0.5f * (float)(kRawTmax - kRawTmin);
+    return __builtin_fmaf(t, kGuardMixed / half, -mid * (kGuardMixed / half));
+}
 __device__ __forceinline__ bool out_of_domain_f32(const PixelIn<double>& x) {
 #ifdef MOD16_NO_GUARD
     return false;
@@ -440,7 +491,7 @@ __device__ __forceinline__ bool raw_out_of_domain_f32(const RawIn<double>& r) {
 #else
     const float y[12] = {(float)r.lw_d, (float)r.lw_n, (float)r.sw_d, (float)r.sw_n, (float)r.alb,
                          (float)r.qv_d * kGuardMixed, (float)r.qv_n * kGuardMixed, (float)r.elev * 4.f,
-                         guard_scale_t1((float)r.t_d), guard_scale_t1((float)r.t_n),
+                         guard_scale_traw1((float)r.t_d), guard_scale_traw1((float)r.t_n),
                          guard_scale_p1((float)r.ps_d), guard_scale_p1((float)r.ps_n)};
     return guard_list_f32(y, 12);
 #endif

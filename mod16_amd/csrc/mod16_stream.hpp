@@ -551,13 +551,13 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                         unsigned fp[2] = {(bits[1] >> (8 * jj)) & 0xffu, (bits[1] >> (8 * jj + 8)) & 0xffu};
                         const unsigned lx[2] = {(bits[2] >> (8 * jj)) & 0xffu, (bits[2] >> (8 * jj + 8)) & 0xffu};
                         float din[14][2];
-                        double vpd64[2][2];
+                        Humid2 hum[2];
                         const unsigned b2 = raw_pair_out_of_domain(pin);
                         bad |= b2 != 0u;
                         fp[0] = (b2 & 1u) ? 255u : fp[0];        // a fill code: fPAR = NaN
                         fp[1] = (b2 & 2u) ? 255u : fp[1];
-                        raw_pair_mixed(pin, fp, lx, tab, din, vpd64);
-                        et_pair_mixed_parts<false, true>(din, lut + c0, lut + c1, kLutCols, tab, pd, pn, vpd64, lutf + c0, lutf + c1);
+                        raw_pair_mixed(pin, fp, lx, tab, din, hum);
+                        et_pair_mixed_parts<false, true>(din, lut + c0, lut + c1, kLutCols, tab, pd, pn, nullptr, lutf + c0, lutf + c1, hum);
                     } else {
                         if constexpr (GUARD) {
                             const unsigned b2 = pair_out_of_domain(pin);
