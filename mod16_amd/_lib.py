@@ -268,7 +268,7 @@ def load_experiments():
     '''The experiments build of the library (``libmod16hip_exp.so``: the same sources with
     ``-DMOD16_EXPERIMENTS``), whose contexts read the launch-geometry overrides ``MOD16_NO_DMA``,
     ``MOD16_RUN_SHIFT``, ``MOD16_STATIC_BELOW``, ``MOD16_STREAM_BLOCKS``, ``MOD16_PITCH``,
-    ``MOD16_GRID_MULT`` from the environment when they are created. For tests and tools: the
+    ``MOD16_GRID_MULT`` (and the fault injection ``MOD16_POISON_TICKET``) from the environment when they are created. For tests and tools: the
     product never calls this (``Context(device, experiments=True)`` is how a test asks for it).'''
     global _exp_lib
     if _exp_lib is None:

@@ -58,6 +58,8 @@ struct mod16_ctx {
     int stream_blocks = 2;           // blocks of the pipeline kernel per CU (1 = one wave per SIMD)
     int static_below = 8;            // runs per wave below which runs are dealt out statically (0: never)
     int use_pitch = 1;               // scalar base + pitch addressing for slab layouts
+    int poison_ticket = 0;           // experiments build, MOD16_POISON_TICKET=k: the next k dynamically scheduled launches find
+                                     // their ticket counter in use (what an abandoned launch leaves behind): the test of kStatusIncomplete
     unsigned long long* dyn_counters = nullptr;   // ring of ticket counters, 128 B apart
     int dyn_next = 0;
     bool have_lut = false;
@@ -199,6 +201,7 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
         if (const char* g = getenv("MOD16_RUN_SHIFT")) ctx->run_shift = std::max(1, std::min(6, atoi(g)));
         if (const char* g = getenv("MOD16_STATIC_BELOW")) ctx->static_below = std::max(0, std::min(64, atoi(g)));
         if (const char* g = getenv("MOD16_STREAM_BLOCKS")) ctx->stream_blocks = std::max(1, std::min(2, atoi(g)));
+        if (const char* g = getenv("MOD16_POISON_TICKET")) ctx->poison_ticket = std::max(0, atoi(g));
 #endif
         HIPCHK(ctx, hipMalloc(&ctx->dyn_counters, 64 * 128));
         HIPCHK(ctx, hipMemset(ctx->dyn_counters, 0, 64 * 128));
@@ -480,6 +483,12 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     // zero when it was allocated, and every launch leaves it at zero again (the kernel's last
     // block resets it) -- no memset in front of the kernel, see et_stream_kernel
     s.dyn_counter = ctr;
+#ifdef MOD16_EXPERIMENTS
+    if (ctx->poison_ticket > 0 && !g.static_sched) {      // (first 8 bytes only: the ticket, not the serial number)
+        --ctx->poison_ticket;
+        HIPCHK(ctx, hipMemsetAsync(ctr, 0x3f, 8, st));
+    }
+#endif
     s.run_shift = g.run_shift;
     s.static_sched = g.static_sched;
     const int grid = g.grid;
@@ -528,8 +537,12 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
             fin = stage;
             count = (count + per - 1) / per;
         }
+        // (a trusted launch has no kernel behind it that looks at every run: the sum checks the markers)
+        const bool check = !GUARD && !g.static_sched;
         hipLaunchKernelGGL(diag_final_fused_kernel, dim3(1), dim3(kFinalBlock), 0, st,
-                           fin, (int)count, s.n, ddiag);
+                           fin, (int)count, s.n, ddiag,
+                           check ? reinterpret_cast<const unsigned*>(ctr) + 3 : (const unsigned*)nullptr,
+                           check ? ctx->status : (unsigned*)nullptr, nruns);
     }
     return ws_release(ctx, st);
 }
@@ -724,6 +737,10 @@ static int read_status(mod16_ctx* ctx, hipStream_t st) {
     HIPCHK(ctx, hipMemcpyAsync(ctx->status_host, ctx->status, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemsetAsync(ctx->status, 0, sizeof(unsigned), st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    if (*ctx->status_host & kStatusIncomplete)
+        return fail(ctx, MOD16_ERR_HIP, "a launch processed only part of its raster: it found its ticket counter in use "
+                                        "(an earlier launch on this context ended abnormally, or more launches were in "
+                                        "flight than the context has counters) -- the outputs of that step are not valid");
     if (*ctx->status_host & kStatusClassRange)
         return fail(ctx, MOD16_ERR_CLASS_RANGE, "class raster holds a code >= 13 (numpy would raise IndexError)");
     return MOD16_OK;

@@ -19,6 +19,15 @@ namespace mod16 {
 constexpr int kBlock = 256;
 constexpr int kLutCols = 16;   // 13 class codes + NaN padding (col 13..15)
 constexpr unsigned kStatusClassRange = 1u;
+// A dynamically scheduled launch of the pipeline kernel (mod16_stream.hpp) did not process every
+// run of its raster: it found a ticket counter that was not at zero (an earlier launch on that
+// counter ended abnormally, or two launches in flight shared it). Such a launch keeps the previous
+// step's outputs and partials for the runs it did not reach -- plausible numbers -- so it is
+// detected: every run's partial carries the launch's serial number (field kSerialField) and what
+// runs behind the pipeline kernel counts the runs that carry it.
+constexpr unsigned kStatusIncomplete = 2u;
+constexpr int kSerialField = 3;      // the field of a run's diagnostics partial that carries the marker
+__device__ __forceinline__ double launch_marker(unsigned serial) { return (double)((serial & 0xffffu) + 1u); }
 
 template <typename T> struct EtArgs {
     const T* drv[14];
@@ -361,9 +370,15 @@ __global__ void __launch_bounds__(kBlock) diag_stage_kernel(const double* partia
 // t adds partials t, t + 1024, ...; then a fixed wave / block tree);
 // n_valid = n - n_nan. 1024 threads keep the dependent-load chain short.
 constexpr int kFinalBlock = 1024;
+// serial_word / status / nruns (trusted launches, which have no kernel behind them that revisits the
+// runs): the launch's serial number AFTER the pipeline kernel incremented it, the status word and the
+// number of runs -- field kSerialField of the partials must add up to nruns markers.
 __global__ void __launch_bounds__(kFinalBlock) diag_final_fused_kernel(const double* partial,
                                                                        int nblocks, int64_t n,
-                                                                       double* out) {
+                                                                       double* out,
+                                                                       const unsigned* serial_word = nullptr,
+                                                                       unsigned* status = nullptr,
+                                                                       int64_t nruns = 0) {
     double acc[kDiag] = {0, 0, 0, 0, 0, 0, -__builtin_huge_val(), -__builtin_huge_val()};
     for (int b = threadIdx.x; b < nblocks; b += kFinalBlock) {
         double o[kDiag];
@@ -397,6 +412,10 @@ __global__ void __launch_bounds__(kFinalBlock) diag_final_fused_kernel(const dou
         out[5] = acc[5];
         out[6] = acc[6];
         out[7] = acc[7];
+        if (serial_word) {
+            const unsigned serial = __hip_atomic_load(serial_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
+            if (acc[kSerialField] != (double)nruns * launch_marker(serial)) atomicOr(status, kStatusIncomplete);
+        }
     }
 }
 

@@ -308,10 +308,12 @@ constexpr int kFlagBits = 52;        // ... as an exact integer in a double
 // domain test, no flag record, nothing revisited -- the loop of round 2.
 // (the one exception, round 5: the raw-driver instances with per-pixel hours of daylight -- 15 wide
 // inputs -- came out at 258 / 260 registers once the humidity moved into the period, i.e. ONE wave
-// per SIMD; they alone are told to stay within two)
-constexpr int stream_min_waves(int mode) { return mode == kStreamRawTotalHours ? 2 : 1; }
+// per SIMD; they alone are told to stay within two, and do so without a spill or a register parked
+// in the accumulator file -- the float32-raster ones because their four pixels per thread are kept
+// apart, see the loop; tests/test_abi.py::test_no_kernel_spills_vector_registers)
+constexpr int stream_min_waves(int mode, bool f64) { return mode == kStreamRawTotalHours ? 2 : 1; }
 #define MOD16_STREAM_BOUNDS __launch_bounds__(kBlock) \
-    __attribute__((amdgpu_waves_per_eu(stream_min_waves(MODE), 8)))
+    __attribute__((amdgpu_waves_per_eu(stream_min_waves(MODE, sizeof(T) == 8), 8)))
 template <typename T, int MODE, bool PITCHED = false, bool GUARD = true>
 __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     typedef StreamSpec<MODE> S;
@@ -379,6 +381,15 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     // where scalar registers are what hipcc runs out of
     unsigned long long flags = 0;
     asm volatile("" : "+v"(flags));
+    // the launch's serial number (word [3] of the ticket counter's block; the last block of a launch
+    // increments it): every run's partial carries it, and what runs behind this kernel counts the
+    // runs that do -- a launch that met a stale ticket counter and processed only its first runs is
+    // reported (kStatusIncomplete) instead of passing the previous step's numbers on. In a vector
+    // register, like `flags`: read at a flush only.
+    unsigned serial = 0;
+    if (!a.static_sched)
+        serial = __hip_atomic_load(reinterpret_cast<const unsigned*>(a.dyn_counter) + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" : "+v"(serial));
     int iters = 0;                     // iterations this wave has done
     // the 8 fields of a diagnostics partial, one per lane (lane k < 8: field k), from the
     // accumulators, which are reset: butterfly sums in a fixed order; field kFlagField = `flags`
@@ -398,6 +409,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         const double cnt_d = (double)__builtin_amdgcn_readfirstlane(nan_d);
         const double cnt_n = (double)__builtin_amdgcn_readfirstlane(nan_n);
         const double f = lane == 0 ? dsum_d : lane == 1 ? dsum_n : lane == kFlagField ? (double)flags
+                       : lane == kSerialField ? launch_marker(serial)
                        : lane == 4 ? cnt_d : lane == 5 ? cnt_n : lane == 6 ? dmax_d : lane == 7 ? dmax_n : 0.0;
         dsum_d = dsum_n = 0.0;
         dmax_d = dmax_n = -__builtin_huge_val();
@@ -703,6 +715,10 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                     dmax_d = FastMath<double>::vmax(dmax_d, d);
                     dmax_n = FastMath<double>::vmax(dmax_n, g);
                 }
+                // float32 raster, float64 arithmetic, raw drivers: four pixels per thread interleaved
+                // need more than 256 registers (one wave per SIMD, or spills inside the counted-vmcnt
+                // loop); one pixel after the other they fit
+                if constexpr (V == 4 && RAW) __builtin_amdgcn_sched_barrier(0);
             }
             }
             const int64_t first = offs_of(cbase, run).o;
@@ -765,6 +781,9 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
             if (__hip_atomic_fetch_add(fin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
                 __hip_atomic_store(late.dyn_counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(fin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the next launch on this counter is another launch: its runs carry another marker
+                // (every wave of this one has left the loop: all of them read the old number)
+                __hip_atomic_fetch_add(fin + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -796,7 +815,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                 f = redo_fold(acc, lane, f);
             }
         }
-        if (lane < kDiag) wave_part[wave][lane] = lane == kFlagField ? 0.0 : f;
+        if (lane < kDiag) wave_part[wave][lane] = (lane == kFlagField || lane == kSerialField) ? 0.0 : f;
         __syncthreads();
         if (wave == 0 && lane < kDiag) {
             double g = wave_part[0][lane];
@@ -892,9 +911,15 @@ __global__ void __launch_bounds__(kBlock) et_stream_redo_kernel(const StreamArgs
     const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const int64_t npiece = (a.n / V + 63) / 64;
     const int rs = a.run_shift;
+    // every run's partial must carry the marker of the launch in front of this kernel (which has
+    // incremented the serial number since): a run without it was not processed
+    const double marker = launch_marker(__hip_atomic_load(reinterpret_cast<const unsigned*>(a.dyn_counter) + 3,
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u);
     for (int64_t r0 = wave * 64; r0 < a.nruns; r0 += nwaves * 64) {
         const int64_t mine = r0 + lane;
         const double fl = mine < a.nruns ? a.diag_partial[mine * kDiag + kFlagField] : 0.0;
+        const double mk = mine < a.nruns ? a.diag_partial[mine * kDiag + kSerialField] : marker;
+        if (__any(mk != marker) && lane == 0) atomicOr(a.status, kStatusIncomplete);
         unsigned long long any = __ballot(fl != 0.0);
         while (any) {
             const int src = __builtin_ctzll(any);

@@ -1,0 +1,111 @@
+"""A dynamically scheduled launch that does not process its raster must not pass for one that did
+(round 4's defect: graph replays between two RCCL barriers found their ticket
+counter in use, claimed nothing and left the previous step's outputs and diagnostics in place --
+plausible numbers, a step twelve times too fast, status OK).
+
+Two checks. The functional one: a captured step replayed K times back to back with the drivers
+changed between the replays -- every replay's outputs and diagnostics are the ones of ITS drivers.
+The loud one: every run's diagnostics partial carries the launch's serial number and what runs
+behind the pipeline kernel counts the runs that carry it (kStatusIncomplete); a launch whose ticket
+counter was poisoned (fault injection of the experiments build) is reported by check(), guarded
+and trusted, and the launch after it is whole again."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 32 * 1024 * 1024          # dynamic schedule: 262144 pieces, 16384+ runs, more than 8 per wave
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    from mod16_amd.raster import RasterEngine
+    from mod16_amd.utils import restore_bplut, bplut_table
+    from mod16_amd.models import COLLECTION61_BPLUT
+    return torch, RasterEngine, bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
+
+
+@pytest.mark.parametrize('layout', ['tiled', 'plain'])
+def test_replays_of_a_captured_step_follow_their_drivers(env, layout):
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table)
+    K = 6
+    diag = torch.zeros(8, dtype=torch.float64, device='cuda')
+    if layout == 'tiled':
+        ras = eng.alloc_tiled(N)
+        step = eng.bind_tiled(ras, diag)
+        fill = lambda k: eng.synth_tiled(ras, seed=40, step=k)
+        outs = lambda: (ras.flat(ras.day, 0, 1 << 20), ras.flat(ras.night, N - (1 << 20), N))
+    else:
+        cls, drv, day, night = eng.alloc_raster(N)
+        step = eng.bind(cls, drv, day, night, diag, graph=True)
+        fill = lambda k: eng.synth(N, seed=40, step=k, out=(cls, drv))
+        outs = lambda: (day[:1 << 20].clone(), night[N - (1 << 20):].clone())
+    # the reference: every step on its own, synchronised, direct launches (no graph)
+    want = []
+    for k in range(K):
+        fill(k)
+        if layout == 'tiled':
+            eng.run_tiled(ras, diag=diag)
+        else:
+            eng.run(cls, drv, day, night, diag=diag)
+        eng.check()
+        want.append((diag.clone(), ) + outs())
+    # K replays queued back to back, the generator between them, nothing waited for
+    torch.cuda.synchronize()
+    got = []
+    for k in range(K):
+        fill(k)
+        step()
+        got.append((diag.clone(), ) + outs())
+    torch.cuda.synchronize()
+    eng.check()
+    for k in range(K):
+        for a, b in zip(got[k], want[k]):
+            assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), (layout, k)
+        assert got[k][0][2] + got[k][0][4] == N          # every pixel counted: valid + NaN
+    for k in range(1, K):                                # ... and the steps do differ
+        assert not torch.equal(got[k][0], got[k - 1][0])
+
+
+@pytest.mark.parametrize('trusted', [False, True])
+def test_a_launch_that_found_its_ticket_in_use_is_reported(env, trusted, monkeypatch):
+    torch, RasterEngine, table = env
+    from mod16_amd import _lib
+    good = RasterEngine(table, trusted=trusted)
+    monkeypatch.setenv('MOD16_POISON_TICKET', '1')      # read when the context is created
+    eng = RasterEngine(table, trusted=trusted, experiments=True)
+    monkeypatch.delenv('MOD16_POISON_TICKET')
+    ras = eng.synth_tiled(eng.alloc_tiled(N), seed=41)
+    diag = torch.zeros(8, dtype=torch.float64, device='cuda')
+    ref = torch.zeros(8, dtype=torch.float64, device='cuda')
+    good.run_tiled(ras, diag=ref)
+    good.check()
+    day_ref = ras.flat(ras.day)
+    ras.day.zero_()
+    eng.run_tiled(ras, diag=diag)                        # its ticket counter is poisoned: processes its first runs only
+    with pytest.raises(_lib.Mod16Error, match='only part of its raster'):
+        eng.check()
+    assert (ras.flat(ras.day) == 0).sum() > N // 2       # most of the raster untouched: what went unnoticed in round 4
+    eng.run_tiled(ras, diag=diag)                        # the poisoned launch left the counter at zero: whole again
+    eng.check()
+    assert torch.equal(diag, ref)
+    assert torch.equal(torch.nan_to_num(ras.flat(ras.day), nan=-7.0), torch.nan_to_num(day_ref, nan=-7.0))
+    # the numpy path (HOST mode) reports it as well
+    monkeypatch.setenv('MOD16_POISON_TICKET', '1')
+    ctx = _lib.Context(0, experiments=True)
+    monkeypatch.delenv('MOD16_POISON_TICKET')
+    ctx.set_bplut(table)
+    n = 1 << 21
+    cls = np.ones(n, np.uint8)
+    drv = [np.full(n, v) for v in (-50., -20., 200., 0., 0.15, 290., 280., 285., 278., 800., 300., 1e5, 0.5, 2.0)]
+    out = [np.empty(n), np.empty(n)]
+    with pytest.raises(_lib.Mod16Error, match='only part of its raster'):
+        ctx.et(np.float64, cls.ctypes.data, [d.ctypes.data for d in drv], [1] * 14, None, None, n,
+               out[0].ctypes.data, out[1].ctypes.data, None, where=_lib.HOST)
+    ctx.et(np.float64, cls.ctypes.data, [d.ctypes.data for d in drv], [1] * 14, None, None, n,
+           out[0].ctypes.data, out[1].ctypes.data, None, where=_lib.HOST)
+    assert np.isfinite(out[0]).all() and (out[0] == out[0][0]).all()

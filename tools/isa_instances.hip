@@ -14,5 +14,7 @@ template __global__ void et_stream_kernel<float, kStreamTotals, true, true>(cons
 template __global__ void et_stream_kernel<float, kStreamTotalsMixed, true, true>(const StreamArgs<float>);
 template __global__ void et_stream_kernel<float, kStreamRawMixed, true, true>(const StreamArgs<float>);
 template __global__ void et_stream_kernel<float, kStreamRawTotalHoursMixed, true, true>(const StreamArgs<float>);
+template __global__ void et_stream_kernel<float, kStreamRawTotalHours, true, true>(const StreamArgs<float>);
+template __global__ void et_stream_kernel<float, kStreamRaw, true, true>(const StreamArgs<float>);
 #endif
 }  // namespace mod16
