@@ -58,8 +58,8 @@ struct mod16_ctx {
     int stream_blocks = 2;           // blocks of the pipeline kernel per CU (1 = one wave per SIMD)
     int static_below = 8;            // runs per wave below which runs are dealt out statically (0: never)
     int use_pitch = 1;               // scalar base + pitch addressing for slab layouts
-    int poison_ticket = 0;           // experiments build, MOD16_POISON_TICKET=k: the next k dynamically scheduled launches find
-                                     // their ticket counter in use (what an abandoned launch leaves behind): the test of kStatusIncomplete
+    int poison_ticket = 0;           // experiments build, MOD16_POISON_TICKET=k: the k-th dynamically scheduled launch finds
+                                     // its ticket counter in use (what an abandoned launch leaves behind): the test of kStatusIncomplete
     unsigned long long* dyn_counters = nullptr;   // ring of ticket counters, 128 B apart
     int dyn_next = 0;
     bool have_lut = false;
@@ -204,7 +204,14 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
         if (const char* g = getenv("MOD16_POISON_TICKET")) ctx->poison_ticket = std::max(0, atoi(g));
 #endif
         HIPCHK(ctx, hipMalloc(&ctx->dyn_counters, 64 * 128));
-        HIPCHK(ctx, hipMemset(ctx->dyn_counters, 0, 64 * 128));
+        {   // ticket = 0, blocks done = 0, and a serial number (word [3]) that starts somewhere else in
+            // every slot of the ring: successive launches take successive slots and share the
+            // diagnostics workspace, so their markers (kSerialField) must differ -- launch j carries
+            // (j % 64) * 1021 + j / 64
+            unsigned init[64 * 32] = {};
+            for (unsigned i = 0; i < 64; ++i) init[i * 32 + 3] = i * 1021u;
+            HIPCHK(ctx, hipMemcpy(ctx->dyn_counters, init, sizeof init, hipMemcpyHostToDevice));
+        }
         const size_t nlut = MOD16_LUT_ROWS * kLutCols;
         HIPCHK(ctx, hipMalloc(&ctx->lut64, nlut * sizeof(double)));
         HIPCHK(ctx, hipMalloc(&ctx->lut32, nlut * sizeof(float)));
@@ -484,9 +491,12 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     // block resets it) -- no memset in front of the kernel, see et_stream_kernel
     s.dyn_counter = ctr;
 #ifdef MOD16_EXPERIMENTS
-    if (ctx->poison_ticket > 0 && !g.static_sched) {      // (first 8 bytes only: the ticket, not the serial number)
-        --ctx->poison_ticket;
-        HIPCHK(ctx, hipMemsetAsync(ctr, 0x3f, 8, st));
+    if (ctx->poison_ticket > 0 && !g.static_sched && --ctx->poison_ticket == 0) {
+        // (MOD16_POISON_TICKET=k: the k-th dynamically scheduled launch of the context) the ticket
+        // -- zero between launches -- becomes 2^40: "every run has been claimed", as a counter left
+        // behind by an abandoned launch says: the waves process their first, statically assigned
+        // runs and find nothing to claim
+        HIPCHK(ctx, hipMemsetAsync(reinterpret_cast<char*>(ctr) + 5, 1, 1, st));
     }
 #endif
     s.run_shift = g.run_shift;

@@ -76,7 +76,7 @@ def test_a_launch_that_found_its_ticket_in_use_is_reported(env, trusted, monkeyp
     torch, RasterEngine, table = env
     from mod16_amd import _lib
     good = RasterEngine(table, trusted=trusted)
-    monkeypatch.setenv('MOD16_POISON_TICKET', '1')      # read when the context is created
+    monkeypatch.setenv('MOD16_POISON_TICKET', '3')      # read when the context is created: its 3rd dynamic launch
     eng = RasterEngine(table, trusted=trusted, experiments=True)
     monkeypatch.delenv('MOD16_POISON_TICKET')
     ras = eng.synth_tiled(eng.alloc_tiled(N), seed=41)
@@ -85,6 +85,12 @@ def test_a_launch_that_found_its_ticket_in_use_is_reported(env, trusted, monkeyp
     good.run_tiled(ras, diag=ref)
     good.check()
     day_ref = ras.flat(ras.day)
+    # two whole launches first: the workspace then holds the partials of a COMPLETE launch of the
+    # same shape -- what the poisoned launch leaves in place for the runs it does not reach
+    for _ in range(2):
+        eng.run_tiled(ras, diag=diag)
+        eng.check()
+        assert torch.equal(diag, ref)
     ras.day.zero_()
     eng.run_tiled(ras, diag=diag)                        # its ticket counter is poisoned: processes its first runs only
     with pytest.raises(_lib.Mod16Error, match='only part of its raster'):
@@ -94,18 +100,5 @@ def test_a_launch_that_found_its_ticket_in_use_is_reported(env, trusted, monkeyp
     eng.check()
     assert torch.equal(diag, ref)
     assert torch.equal(torch.nan_to_num(ras.flat(ras.day), nan=-7.0), torch.nan_to_num(day_ref, nan=-7.0))
-    # the numpy path (HOST mode) reports it as well
-    monkeypatch.setenv('MOD16_POISON_TICKET', '1')
-    ctx = _lib.Context(0, experiments=True)
-    monkeypatch.delenv('MOD16_POISON_TICKET')
-    ctx.set_bplut(table)
-    n = 1 << 21
-    cls = np.ones(n, np.uint8)
-    drv = [np.full(n, v) for v in (-50., -20., 200., 0., 0.15, 290., 280., 285., 278., 800., 300., 1e5, 0.5, 2.0)]
-    out = [np.empty(n), np.empty(n)]
-    with pytest.raises(_lib.Mod16Error, match='only part of its raster'):
-        ctx.et(np.float64, cls.ctypes.data, [d.ctypes.data for d in drv], [1] * 14, None, None, n,
-               out[0].ctypes.data, out[1].ctypes.data, None, where=_lib.HOST)
-    ctx.et(np.float64, cls.ctypes.data, [d.ctypes.data for d in drv], [1] * 14, None, None, n,
-           out[0].ctypes.data, out[1].ctypes.data, None, where=_lib.HOST)
-    assert np.isfinite(out[0]).all() and (out[0] == out[0][0]).all()
+    # (the numpy path -- HOST mode -- stages tiles of 2^21 pixels, which are dealt out statically:
+    # it never reads a ticket counter)
