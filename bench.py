@@ -841,6 +841,7 @@ def build_summary(line):
         'c2_batch64_us_per_tile': c2.get('batch64_us_per_tile'),
         'c4_ms_per_step': c4.get('ms_per_step'),
         'c4_gpx_s': c4['pixels_per_s'] / 1e9 if c4.get('pixels_per_s') else None,
+        'c4_step_over_sum_of_kernels': c4.get('step_over_sum_of_kernels'),
         'c5_mixed_ms': c5.get('mixed_ms'), 'c5_mixed_frac': c5.get('mixed_frac'),
         'c5_fast_ms': c5.get('fast_float64_arithmetic_ms'), 'c5_fast_frac': c5.get('fast_float64_arithmetic_frac'),
         'c5_masks_equal': _dig(c5, 'mixed_vs_float64_arithmetic_full_grid', 'nan_masks_equal'),
@@ -986,6 +987,19 @@ def other_configs(args, torch, np, _lib, RasterEngine, table, bplut):
     torch.cuda.synchronize()
     t_series = time.perf_counter() - t0
     eng.check()
+    # the two kernels of a series step ALONE, on this stream, by events: both stream through the same
+    # HBM, so a step cannot beat their sum; it should not be far above it either (the pipeline kernel
+    # enqueued right behind a cross-stream wait once cost 45 ms where the sum is 39: RasterEngine._gate)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev[0].record()
+    for k in range(3):
+        eng.synth_tiled(ring[0], seed=SEED, step=k)
+    ev[1].record()
+    for k in range(3):
+        eng.run_tiled(ring[0], diag=diag)
+    ev[2].record()
+    torch.cuda.synchronize()
+    synth_ms, et_ms = ev[0].elapsed_time(ev[1]) / 3, ev[1].elapsed_time(ev[2]) / 3
     worst, masks = 0.0, True
     for s, (d, c, gd, gn) in grabbed.items():
         want = oracle.evapotranspiration_raster(bplut, c.cpu().numpy(), *[x.cpu().numpy() for x in d])
@@ -998,6 +1012,8 @@ def other_configs(args, torch, np, _lib, RasterEngine, table, bplut):
         'steps': args.series_steps, 'seconds': t_series,
         'pixels_per_s': n * args.series_steps / t_series,
         'ms_per_step': 1e3 * t_series / args.series_steps,
+        'generator_kernel_ms': synth_ms, 'et_kernel_ms': et_ms,
+        'step_over_sum_of_kernels': 1e3 * t_series / args.series_steps / (synth_ms + et_ms),
         'note': 'includes producing every step\'s 14 driver arrays on the device '
                 '(113 B/pixel written by the generator on a second stream): 242 B/pixel of traffic per step',
         'GBps_total_traffic': 242.0 * n * args.series_steps / t_series / 1e9,

@@ -100,7 +100,10 @@ enum mod16_where { MOD16_HOST = 0, MOD16_DEVICE = 1 };
  * masks included. The raw-driver forms test the raw fields instead: |specific humidity| < 1
  * kg/kg, |surface pressure| < 1e50 Pa, an elevation between -2000 m and 12000 m (the interval on
  * which the fast form evaluates air pressure as a polynomial, 3.7e-14 relative; MIXED: |z| < 25 km),
- * the temperatures and radiation terms as above.
+ * the radiation terms as above, and day / night temperatures between 190 K and 360 K (-83 C ..
+ * +87 C, FAST and MIXED): on that interval the two saturation formulas of the path -- MOD16.vpd's
+ * 610.7 exp(17.38 tc / (239 + tc)) and svp's 610.8 exp(17.27 tc / (237.3 + tc)) -- share one
+ * exponential (their exponents differ by |delta| < 0.043, exp(delta) is a short polynomial; round 5).
  * MOD16_MATH_EXACT is the reference's operation order throughout. */
 #define MOD16_MATH_FAST   0u  /* strength-reduced arithmetic (default)          */
 #define MOD16_MATH_EXACT  1u  /* reference operation order, IEEE divide/pow     */
@@ -469,6 +472,15 @@ MOD16_API int mod16_et_static_batch_f32(mod16_ctx* ctx, const float* const* driv
  *   mod16_static_batch_time       mean milliseconds of the GPU part of the last-shaped
  *       objective evaluation (graph replays bracketed by HIP events).
  * Calls on one object are serialised by its ctx's mutex. Synchronous.
+ *
+ * where = MOD16_DEVICE: the object works on a private stream and the interface takes none, so the
+ * caller's arrays must be COMPLETE when mod16_static_batch_bind_* is called (synchronise the stream
+ * that produced them first) and must not change while the object lives -- the pixels outside the
+ * FAST domain are listed once, at bind time, from the values found then. Device memory that cannot
+ * be had is MOD16_ERR_NOMEM (bind: resident copies, workspace for max_draws parameter vectors -- about
+ * 190 bytes per draw; objective: the per-block partials, 20 bytes x draws x ceil(n / 256), sized for
+ * the draws actually evaluated and grown on demand -- a problem bound for max_draws = 4096 that is
+ * evaluated 256 draws at a time holds a sixteenth of what 4096 would take; EXACT problems: none).
  */
 typedef struct mod16_batch mod16_batch;
 MOD16_API int mod16_static_batch_bind_f64(mod16_ctx* ctx, const double* const* drivers,

@@ -402,6 +402,19 @@ def _host_ram_bytes():
         return 0
 
 
+def _default_pinned_live():
+    '''Default bound on page-locked result memory of THIS process: a quarter of the host's RAM,
+    between 8 and 64 GiB -- divided by the number of processes the launcher put on the node
+    (LOCAL_WORLD_SIZE, else WORLD_SIZE: one rank per GPU), so that eight ranks together stay within
+    that quarter instead of pinning twice the RAM (never below 1 GiB per rank).'''
+    try:
+        ranks = max(1, int(os.environ.get('LOCAL_WORLD_SIZE') or os.environ.get('WORLD_SIZE') or 1))
+    except ValueError:
+        ranks = 1
+    whole = min(64 << 30, max(8 << 30, _host_ram_bytes() // 4))
+    return max(1 << 30, whole // ranks)
+
+
 class _PinnedPool(object):
     '''Page-locked host blocks behind the result arrays of the numpy entry points.
 
@@ -420,13 +433,13 @@ class _PinnedPool(object):
     ordinary (writeable, C-contiguous, own their memory through ``.base``).
 
     Locking: ``give`` runs from ``weakref.finalize``, i.e. possibly inside a garbage
-    collection triggered while ``take`` holds the lock on the same thread -- the lock is
-    re-entrant, and ``hipHostFree`` (which synchronises the device) is only ever called
-    after the lock has been released.'''
+    collection triggered while ``take`` / ``trim`` holds the lock on the same thread -- the lock
+    is re-entrant, and ``hipHostFree`` (which synchronises the device) is only ever called
+    after the lock has been released: a ``give`` that finds its own thread inside the lock leaves
+    the blocks it wants freed on ``deferred``, and whoever holds the lock frees them on the way out.'''
     MIN_BYTES = 1 << 20
     MAX_CACHED = int(os.environ.get('MOD16_PINNED_CACHE', 1 << 30))
-    MAX_LIVE = int(os.environ.get('MOD16_PINNED_LIVE',
-                                  min(64 << 30, max(8 << 30, _host_ram_bytes() // 4))))
+    MAX_LIVE = int(os.environ.get('MOD16_PINNED_LIVE', _default_pinned_live()))
 
     def __init__(self):
         import collections
@@ -437,6 +450,20 @@ class _PinnedPool(object):
         self.recent = collections.deque(maxlen=8)     # sizes of the last results handed out
         self.fallbacks = 0      # results that had to be plain numpy arrays
         self._warned = False
+        self.deferred = []      # blocks a re-entrant give() wants freed (by the lock's holder, after release)
+        self._inside = threading.local()    # depth of this thread inside `with self.lock`
+
+    def _enter(self):
+        self.lock.acquire()
+        self._inside.n = getattr(self._inside, 'n', 0) + 1
+
+    def _leave(self, doomed):
+        '''Releases the lock; the outermost holder takes the deferred blocks along.'''
+        self._inside.n -= 1
+        if self._inside.n == 0 and self.deferred:
+            doomed.extend(self.deferred)
+            del self.deferred[:]
+        self.lock.release()
 
     def _cache_bound(self):
         return min(self.MAX_LIVE, max(self.MAX_CACHED, sum(self.recent)))
@@ -462,19 +489,25 @@ class _PinnedPool(object):
 
     def take(self, nbytes):
         doomed = []
-        with self.lock:
+        self._enter()
+        try:
             self.recent.append(nbytes)
             blocks = self.free.get(nbytes)
-            if blocks:
-                self.cached -= nbytes
-                return blocks.pop()
+            hit = blocks.pop() if blocks else None
             room = True
-            if self.live + nbytes > self.MAX_LIVE:
-                self._trim_locked(self.live + nbytes - self.MAX_LIVE, doomed)
-                room = self.live + nbytes <= self.MAX_LIVE
-            if room:
-                self.live += nbytes
+            if hit is not None:
+                self.cached -= nbytes
+            else:
+                if self.live + nbytes > self.MAX_LIVE:
+                    self._trim_locked(self.live + nbytes - self.MAX_LIVE, doomed)
+                    room = self.live + nbytes <= self.MAX_LIVE
+                if room:
+                    self.live += nbytes
+        finally:
+            self._leave(doomed)
         self._free_blocks(doomed)
+        if hit is not None:
+            return hit
         if not room:
             self._over_bound(nbytes)
             return None
@@ -499,20 +532,28 @@ class _PinnedPool(object):
     def trim(self, keep=0):
         '''Free idle blocks until at most ``keep`` bytes of them remain.'''
         doomed = []
-        with self.lock:
+        self._enter()
+        try:
             self._trim_locked(self.cached - keep, doomed)
+        finally:
+            self._leave(doomed)
         self._free_blocks(doomed)
 
     def give(self, addr, nbytes):
         doomed = []
-        with self.lock:
+        reentrant = getattr(self._inside, 'n', 0) > 0      # a finalizer running inside take() / trim() of this thread
+        self._enter()
+        try:
             if self.cached + nbytes <= self._cache_bound():
                 self.free.setdefault(nbytes, []).append(addr)
                 self.cached += nbytes
             else:
                 self.live -= nbytes
-                doomed.append(addr)
-        self._free_blocks(doomed)
+                (self.deferred if reentrant else doomed).append(addr)
+        finally:
+            self._leave(doomed)
+        if doomed:
+            self._free_blocks(doomed)
 
     def empty(self, shape, dtype):
         '''``numpy.empty(shape, dtype)``, page-locked when large enough.'''

@@ -1887,6 +1887,8 @@ struct mod16_batch {
     void* dparams = nullptr;            // [max_draws][11] of the data type
     double *par16 = nullptr, *partial = nullptr, *redo = nullptr, *dsse = nullptr, *dcnt = nullptr;
     unsigned *any_gs = nullptr, *any_draw = nullptr, *dflags = nullptr;
+    void* eval_ws = nullptr;            // partial + any_gs of the FAST objective: sized for the draws actually evaluated
+    int64_t eval_draws = 0;             //   (grown on demand; max_draws x blocks x 20 bytes would be GBs for large n)
     void* rows = nullptr;               // [ndraw][n] x up to 3: rows workspace, allocated when first asked for
     size_t rows_bytes = 0;
     void* hparams = nullptr;            // pinned staging
@@ -1907,6 +1909,7 @@ extern "C" int mod16_static_batch_destroy(mod16_batch* b) {
     if (b->skip) (void)hipFree(b->skip);
     if (b->list) (void)hipFree(b->list);
     if (b->ws) (void)hipFree(b->ws);
+    if (b->eval_ws) (void)hipFree(b->eval_ws);
     if (b->rows) (void)hipFree(b->rows);
     if (b->hparams) (void)hipHostFree(b->hparams);
     if (b->hout) (void)hipHostFree(b->hout);
@@ -1955,8 +1958,17 @@ static int batch_bind(mod16_ctx* ctx, const T* const* drivers, const int64_t* ds
         HIPCHK(ctx, hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking));
         const size_t per_arr = (((size_t)n * sizeof(T)) + 255) / 256 * 256;
         for (int k = 0; k < 14; ++k) if (dstride[k]) b->dense_drv |= 1u << k;
+        // device memory that cannot be had is MOD16_ERR_NOMEM, not a HIP error
+        auto dmalloc = [&](void** p, size_t bytes, const char* what) -> int {
+            if (hipMalloc(p, bytes) == hipSuccess) return MOD16_OK;
+            (void)hipGetLastError();
+            *p = nullptr;
+            ctx->err = std::string("mod16_static_batch_bind: device memory for ") + what;
+            return MOD16_ERR_NOMEM;
+        };
+#define MOD16_DMALLOC(p, bytes, what) do { int r_ = dmalloc(reinterpret_cast<void**>(p), bytes, what); if (r_ != MOD16_OK) return r_; } while (0)
         if (where == MOD16_HOST) {
-            HIPCHK(ctx, hipMalloc(&b->owned, per_arr * 16));
+            MOD16_DMALLOC(&b->owned, per_arr * 16, "the resident drivers");
             char* base = static_cast<char*>(b->owned);
             for (int k = 0; k < 14; ++k) {
                 HIPCHK(ctx, hipMemcpyAsync(base + per_arr * k, drivers[k], sizeof(T) * (dstride[k] ? n : 1), hipMemcpyHostToDevice, b->st));
@@ -1978,16 +1990,16 @@ static int batch_bind(mod16_ctx* ctx, const T* const* drivers, const int64_t* ds
         // evaluation workspace
         const int64_t D = max_draws;
         auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+        // (the per-block partials of the FAST objective -- draws x blocks x 20 bytes, 3.2 GB at 4096
+        // draws x 10 M pixels -- are NOT part of this: batch_eval_ws sizes them for the draws an
+        // evaluation actually brings; an EXACT problem never has them)
         const size_t sz_par = al((size_t)D * 11 * sizeof(T)), sz_p16 = al((size_t)D * kPar16 * 8),
-                     sz_part = al((size_t)D * b->gx * 16), sz_any = al((size_t)D * b->gx * 4),
                      sz_d = al((size_t)D * 8), sz_redo = al((size_t)D * 40), sz_u = al((size_t)D * 4);
-        HIPCHK(ctx, hipMalloc(&b->ws, sz_par + sz_p16 + sz_part + sz_any + 2 * sz_d + sz_redo + 2 * sz_u));
+        MOD16_DMALLOC(&b->ws, sz_par + sz_p16 + 2 * sz_d + sz_redo + 2 * sz_u, "the evaluation workspace");
         char* cur = static_cast<char*>(b->ws);
         auto take = [&](size_t x) { char* p = cur; cur += x; return p; };
         b->dparams = take(sz_par);
         b->par16 = reinterpret_cast<double*>(take(sz_p16));
-        b->partial = reinterpret_cast<double*>(take(sz_part));
-        b->any_gs = reinterpret_cast<unsigned*>(take(sz_any));
         b->dsse = reinterpret_cast<double*>(take(sz_d));
         b->dcnt = reinterpret_cast<double*>(take(sz_d));
         b->redo = reinterpret_cast<double*>(take(sz_redo));
@@ -1996,7 +2008,7 @@ static int batch_bind(mod16_ctx* ctx, const T* const* drivers, const int64_t* ds
         HIPCHK(ctx, hipHostMalloc(&b->hparams, (size_t)D * 11 * sizeof(T)));
         HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&b->hout), (size_t)D * 16));
         // the pixels outside the domain of the FAST arithmetic: marked once, listed in ascending order
-        HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&b->skip), (size_t)n));
+        MOD16_DMALLOC(&b->skip, (size_t)n, "the domain mask");
         StaticBatchArgs<T> a = batch_args<T>(b);
         hipLaunchKernelGGL((static_domain_kernel<T>), dim3((unsigned)b->gx), dim3(kBlock), 0, b->st, a, b->skip);
         HIPCHK(ctx, hipGetLastError());
@@ -2007,7 +2019,8 @@ static int batch_bind(mod16_ctx* ctx, const T* const* drivers, const int64_t* ds
         for (int64_t i = 0; i < n; ++i) if (mask[(size_t)i]) list.push_back(i);
         b->nlist = (int64_t)list.size();
         if (b->nlist) {
-            HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&b->list), sizeof(int64_t) * list.size()));
+            MOD16_DMALLOC(&b->list, sizeof(int64_t) * list.size(), "the list of pixels outside the domain");
+#undef MOD16_DMALLOC
             HIPCHK(ctx, hipMemcpy(b->list, list.data(), sizeof(int64_t) * list.size(), hipMemcpyHostToDevice));
         }
         return MOD16_OK;
@@ -2042,6 +2055,36 @@ extern "C" int mod16_static_batch_info(const mod16_batch* b, int64_t* n, int64_t
 }
 
 // the kernels of one objective evaluation (FAST arithmetic), enqueued on b->st
+// The per-block partials and flags of the FAST objective for `ndraw` draws (grown to the next power
+// of two, at most max_draws; a captured graph holds the old addresses: dropped with them).
+static int batch_eval_ws(mod16_batch* b, int64_t ndraw) {
+    if (ndraw <= b->eval_draws) return MOD16_OK;
+    mod16_ctx* ctx = b->ctx;
+    int64_t want = 64;
+    while (want < ndraw) want *= 2;
+    want = std::min(want, b->max_draws);
+    if (b->exec) (void)hipGraphExecDestroy(b->exec);
+    if (b->graph) (void)hipGraphDestroy(b->graph);
+    b->exec = nullptr;
+    b->graph = nullptr;
+    b->graph_ndraw = -1;
+    HIPCHK(ctx, hipStreamSynchronize(b->st));
+    if (b->eval_ws) HIPCHK(ctx, hipFree(b->eval_ws));
+    b->eval_ws = nullptr;
+    b->eval_draws = 0;
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t sz_part = al((size_t)want * b->gx * 16), sz_any = al((size_t)want * b->gx * 4);
+    if (hipMalloc(&b->eval_ws, sz_part + sz_any) != hipSuccess) {
+        (void)hipGetLastError();
+        b->eval_ws = nullptr;
+        return fail(ctx, MOD16_ERR_NOMEM, "mod16_static_batch_objective: device memory for the per-block partials of this many draws");
+    }
+    b->partial = reinterpret_cast<double*>(b->eval_ws);
+    b->any_gs = reinterpret_cast<unsigned*>(static_cast<char*>(b->eval_ws) + sz_part);
+    b->eval_draws = want;
+    return MOD16_OK;
+}
+
 template <typename T>
 static void batch_objective_launches(mod16_batch* b, int64_t ndraw) {
     hipStream_t st = b->st;
@@ -2113,6 +2156,8 @@ static int batch_objective(mod16_batch* b, const T* params, int64_t ndraw, doubl
                                       b->dflags, b->skip, b->flags, b->st, true);
         if (rc != MOD16_OK) return rc;
     } else {
+        int rc = batch_eval_ws(b, ndraw);
+        if (rc != MOD16_OK) return rc;
         if (b->graph_ndraw != ndraw) {          // (re)capture: the kernels' arguments hold the number of draws
             if (b->exec) (void)hipGraphExecDestroy(b->exec);
             if (b->graph) (void)hipGraphDestroy(b->graph);

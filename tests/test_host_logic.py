@@ -222,3 +222,44 @@ def test_summary_is_the_tail_of_the_line():
     bare['roofline'].update(bench.roofline_scalars(bare))
     s = bench.build_summary(bare)
     assert s['c2_us'] is None and s['cycles_per_step'] is None and s['kernel_ms'] == 2.5
+
+
+def test_pinned_pool_bound_per_rank_and_deferred_frees(monkeypatch):
+    """(i) the default bound on page-locked result memory is per PROCESS -- with N ranks
+    on the node (LOCAL_WORLD_SIZE / WORLD_SIZE) each takes 1/N of it, not N times a quarter of the RAM;
+    (ii) a give() that runs from a finalizer while its own thread is inside take() / trim() must not
+    call hipHostFree (which synchronises the device) under the lock: the block is deferred to the
+    lock's holder, who frees it after releasing."""
+    from mod16_amd import _lib
+    monkeypatch.delenv('LOCAL_WORLD_SIZE', raising=False)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    whole = _lib._default_pinned_live()
+    assert (8 << 30) <= whole <= (64 << 30)
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    assert _lib._default_pinned_live() == max(1 << 30, whole // 4)
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')          # the ranks of THIS node count
+    assert _lib._default_pinned_live() == max(1 << 30, whole // 8)
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', 'x')
+    assert _lib._default_pinned_live() == whole
+    pool = _lib._PinnedPool()
+    pool.MAX_LIVE, pool.MAX_CACHED = 4 << 20, 0
+    freed = []
+
+    def free_blocks(doomed):
+        assert getattr(pool._inside, 'n', 0) == 0        # never under the lock
+        freed.extend(doomed)
+    monkeypatch.setattr(pool, '_free_blocks', free_blocks)
+    pool.live = 3 << 20
+    pool.give(111, 1 << 20)                              # nothing recent, MAX_CACHED = 0: freed at once, lock released
+    assert freed == [111] and pool.live == 2 << 20
+    # the re-entrant case: a finalizer fires while this thread is inside the lock
+    doomed = []
+    pool._enter()
+    pool.give(222, 1 << 20)
+    assert freed == [111] and pool.deferred == [222]     # not freed under the lock
+    pool._leave(doomed)
+    assert doomed == [222] and pool.deferred == [] and pool.live == 1 << 20
+    # ... and trim() / take() hand the deferred blocks to _free_blocks on their way out
+    pool.deferred.append(333)
+    pool.trim()
+    assert freed == [111, 333]
