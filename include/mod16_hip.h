@@ -118,7 +118,7 @@ enum mod16_where { MOD16_HOST = 0, MOD16_DEVICE = 1 };
  * NaN-masked rasters): the totals form of the production pipeline (dense class raster,
  * outputs day + night; mod16_et_*, mod16_et_diag_*, mod16_et_tiled_*, their graphs) then runs
  * the instance without the domain test and without the dispatch that revisits flagged pixels
- * (-2.6 % kernel time on the float64 global grid, -3 % MIXED). A pixel outside the domain then
+ * (-1.6 % kernel time on the float64 global grid, -2.3 % MIXED: tools/guardcost.py, round 5). A pixel outside the domain then
  * gets whatever the rearranged arithmetic gives. Other forms and shapes ignore the flag. */
 #define MOD16_DOMAIN_TRUSTED 4u
 

@@ -1339,10 +1339,9 @@ static int method_entry(mod16_ctx* ctx, int method, const T* const* in, const in
             if (ctx->slab[s]) HIPCHK(ctx, hipFree(ctx->slab[s]));
             ctx->slab[s] = nullptr;
         }
-        ctx->slab_bytes = 0;
-        for (int s = 0; s < kSlots; ++s) HIPCHK(ctx, hipMalloc(&ctx->slab[s], need));
         ctx->slab_bytes = need;
     }
+    if (!ctx->slab[0]) HIPCHK(ctx, hipMalloc(&ctx->slab[0], ctx->slab_bytes));      // (this mode uses one slot)
     if (!ctx->streams[0]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking));
     hipStream_t st = ctx->streams[0];
     T hs[32];
@@ -1498,8 +1497,14 @@ static int raw_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* raw,
         return MOD16_OK;
     }
     if (where != MOD16_HOST) return fail(ctx, MOD16_ERR_ARG, "mod16_et_raw: bad `where`");
-    // HOST: one slab, tile by tile
+    // HOST: tiles of kTilePixels staged through the context's slabs, one host thread and one stream
+    // per slot, as run_host does for the processed drivers (round 5; one slab and one thread before:
+    // the copies from pageable memory, which the runtime stages on the calling thread, are what bounds
+    // this mode, and the light input form -- 58 bytes per pixel in float32 -- is the one worth feeding
+    // at the link's rate)
     const int64_t tile = std::min<int64_t>(n, kTilePixels);
+    const int64_t ntiles = (n + tile - 1) / tile;
+    const int nslots = (int)std::min<int64_t>(ntiles, ctx->host_threads);
     const size_t per_arr = (((size_t)tile * sizeof(T)) + 255) / 256 * 256 + kStagger;
     const size_t need = per_arr * (14 + 1 + 3) + 3 * ((size_t)tile + 256) + 256;
     if (ctx->slab_bytes < need) {
@@ -1507,22 +1512,27 @@ static int raw_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* raw,
             if (ctx->slab[s]) HIPCHK(ctx, hipFree(ctx->slab[s]));
             ctx->slab[s] = nullptr;
         }
-        ctx->slab_bytes = 0;
-        for (int s = 0; s < kSlots; ++s) HIPCHK(ctx, hipMalloc(&ctx->slab[s], need));
         ctx->slab_bytes = need;
     }
-    if (!ctx->streams[0]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking));
-    hipStream_t st = ctx->streams[0];
+    for (int s = 0; s < nslots; ++s) {
+        if (!ctx->slab[s]) HIPCHK(ctx, hipMalloc(&ctx->slab[s], ctx->slab_bytes));
+        if (!ctx->streams[s]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->streams[s], hipStreamNonBlocking));
+    }
     T hs[16];
     for (int k = 0; k < 14; ++k) hs[k] = ((a.dense_drv >> k) & 1u) ? T(0) : a.drv[k][0];
     hs[14] = (a.day_hours && !a.dense_hours) ? a.day_hours[0] : T(0);
     HIPCHK(ctx, hipMemcpy(ctx->scalars, hs, sizeof(T) * 15, hipMemcpyHostToDevice));
     const T* dscal = static_cast<const T*>(ctx->scalars);
-    char* base = static_cast<char*>(ctx->slab[0]);
-    uint8_t* bytes = reinterpret_cast<uint8_t*>(base + per_arr * 18);
     const size_t per_b = ((size_t)tile + 255) / 256 * 256;
-    for (int64_t off = 0; off < n; off += tile) {
-        const int64_t m = std::min(tile, n - off);
+    {   // the kernels' shared workspace at its final size before any thread launches
+        const int64_t npiece = (tile / VecOf<T>::v + 63) / 64;
+        int rc = reserve_diag(ctx, npiece / 2 + 2048);
+        if (rc != MOD16_OK) return rc;
+    }
+    auto stage = [&](int slot, int64_t off, int64_t m) -> int {
+        hipStream_t st = ctx->streams[slot];
+        char* base = static_cast<char*>(ctx->slab[slot]);
+        uint8_t* bytes = reinterpret_cast<uint8_t*>(base + per_arr * 18);
         RawArgs<T> d = a;
         d.n = m;
         for (int k = 0; k < 14; ++k) {
@@ -1552,15 +1562,35 @@ static int raw_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* raw,
         }
         for (int k = 0; k < 3; ++k) d.out[k] = a.out[k] ? reinterpret_cast<T*>(base + per_arr * (15 + k)) : nullptr;
         {
+            std::lock_guard<std::mutex> lock(ctx->launch_mu);      // (the launches share the context's workspace)
             int rc = launch(d, st, (a.day_hours && !a.dense_hours) ? &hs[14] : nullptr);
             if (rc != MOD16_OK) return rc;
+            HIPCHK(ctx, hipGetLastError());
         }
-        HIPCHK(ctx, hipGetLastError());
         for (int k = 0; k < 3; ++k)
             if (a.out[k]) HIPCHK(ctx, hipMemcpyAsync(a.out[k] + off, d.out[k], sizeof(T) * m, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
+        HIPCHK(ctx, hipStreamSynchronize(st));      // the slab of this slot is free again
+        return MOD16_OK;
+    };
+    if (nslots == 1) {
+        for (int64_t off = 0; off < n; off += tile) {
+            int rc = stage(0, off, std::min(tile, n - off));
+            if (rc != MOD16_OK) return rc;
+        }
+    } else {
+        int rcs[kSlots] = {};
+        std::vector<std::thread> workers;
+        for (int s = 0; s < nslots; ++s)
+            workers.emplace_back([&, s]() {
+                if (hipSetDevice(ctx->device) != hipSuccess) { rcs[s] = MOD16_ERR_HIP; return; }
+                for (int64_t t = s; t < ntiles && rcs[s] == MOD16_OK; t += nslots)
+                    rcs[s] = stage(s, t * tile, std::min(tile, n - t * tile));
+            });
+        for (auto& w : workers) w.join();
+        for (int s = 0; s < nslots; ++s)
+            if (rcs[s] != MOD16_OK) return rcs[s];
     }
-    return read_status(ctx, st);
+    return read_status(ctx, ctx->streams[0]);
 }
 
 extern "C" int mod16_et_raw_f64(mod16_ctx* ctx, const uint8_t* cls, const double* const* raw,

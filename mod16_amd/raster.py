@@ -165,7 +165,8 @@ class RasterEngine(object):
         the domain of the production arithmetic (quality-controlled or NaN-masked
         rasters; the bounds are in ``include/mod16_hip.h``) -- the totals form then
         runs without the domain test and without the dispatch that revisits flagged
-        pixels (-1.9 % kernel time on the float64 global grid, round 4). Default: False, the
+        pixels (-1.6 % kernel time on the float64 global grid, -2.3 % MIXED: tools/guardcost.py, round 5).
+        Default: False, the
         arithmetic that returns the reference's result on every input.
     '''
 

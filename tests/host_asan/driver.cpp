@@ -217,6 +217,32 @@ static void host_cases(mod16_ctx* ctx, const char* what) {
         double folded[8];
         EXPECT(mod16_fold_diag_host(tile_diag.data(), (int64_t)tile_diag.size() / 8, folded) == MOD16_OK);
     }
+    // raw drivers through the same staging (threads and slots since round 5), hours dense / scalar / absent
+    for (int64_t n : {(int64_t)7, (int64_t)2 * tile + 4321}) {
+        std::vector<std::vector<T>> raw(14, std::vector<T>(n, T(280)));
+        std::vector<uint8_t> cls(n, 1), fpar(n, 50), lai(n, 20);
+        std::vector<T> day(n), night(n), total(n), hours(n, T(12));
+        const T* rp[14];
+        int64_t rs[14];
+        for (int k = 0; k < 14; ++k) { rp[k] = raw[k].data(); rs[k] = 1; }
+        T elev = T(350);
+        rp[13] = &elev; rs[13] = 0;
+        if (sizeof(T) == 8) {
+            auto R = reinterpret_cast<const double* const*>(rp);
+            OK(mod16_et_raw_f64(ctx, cls.data(), R, rs, fpar.data(), lai.data(), reinterpret_cast<const double*>(hours.data()), 1, n,
+                                reinterpret_cast<double*>(day.data()), reinterpret_cast<double*>(night.data()), reinterpret_cast<double*>(total.data()), MOD16_MATH_FAST, MOD16_HOST, nullptr));
+            OK(mod16_et_raw_f64(ctx, cls.data(), R, rs, fpar.data(), lai.data(), reinterpret_cast<const double*>(hours.data()), 0, n,
+                                reinterpret_cast<double*>(day.data()), reinterpret_cast<double*>(night.data()), reinterpret_cast<double*>(total.data()), MOD16_MATH_FAST, MOD16_HOST, nullptr));
+            OK(mod16_et_raw_f64(ctx, cls.data(), R, rs, fpar.data(), lai.data(), nullptr, 0, n,
+                                reinterpret_cast<double*>(day.data()), reinterpret_cast<double*>(night.data()), nullptr, MOD16_MATH_EXACT, MOD16_HOST, nullptr));
+        } else {
+            auto R = reinterpret_cast<const float* const*>(rp);
+            OK(mod16_et_raw_f32(ctx, cls.data(), R, rs, fpar.data(), lai.data(), reinterpret_cast<const float*>(hours.data()), 1, n,
+                                reinterpret_cast<float*>(day.data()), reinterpret_cast<float*>(night.data()), reinterpret_cast<float*>(total.data()), MOD16_MATH_MIXED, MOD16_HOST, nullptr));
+            OK(mod16_et_raw_f32(ctx, cls.data(), R, rs, fpar.data(), lai.data(), nullptr, 0, n,
+                                reinterpret_cast<float*>(day.data()), reinterpret_cast<float*>(night.data()), nullptr, MOD16_MATH_FAST, MOD16_HOST, nullptr));
+        }
+    }
     double x[8];
     EXPECT(mod16_fold_diag_host(nullptr, 1, x) == MOD16_ERR_ARG);
     EXPECT(mod16_fold_diag_host(x, 0, x) == MOD16_ERR_ARG);
