@@ -720,7 +720,9 @@ def main():
                 if bplut is None and not args.no_parity:
                     from oracle import mod16_oracle as oracle
                     bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
-                devs = [0] * world if rehearsal else list(range(world))
+                # (a launcher may show a rank its own GPU only: then the leg runs on what this rank sees)
+                visible = torch.cuda.device_count()
+                devs = [0] * world if rehearsal else [local_rank] if visible < world else list(range(world))
                 host_call = numpy_in_numpy_out(np, torch, eng, table, devs, bplut)
             except Exception as exc:        # noqa: BLE001 -- recorded in the line
                 host_call = {'error': '%s: %s' % (type(exc).__name__, str(exc)[:300])}
@@ -898,7 +900,7 @@ def numpy_in_numpy_out(np, torch, eng, table, devices, bplut, tiles_per_device=1
         t0 = time.perf_counter()
         res = call(n, devices)
         best = min(best, time.perf_counter() - t0)
-    out = {'pixels': n, 'n_devices': len(devices), 'devices': list(devices), 'seconds': best,
+    out = {'pixels': n, 'n_devices': len(devices), 'devices': list(devices), 'visible_devices': torch.cuda.device_count(), 'seconds': best,
            'pixels_per_s': n / best, 'pcie_GBps_both_directions': 129.0 * n / best / 1e9,
            'diagnostics': [float(v) for v in res[2]],
            'note': 'mod16_amd.evapotranspiration_raster(table, cls, *drivers, devices=range(N), diagnostics=True) '
