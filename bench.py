@@ -722,7 +722,7 @@ def main():
                     bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
                 # (a launcher may show a rank its own GPU only: then the leg runs on what this rank sees)
                 visible = torch.cuda.device_count()
-                devs = [0] * world if rehearsal else [local_rank] if visible < world else list(range(world))
+                devs = [0] * world if rehearsal else [torch.cuda.current_device()] if visible < world else list(range(world))
                 host_call = numpy_in_numpy_out(np, torch, eng, table, devs, bplut)
             except Exception as exc:        # noqa: BLE001 -- recorded in the line
                 host_call = {'error': '%s: %s' % (type(exc).__name__, str(exc)[:300])}
