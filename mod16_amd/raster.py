@@ -196,7 +196,10 @@ class RasterEngine(object):
         the two kernels got in each other's way -- with one tiny dispatch between the wait and the
         kernel 38.5 ms, the sum of the two kernels alone (19.4 + 19.9 ms: both are bound by the same
         HBM). Round 3's launch sequence had such a dispatch by accident (the memset of the ticket
-        counter, gone since the kernel resets it itself).'''
+        counter, gone since the kernel resets it itself). Round 5, wall clock and kernel trace of both
+        (``tools/gate_probe.py``, ``profiles/r05_gate_probe.json``): 39.4 ms per step with the gate = the sum
+        of the kernels alone (39.2), 46.3 without; ``bench.py`` reports the ratio of every run
+        (``configs.c4_series_float64.step_over_sum_of_kernels``, 1.004).'''
         torch = _torch()
         if getattr(self, '_gate_word', None) is None:
             self._gate_word = torch.zeros(64, dtype=torch.float32, device=self._dev())
