@@ -9,9 +9,6 @@ The loud one: every run's diagnostics partial carries the launch's serial number
 behind the pipeline kernel counts the runs that carry it (kStatusIncomplete); a launch whose ticket
 counter was poisoned (fault injection of the experiments build) is reported by check(), guarded
 and trusted, and the launch after it is whole again."""
-import os
-
-import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
