@@ -114,6 +114,13 @@ def test_no_kernel_spills_vector_registers(tmp_path):
     assert len(kernels) > 50
     spilling = [name for name, count in kernels if int(count) > 0]
     assert not spilling, spilling
+    # the pipeline kernel hides HBM latency behind a second wave per SIMD: every instance must fit two
+    # (unified register file of 512 per lane: at most 256 each, accumulator registers included) -- round 5's
+    # raw-driver instances with per-pixel hours had grown to 258 / 260, i.e. ONE wave
+    regs = re.findall(r'\.name:\s+(\S*et_stream_kernel\S*)\n(?:.*\n){0,14}?\s*\.vgpr_count:\s*(\d+)', text)
+    assert len(regs) >= 40, len(regs)
+    fat = [(name, int(count)) for name, count in regs if int(count) > 256]
+    assert not fat, fat
     # ... and none may touch scratch memory or park registers in the accumulator file
     # (how hipcc spilled that kernel: 183 v_accvgpr_write / 263 v_accvgpr_read, no
     # scratch): the stream kernels count their own vector-memory operations
