@@ -855,6 +855,7 @@ def build_summary(line):
         'ingest_gpx_s': _dig(line, 'ingest', 'pixels_per_s') / 1e9 if _dig(line, 'ingest', 'pixels_per_s') else None,
         'ingest_h2d_GBps': _dig(line, 'ingest', 'h2d_GBps'),
         'host_call_gpx_s': host['pixels_per_s'] / 1e9 if host.get('pixels_per_s') else None,
+        'host_call_pinned_gpx_s': _dig(host, 'pinned_drivers', 'pixels_per_s') / 1e9 if _dig(host, 'pinned_drivers', 'pixels_per_s') else None,
         'host_call_devices': host.get('n_devices'), 'host_call_one_device_gpx_s':
             host['one_device_pixels_per_s'] / 1e9 if host.get('one_device_pixels_per_s') else None,
         'host_call_bits_equal_one_device': host.get('bits_equal_one_device'), 'host_call_error': host.get('error'),
@@ -905,6 +906,26 @@ def numpy_in_numpy_out(np, torch, eng, table, devices, bplut, tiles_per_device=1
            'diagnostics': [float(v) for v in res[2]],
            'note': 'mod16_amd.evapotranspiration_raster(table, cls, *drivers, devices=range(N), diagnostics=True) '
                    'on host float64 arrays, %d staging tiles of %d pixels per device; best of 2 calls' % (tiles_per_device, tile)}
+    # the same call with the drivers in page-locked memory (mod16_amd.pinned_empty): the host-to-device
+    # copies are pure DMA, no staging copy on the host's threads -- what keeps eight links fed
+    try:
+        p_cls = mod16_amd.pinned_empty(n, np.uint8)
+        p_drv = [mod16_amd.pinned_empty(n, np.float64) for _ in range(14)]
+        p_cls[:] = h_cls
+        for a, b in zip(p_drv, h_drv):
+            a[:] = b
+        pinned_call = lambda: mod16_amd.evapotranspiration_raster(table, p_cls, *p_drv, devices=devices, diagnostics=True)
+        pinned_call()
+        t0 = time.perf_counter()
+        pres = pinned_call()
+        dt = time.perf_counter() - t0
+        out['pinned_drivers'] = {'pixels_per_s': n / dt, 'seconds': dt,
+                                 'bits_equal_pageable_call': bool(np.array_equal(pres[0], res[0], equal_nan=True)
+                                                                  and np.array_equal(pres[2], res[2])),
+                                 'page_locked': bool(p_drv[0].base is not None)}
+        del pres, p_cls, p_drv
+    except Exception as exc:        # noqa: BLE001 -- recorded
+        out['pinned_drivers'] = {'error': '%s: %s' % (type(exc).__name__, str(exc)[:200])}
     if len(devices) > 1:
         call(2 * tile, devices[:1])
         t0 = time.perf_counter()

@@ -8,5 +8,5 @@ from mod16_amd import (          # noqa: F401  (names a star import leaves out o
     MOD16, PFT_VALID, STEFAN_BOLTZMANN, SPECIFIC_HEAT_CAPACITY_AIR, MOL_WEIGHT_WET_DRY_RATIO_AIR,
     TEMP_LAPSE_RATE, GRAV_ACCEL, GAS_LAW_CONST, AIR_MOL_WEIGHT, STD_TEMP_K, STD_PRESSURE_PASCALS,
     AIR_PRESSURE_RATE, latent_heat_vaporization, psychrometric_constant, radiation_net, svp,
-    svp_slope, evapotranspiration_raster, evapotranspiration_raw, __version__)
+    svp_slope, evapotranspiration_raster, evapotranspiration_raw, pinned_empty, __version__)
 from . import utils, models      # noqa: F401,E402

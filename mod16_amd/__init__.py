@@ -53,6 +53,20 @@ DRIVER_NAMES = (
     'pressure', 'fpar', 'lai')
 
 
+def pinned_empty(shape, dtype=np.float64):
+    '''(Extension.) ``numpy.empty(shape, dtype)`` in page-locked host memory -- for DRIVER arrays
+    that are filled once and handed to the numpy entry points again and again (a time loop, a
+    raster read from disk into it). A host-to-device copy from ordinary (pageable) numpy memory
+    goes through the HIP runtime's own staging buffers on the calling threads: a CPU copy per
+    byte, 13-17 GB/s per thread, which the HOST mode hides behind eight threads per GPU -- but
+    with ``devices=range(8)`` that is 64 threads copying at once and the host's memory, not the
+    eight PCIe links, becomes the bound. From page-locked memory the copy is pure DMA. The
+    arrays come from the same bounded pool as the results (``_lib.pinned``; beyond its bound, or
+    without a GPU runtime, an ordinary array comes back) and are ordinary numpy arrays to
+    everything else.'''
+    return _lib.pinned.empty(tuple(np.atleast_1d(shape)) if not isinstance(shape, tuple) else shape, np.dtype(dtype))
+
+
 def _result_dtype(values):
     '''float32 only if every array-like input is float32 (numpy's own rule
     for the reference code); Python scalars are weak.'''

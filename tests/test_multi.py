@@ -158,6 +158,28 @@ def test_two_contexts_on_one_gpu_give_the_bits_of_one(table, dtype):
 
 
 @pytest.mark.gpu
+def test_page_locked_driver_arrays(table):
+    """mod16_amd.pinned_empty: driver arrays in page-locked memory (pure-DMA uploads) are ordinary
+    numpy arrays to the call -- same results, single device and sharded; small ones are plain arrays."""
+    import mod16_amd
+    from mod16_amd import multi
+    n = multi.host_tile() + 999
+    cls, drv = synth.drivers((n,), seed=77)
+    want = mod16_amd.evapotranspiration_raster(table, cls, *drv)
+    p_drv = [mod16_amd.pinned_empty(n) for _ in range(14)]
+    p_cls = mod16_amd.pinned_empty((n,), np.uint8)
+    assert all(a.base is not None and a.flags.c_contiguous and a.flags.writeable for a in p_drv)
+    p_cls[:] = cls
+    for a, b in zip(p_drv, drv):
+        a[:] = b
+    for devices in (None, [0, 0]):
+        got = mod16_amd.evapotranspiration_raster(table, p_cls, *p_drv, devices=devices)
+        assert same(got[0], want[0]) and same(got[1], want[1])
+    small = mod16_amd.pinned_empty((10, 3), np.float32)
+    assert small.shape == (10, 3) and small.dtype == np.float32 and small.base is None
+
+
+@pytest.mark.gpu
 def test_sharded_components_pet_and_per_pixel_parameters(table):
     """The other shapes of the call through the shards: separate=True, pet=True, the class
     surface with per-pixel parameter arrays (MOD16(params, devices=...)), a 2-D raster, and a
