@@ -321,6 +321,12 @@ def test_rasters_on_disk(m16, tmp_path):
     assert np.array_equal(np.load(str(tmp_path / 'day.npy')), want_d, equal_nan=True)
     assert np.array_equal(np.load(str(tmp_path / 'night.npy')), want_n, equal_nan=True)
     assert day.shape == (1500, 1700) and isinstance(day, np.memmap)
+    # ... and dealt over two contexts of the GPU (mod16_amd.multi): memory-mapped inputs and outputs
+    # shared by the shards, the same bytes in the files
+    m16io.evapotranspiration_npy(f['table'], str(tmp_path / 'cls.npy'), paths, str(tmp_path / 'day2.npy'),
+                                 str(tmp_path / 'night2.npy'), devices=[0, 0])
+    assert np.array_equal(np.load(str(tmp_path / 'day2.npy')), want_d, equal_nan=True)
+    assert np.array_equal(np.load(str(tmp_path / 'night2.npy')), want_n, equal_nan=True)
     with pytest.raises(KeyError):
         m16io.evapotranspiration_npy(f['table'], str(tmp_path / 'cls.npy'), {'lai': paths['lai']},
                                      str(tmp_path / 'd2.npy'), str(tmp_path / 'n2.npy'))
