@@ -988,6 +988,9 @@ def other_configs(args, torch, np, _lib, RasterEngine, table, bplut):
             c2['parity'] = {'max_rel_err_vs_oracle': max(errs), 'masks_equal': masks, 'pixels': m}
         del r
     c2['target_us_survey'] = 33.0
+    c2['note'] = ('*_us_per_launch = the launch PERIOD of 200 back-to-back direct launches (HIP events); the kernel itself takes '
+                  'about 5.5 us less -- the constant dispatch + completion gap between two launches on a stream '
+                  '(profiles/r05_c2_kernel_vs_launch_gap.json: kernel 38-39 us with diagnostics, 35.6 without)')
     out['c2_1200x1200_float64'] = c2
     torch.cuda.empty_cache()
 
