@@ -75,6 +75,7 @@ struct mod16_ctx {
     hipEvent_t ws_event = nullptr;   // recorded behind the last launch that produced diagnostics in `ws`
     hipStream_t ws_stream = nullptr; // ... and the stream it ran on
     bool ws_pending = false;
+    bool ws_recorded = false;        // ... and whether ws_event has been recorded behind it yet (ws_publish)
     double* diag_dev = nullptr;      // device [kDiag]
     double* diag_host = nullptr;     // pinned [kDiag]
     double* hdiag_dev = nullptr;     // device [kSlots][kDiag]: per-tile diagnostics of the HOST mode (mod16_et_hdiag_*)
@@ -413,15 +414,38 @@ static int ws_acquire(mod16_ctx* ctx, hipStream_t st) {
     if (st && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
         return fail(ctx, MOD16_ERR_ARG, "the stream is being captured into a graph: use mod16_graph_et_diag_* / "
                                         "mod16_graph_et_tiled_* (they capture the step with a workspace of its own)");
-    if (ctx->ws_pending && st != ctx->ws_stream)
-        HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ws_event, 0));
+    // The event behind the previous launch is recorded only NOW, when a launch on another stream
+    // needs it (round 5): recorded behind every launch it put a marker packet between any two
+    // launches of a stream -- part of the 5.5 us that lie between two 1200 x 1200 launches. Recorded
+    // late it also covers whatever else the caller has queued on that stream since: more than
+    // needed, never less. A stream that is gone by now (destroyed by its owner) cannot be recorded
+    // on: the device is waited for instead.
+    if (ctx->ws_pending && st != ctx->ws_stream) {
+        if (ctx->ws_recorded || hipEventRecord(ctx->ws_event, ctx->ws_stream) == hipSuccess) {
+            HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ws_event, 0));
+        } else {
+            (void)hipGetLastError();
+            HIPCHK(ctx, hipDeviceSynchronize());
+        }
+        ctx->ws_pending = false;
+    }
     return MOD16_OK;
 }
 static int ws_release(mod16_ctx* ctx, hipStream_t st) {
     if (ctx->force_ws) return MOD16_OK;
-    HIPCHK(ctx, hipEventRecord(ctx->ws_event, st));
     ctx->ws_stream = st;
     ctx->ws_pending = true;
+    ctx->ws_recorded = false;
+    return MOD16_OK;
+}
+// The HOST-mode tilers launch their tiles on one stream per slot and queue the tile's copies back
+// right behind the launch: they record the event at once (under launch_mu, behind the launch and
+// in front of the copies), so that the next slot's launch waits for this tile's KERNELS only and
+// the copies of one tile keep running under the kernels of the next.
+static int ws_publish(mod16_ctx* ctx) {
+    if (ctx->force_ws || !ctx->ws_pending || ctx->ws_recorded) return MOD16_OK;
+    HIPCHK(ctx, hipEventRecord(ctx->ws_event, ctx->ws_stream));
+    ctx->ws_recorded = true;
     return MOD16_OK;
 }
 
@@ -818,6 +842,8 @@ static int stage_tile(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags, const 
     {
         std::lock_guard<std::mutex> lock(ctx->launch_mu);
         int rc = launch_et<T>(ctx, d, flags, st, dd);
+        if (rc != MOD16_OK) return rc;
+        rc = ws_publish(ctx);
         if (rc != MOD16_OK) return rc;
     }
     for (int k = 0; k < 10; ++k)
@@ -1566,6 +1592,8 @@ static int raw_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* raw,
             int rc = launch(d, st, (a.day_hours && !a.dense_hours) ? &hs[14] : nullptr);
             if (rc != MOD16_OK) return rc;
             HIPCHK(ctx, hipGetLastError());
+            rc = ws_publish(ctx);
+            if (rc != MOD16_OK) return rc;
         }
         for (int k = 0; k < 3; ++k)
             if (a.out[k]) HIPCHK(ctx, hipMemcpyAsync(a.out[k] + off, d.out[k], sizeof(T) * m, hipMemcpyDeviceToHost, st));

@@ -363,6 +363,7 @@ hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = reinterpret
 hipError_t hipStreamCreate(hipStream_t* s) { return hipStreamCreateWithFlags(s, 0); }
 hipError_t hipStreamDestroy(hipStream_t s) { delete reinterpret_cast<int*>(s); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static thread_local bool t_capturing = false;
 hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) {

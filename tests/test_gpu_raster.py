@@ -1007,3 +1007,33 @@ def test_series_from_host_in_the_light_input_form(env, math):
         else:
             with np.errstate(over='ignore'):
                 assert_parity(got.cpu().numpy(), w.astype(np.float32), 1e-6, 'raw series')
+
+
+def test_a_launch_behind_one_on_a_stream_that_is_gone(env):
+    """The event that orders two launches on DIFFERENT streams (they share the context's
+    workspace) is recorded when the second launch needs it -- on the first launch's stream. A
+    stream its owner has destroyed in between cannot be recorded on: the library waits for the
+    device instead of failing (ws_acquire, mod16_capi.hip)."""
+    import ctypes
+    torch, RasterEngine, table = env
+    eng = RasterEngine(table)
+    n = 1200 * 1200
+    cls, drv, day, night = eng.alloc_raster(n)
+    eng.synth(n, seed=8, out=(cls, drv))
+    hip = ctypes.CDLL('libamdhip64.so')
+    raw = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(raw)) == 0
+    torch.cuda.synchronize()
+    vecs = [torch.zeros(8, dtype=torch.float64, device='cuda') for _ in range(3)]
+    gone = torch.cuda.ExternalStream(raw.value)
+    with torch.cuda.stream(gone):
+        eng.run(cls, drv, day, night, diag=vecs[0])
+    gone.synchronize()
+    del gone
+    assert hip.hipStreamDestroy(raw) == 0
+    eng.run(cls, drv, day, night, diag=vecs[1])      # the current stream: behind a launch on `raw`
+    eng.run(cls, drv, day, night, diag=vecs[2])
+    torch.cuda.synchronize()
+    eng.check()
+    assert float(vecs[0][2]) > 0
+    assert torch.equal(vecs[0], vecs[1]) and torch.equal(vecs[0], vecs[2])
