@@ -75,7 +75,9 @@ struct mod16_ctx {
     hipEvent_t ws_event = nullptr;   // recorded behind the last launch that produced diagnostics in `ws`
     hipStream_t ws_stream = nullptr; // ... and the stream it ran on
     bool ws_pending = false;
-    bool ws_recorded = false;        // ... and whether ws_event has been recorded behind it yet (ws_publish)
+    bool ws_recorded = false;        // ... and whether ws_event was recorded behind it
+    bool ws_multi = false;           // the context has launched on more than one stream (or runs HOST tiles on
+                                     // its slots): every launch records ws_event from now on
     double* diag_dev = nullptr;      // device [kDiag]
     double* diag_host = nullptr;     // pinned [kDiag]
     double* hdiag_dev = nullptr;     // device [kSlots][kDiag]: per-tile diagnostics of the HOST mode (mod16_et_hdiag_*)
@@ -414,38 +416,29 @@ static int ws_acquire(mod16_ctx* ctx, hipStream_t st) {
     if (st && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
         return fail(ctx, MOD16_ERR_ARG, "the stream is being captured into a graph: use mod16_graph_et_diag_* / "
                                         "mod16_graph_et_tiled_* (they capture the step with a workspace of its own)");
-    // The event behind the previous launch is recorded only NOW, when a launch on another stream
-    // needs it (round 5): recorded behind every launch it put a marker packet between any two
-    // launches of a stream -- part of the 5.5 us that lie between two 1200 x 1200 launches. Recorded
-    // late it also covers whatever else the caller has queued on that stream since: more than
-    // needed, never less. A stream that is gone by now (destroyed by its owner) cannot be recorded
-    // on: the device is waited for instead.
+    // Ordering across streams costs a marker packet behind EVERY launch (the event) -- part of the
+    // 5.5 us that lie between two 1200 x 1200 launches on one stream -- so a context pays for it
+    // only once it has seen a second stream (round 5): until then nothing is recorded; the first
+    // launch that arrives on another stream waits for the DEVICE (once per context: the earlier
+    // stream may be gone by now -- its owner may destroy it, and an event cannot be recorded on a
+    // destroyed stream), and from then on every launch leaves its event behind (ws_release).
     if (ctx->ws_pending && st != ctx->ws_stream) {
-        if (ctx->ws_recorded || hipEventRecord(ctx->ws_event, ctx->ws_stream) == hipSuccess) {
-            HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ws_event, 0));
-        } else {
-            (void)hipGetLastError();
-            HIPCHK(ctx, hipDeviceSynchronize());
-        }
+        if (ctx->ws_recorded) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ws_event, 0));
+        else HIPCHK(ctx, hipDeviceSynchronize());
+        ctx->ws_multi = true;
         ctx->ws_pending = false;
     }
     return MOD16_OK;
 }
 static int ws_release(mod16_ctx* ctx, hipStream_t st) {
     if (ctx->force_ws) return MOD16_OK;
+    ctx->ws_recorded = false;
+    if (ctx->ws_multi) {
+        HIPCHK(ctx, hipEventRecord(ctx->ws_event, st));
+        ctx->ws_recorded = true;
+    }
     ctx->ws_stream = st;
     ctx->ws_pending = true;
-    ctx->ws_recorded = false;
-    return MOD16_OK;
-}
-// The HOST-mode tilers launch their tiles on one stream per slot and queue the tile's copies back
-// right behind the launch: they record the event at once (under launch_mu, behind the launch and
-// in front of the copies), so that the next slot's launch waits for this tile's KERNELS only and
-// the copies of one tile keep running under the kernels of the next.
-static int ws_publish(mod16_ctx* ctx) {
-    if (ctx->force_ws || !ctx->ws_pending || ctx->ws_recorded) return MOD16_OK;
-    HIPCHK(ctx, hipEventRecord(ctx->ws_event, ctx->ws_stream));
-    ctx->ws_recorded = true;
     return MOD16_OK;
 }
 
@@ -843,8 +836,6 @@ static int stage_tile(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags, const 
         std::lock_guard<std::mutex> lock(ctx->launch_mu);
         int rc = launch_et<T>(ctx, d, flags, st, dd);
         if (rc != MOD16_OK) return rc;
-        rc = ws_publish(ctx);
-        if (rc != MOD16_OK) return rc;
     }
     for (int k = 0; k < 10; ++k)
         if (h.out[k]) HIPCHK(ctx, hipMemcpyAsync(h.out[k] + off, d.out[k], sizeof(T) * m, hipMemcpyDeviceToHost, st));
@@ -860,6 +851,7 @@ static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags, double* 
     const int64_t tile = std::min<int64_t>(n, kTilePixels);
     const int64_t ntiles = (n + tile - 1) / tile;
     const int nslots = (int)std::min<int64_t>(ntiles, ctx->host_threads);
+    if (nslots > 1) ctx->ws_multi = true;       // one stream per slot: the launches leave their events (ws_release)
     // slab layout per slot: 14 drivers | 11 params | 10 outputs (T each) | class bytes
     // successive staged arrays are kStagger bytes apart on top of their size
     const size_t per_arr = (((size_t)tile * sizeof(T)) + 255) / 256 * 256 + kStagger;
@@ -1531,6 +1523,7 @@ static int raw_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* raw,
     const int64_t tile = std::min<int64_t>(n, kTilePixels);
     const int64_t ntiles = (n + tile - 1) / tile;
     const int nslots = (int)std::min<int64_t>(ntiles, ctx->host_threads);
+    if (nslots > 1) ctx->ws_multi = true;       // one stream per slot: the launches leave their events (ws_release)
     const size_t per_arr = (((size_t)tile * sizeof(T)) + 255) / 256 * 256 + kStagger;
     const size_t need = per_arr * (14 + 1 + 3) + 3 * ((size_t)tile + 256) + 256;
     if (ctx->slab_bytes < need) {
@@ -1592,8 +1585,6 @@ static int raw_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* raw,
             int rc = launch(d, st, (a.day_hours && !a.dense_hours) ? &hs[14] : nullptr);
             if (rc != MOD16_OK) return rc;
             HIPCHK(ctx, hipGetLastError());
-            rc = ws_publish(ctx);
-            if (rc != MOD16_OK) return rc;
         }
         for (int k = 0; k < 3; ++k)
             if (a.out[k]) HIPCHK(ctx, hipMemcpyAsync(a.out[k] + off, d.out[k], sizeof(T) * m, hipMemcpyDeviceToHost, st));

@@ -1010,30 +1010,38 @@ def test_series_from_host_in_the_light_input_form(env, math):
 
 
 def test_a_launch_behind_one_on_a_stream_that_is_gone(env):
-    """The event that orders two launches on DIFFERENT streams (they share the context's
-    workspace) is recorded when the second launch needs it -- on the first launch's stream. A
-    stream its owner has destroyed in between cannot be recorded on: the library waits for the
-    device instead of failing (ws_acquire, mod16_capi.hip)."""
+    """Launches on DIFFERENT streams share the context's workspace and are ordered by the
+    library. A context that has only ever seen one stream records nothing behind its launches;
+    the first launch on another stream waits for the device -- not for the earlier stream, which
+    its owner may have destroyed by then (recording an event on a destroyed stream faults) --
+    and from then on every launch leaves an event, recorded while its stream is certainly alive
+    (ws_acquire / ws_release, mod16_capi.hip). Both phases with a destroyed stream in between."""
     import ctypes
+    import torch as _t
     torch, RasterEngine, table = env
     eng = RasterEngine(table)
     n = 1200 * 1200
     cls, drv, day, night = eng.alloc_raster(n)
     eng.synth(n, seed=8, out=(cls, drv))
-    hip = ctypes.CDLL('libamdhip64.so')
-    raw = ctypes.c_void_p()
-    assert hip.hipStreamCreate(ctypes.byref(raw)) == 0
+    # the HIP runtime torch has loaded (another copy of the library would be another runtime)
+    hip = ctypes.CDLL(__import__('os').path.join(__import__('os').path.dirname(_t.__file__), 'lib', 'libamdhip64.so'))
+    vecs = [torch.zeros(8, dtype=torch.float64, device='cuda') for _ in range(6)]
     torch.cuda.synchronize()
-    vecs = [torch.zeros(8, dtype=torch.float64, device='cuda') for _ in range(3)]
-    gone = torch.cuda.ExternalStream(raw.value)
-    with torch.cuda.stream(gone):
-        eng.run(cls, drv, day, night, diag=vecs[0])
-    gone.synchronize()
-    del gone
-    assert hip.hipStreamDestroy(raw) == 0
-    eng.run(cls, drv, day, night, diag=vecs[1])      # the current stream: behind a launch on `raw`
-    eng.run(cls, drv, day, night, diag=vecs[2])
-    torch.cuda.synchronize()
-    eng.check()
+    k = 0
+    for phase in range(2):
+        raw = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(raw)) == 0
+        gone = torch.cuda.ExternalStream(raw.value)
+        with torch.cuda.stream(gone):
+            eng.run(cls, drv, day, night, diag=vecs[k])
+        gone.synchronize()
+        del gone
+        assert hip.hipStreamDestroy(raw) == 0
+        eng.run(cls, drv, day, night, diag=vecs[k + 1])      # the current stream: behind a launch on `raw`
+        eng.run(cls, drv, day, night, diag=vecs[k + 2])
+        torch.cuda.synchronize()
+        eng.check()
+        k += 3
     assert float(vecs[0][2]) > 0
-    assert torch.equal(vecs[0], vecs[1]) and torch.equal(vecs[0], vecs[2])
+    for v in vecs[1:]:
+        assert torch.equal(vecs[0], v)
