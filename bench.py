@@ -827,6 +827,7 @@ def build_summary(line):
     (tests/test_host_logic.py parses the last 6000 bytes of a full line)."""
     roof, cfg = line.get('roofline') or {}, line.get('configs') or {}
     c2, c4, c5 = (cfg.get(k) or {} for k in ('c2_1200x1200_float64', 'c4_series_float64', 'c5_global_grid_float32'))
+    c1 = cfg.get('c1_single_site') or {}
     f64, f32 = cfg.get('forms_float64') or {}, cfg.get('forms_float32_mixed') or {}
     par = line.get('parity') or {}
     full = par.get('full_grid_fast_vs_exact_kernel') or par.get('full_grid_mixed_vs_float64_arithmetic') or {}
@@ -839,6 +840,8 @@ def build_summary(line):
         'copy_GBps': roof.get('measured_copy_GBps'),
         'sclk_mhz': roof.get('sclk_mhz'), 'power_w': roof.get('power_w'), 'cycles_per_step': roof.get('cycles_per_step'),
         'plain_ms': roof.get('plain_ms'), 'plain_frac': roof.get('plain_frac'),
+        'c1_scalar_call_us': _dig(c1, 'scalars', 'call_us'), 'c1_scalar_numpy_us': _dig(c1, 'scalars', 'numpy_oracle_us'),
+        'c1_year_call_us': _dig(c1, 'site_year_365', 'call_us'), 'c1_year_numpy_us': _dig(c1, 'site_year_365', 'numpy_oracle_us'),
         'c2_us': c2.get('tile_us_per_launch'), 'c2_us_no_diag': c2.get('tile_us_per_launch_without_diagnostics'),
         'c2_batch64_us_per_tile': c2.get('batch64_us_per_tile'),
         'c4_ms_per_step': c4.get('ms_per_step'),
@@ -950,6 +953,42 @@ def numpy_in_numpy_out(np, torch, eng, table, devices, bplut, tiles_per_device=1
     return out
 
 
+def single_site_config(np, oracle):
+    """BASELINE.json configs[0]: ONE call of the drop-in, numpy in -> numpy out, on the scalars of the
+    reference's flux-tower test (tests/tests.py:21-54, golden fixture F1), on a year of that site
+    (365 values per driver) and on a 100 x 100 window -- wall clock of MOD16.evapotranspiration()
+    (best and median of 300; HOST mode: calls this small go through the library's copy-free path)
+    next to the numpy oracle on this box's host cores for the same call, each result checked
+    against the oracle's."""
+    import mod16_amd
+    f1 = np.load(os.path.join(ROOT, 'tests', 'golden', 'f1_tests_scalars.npz'))
+    params = dict(zip(mod16_amd.MOD16.required_parameters, (float(v) for v in f1['params'])))
+    model = mod16_amd.MOD16(params)
+    rng = np.random.default_rng(SEED)
+    out = {}
+
+    def timed(fn, reps):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[0] * 1e6, ts[len(ts) // 2] * 1e6
+    for name, shape in (('scalars', ()), ('site_year_365', (365,)), ('window_100x100', (100, 100))):
+        drv = [float(v) * (1 + 0.01 * rng.uniform(-1, 1, shape)) if shape else float(v) for v in f1['drivers']]
+        got = model.evapotranspiration(*drv)
+        want = oracle.evapotranspiration(params, *drv)
+        err = max(float(np.max(np.abs(np.asarray(g) - np.asarray(w)) / np.abs(np.asarray(w)))) for g, w in zip(got, want))
+        best, med = timed(lambda: model.evapotranspiration(*drv), 300)
+        obest, omed = timed(lambda: oracle.evapotranspiration(params, *drv), 30)
+        out[name] = {'pixels': int(np.prod(shape, dtype=np.int64)) if shape else 1, 'call_us': best, 'call_us_median': med,
+                     'numpy_oracle_us': obest, 'numpy_oracle_us_median': omed, 'max_rel_err_vs_oracle': err}
+    out['note'] = ('wall clock of one MOD16.evapotranspiration() call (numpy in, numpy out, PCIe and Python included); '
+                   'round 4 took 124 us for the scalars -- slower than the reference\'s numpy (86 us)')
+    return out
+
+
 def other_configs(args, torch, np, _lib, RasterEngine, table, bplut):
     """The BASELINE.json configurations beside the headline one, measured in the same
     process on the same GPU (N = 1): configs[1] one 1200 x 1200 float64 tile per launch
@@ -958,6 +997,7 @@ def other_configs(args, torch, np, _lib, RasterEngine, table, bplut):
     Each with its own parity summary."""
     from oracle import mod16_oracle as oracle
     out = {}
+    out['c1_single_site'] = single_site_config(np, oracle)
     eng = RasterEngine(table, dtype='float64')
     diag = torch.zeros(8, dtype=torch.float64, device='cuda')
 

@@ -29,6 +29,8 @@ Two ways in:
 
 __version__ = 'v1.2.0+mi355x.r1'
 
+import ctypes as _ctypes
+
 import numpy as np
 
 from . import _lib
@@ -70,11 +72,57 @@ def pinned_empty(shape, dtype=np.float64):
 def _result_dtype(values):
     '''float32 only if every array-like input is float32 (numpy's own rule
     for the reference code); Python scalars are weak.'''
-    strong = [np.asarray(v).dtype for v in values
-              if isinstance(v, (np.ndarray, np.generic))]
-    if strong and np.result_type(*strong) == np.float32:
-        return np.dtype(np.float32)
-    return np.dtype(np.float64)
+    seen32, others = False, None
+    for v in values:
+        t = type(v)
+        if t is float or t is int:
+            continue
+        if isinstance(v, (np.ndarray, np.generic)):
+            if v.dtype == _F32:
+                seen32 = True
+            elif others is None:
+                others = [v.dtype]
+            else:
+                others.append(v.dtype)
+    if others is None:
+        return _F32 if seen32 else _F64
+    if seen32:
+        others.append(_F32)
+    return _F32 if np.result_type(*others) == _F32 else _F64
+
+
+_F32, _F64 = np.dtype(np.float32), np.dtype(np.float64)
+
+
+def _address(a):
+    '''Address of a C-contiguous array's first element (the buffer protocol is a third of
+    the cost of ``a.ctypes.data``, but wants a writeable, non-empty array).'''
+    if a.flags.writeable and a.size:
+        return _ctypes.addressof(_ctypes.c_char.from_buffer(a))
+    return a.__array_interface__['data'][0]
+
+
+def _broadcast(shapes):
+    '''-> (broadcast shape, number of elements); equal shapes -- the usual call -- without numpy.'''
+    shape = shapes[0]
+    for sh in shapes:
+        if sh != shape:
+            shape = np.broadcast_shapes(*shapes)
+            break
+    n = 1
+    for extent in shape:
+        n *= int(extent)
+    return shape, n
+
+
+def _shape(v):
+    '''``np.shape`` without its detour through ``asarray`` for the two common cases.'''
+    t = type(v)
+    if t is float or t is int:
+        return ()
+    if t is np.ndarray:
+        return v.shape
+    return np.shape(v)
 
 
 def _broadcast_kind(a_shape, size, shape):
@@ -100,24 +148,43 @@ def _marshal(values, shape, dtype, kinds=False):
     size-1 input is passed as a broadcast scalar (stride 0), anything else is
     made dense over ``shape`` (stride 1). With ``kinds`` the third list holds
     broadcast kinds (``_lib.BC_*``) and (N,) rows / (..., 1) columns stay as
-    small as they are.'''
+    small as they are. (The size-1 inputs share ONE small array: a call on the
+    scalars of a flux-tower site costs a handful of numpy operations, not 25
+    times three.)'''
     keep, ptrs, strides = [], [], []
-    for v in values:
-        a = np.asarray(v, dtype=dtype)
-        kind = _broadcast_kind(a.shape, a.size, shape) if kinds else None
-        if a.size == 1:
-            a = np.ascontiguousarray(a.reshape(1))
+    scal = base = None
+    dtype = np.dtype(dtype)
+    esz = dtype.itemsize
+    for i, v in enumerate(values):
+        t = type(v)
+        if t is float or t is int:
+            a = None
+        else:
+            a = v if (t is np.ndarray and v.dtype == dtype) else np.asarray(v, dtype=dtype)
+            if a.size == 1:
+                v = a.reshape(-1)[0]
+                a = None
+        if a is None:
+            if scal is None:
+                scal = np.empty(len(values), dtype)
+                base = _address(scal)
+                keep.append(scal)
+            scal[i] = v
+            ptrs.append(base + i * esz)
             strides.append(0)
-        elif kind in (_lib.BC_ROW, _lib.BC_COL):
+            continue
+        kind = _broadcast_kind(a.shape, a.size, shape) if kinds else None
+        if kind in (_lib.BC_ROW, _lib.BC_COL):
             a = np.ascontiguousarray(a.reshape(-1))
             strides.append(kind)
         else:
             if a.shape != shape:
                 a = np.broadcast_to(a, shape)
-            a = np.ascontiguousarray(a)
+            if not a.flags.c_contiguous:
+                a = np.ascontiguousarray(a)
             strides.append(1)
         keep.append(a)
-        ptrs.append(a.ctypes.data)
+        ptrs.append(_address(a))
     return keep, ptrs, strides
 
 
@@ -145,7 +212,7 @@ def _forward(cls, drivers, params, separate, flags, device, pet=False, out=None,
     devs = multi.device_list(devices)
     values = list(drivers) + (list(params) if params is not None else [])
     dtype = _result_dtype(values)
-    shapes = [np.shape(v) for v in values]
+    shapes = [_shape(v) for v in values]
     if cls is not None:
         cls = np.asarray(cls)
         if cls.dtype != np.uint8:
@@ -153,8 +220,7 @@ def _forward(cls, drivers, params, separate, flags, device, pet=False, out=None,
                 raise IndexError('class code outside [0, 255]')
             cls = cls.astype(np.uint8)
         shapes.append(cls.shape)
-    shape = np.broadcast_shapes(*shapes)
-    n = int(np.prod(shape, dtype=np.int64))
+    shape, n = _broadcast(shapes)
     if diagnostics and (pet or separate):
         raise ValueError('diagnostics come with the (day, night) totals only')
     # (N,) rows and (..., 1) columns against (..., N) drivers are not made dense
@@ -255,8 +321,7 @@ def _call_method(method, inputs, params=None, nout=1, alpha=1.26, device=0, tiny
     params = dict((k, v) for k, v in (params or {}).items() if v is not None)
     pvals = list(params.values())
     dtype = _result_dtype(present + pvals)
-    shape = np.broadcast_shapes(*[np.shape(v) for v in present + pvals])
-    n = int(np.prod(shape, dtype=np.int64))
+    shape, n = _broadcast([_shape(v) for v in present + pvals])
     keep, ptrs, strides = _marshal(present, shape, dtype)
     it = iter(zip(ptrs, strides))
     iptr, istr = [], []
@@ -273,7 +338,7 @@ def _call_method(method, inputs, params=None, nout=1, alpha=1.26, device=0, tiny
     outs = [np.empty(shape, dtype) for _ in range(nout)]
     if n:
         ctx.method(dtype, method, iptr, istr, pptr, pstr, n,
-                   [o.ctypes.data for o in outs] + [None] * (2 - nout), alpha=alpha,
+                   [_address(o) for o in outs] + [None] * (2 - nout), alpha=alpha,
                    tiny=tiny)
     if not shape:
         outs = [o[()] for o in outs]

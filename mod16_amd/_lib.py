@@ -290,16 +290,26 @@ def device_count():
     return n.value
 
 
+_ARRAY_TYPES = {}
+
+
+def _array_type(base, n):
+    t = _ARRAY_TYPES.get((base, n))
+    if t is None:
+        t = _ARRAY_TYPES[(base, n)] = base * n
+    return t
+
+
 def ptr_array(ptrs):
     '''Python ints / None -> void*[len]'''
-    arr = (C.c_void_p * len(ptrs))()
-    for i, p in enumerate(ptrs):
-        arr[i] = p
-    return arr
+    return _array_type(C.c_void_p, len(ptrs))(*ptrs)
 
 
 def i64_array(vals):
-    return (C.c_int64 * len(vals))(*[int(v) for v in vals])
+    try:
+        return _array_type(C.c_int64, len(vals))(*vals)
+    except TypeError:       # numpy integers
+        return _array_type(C.c_int64, len(vals))(*[int(v) for v in vals])
 
 
 class Context:
@@ -356,7 +366,7 @@ class Context:
            out_night, out_sep, flags=MATH_FAST, where=HOST, stream=None):
         '''Thin wrapper of mod16_et_f64 / mod16_et_f32; every array argument
         is a raw address (int) or None.'''
-        fn = self.lib.mod16_et_f32 if np.dtype(dtype) == np.float32 \
+        fn = self.lib.mod16_et_f32 if dtype == np.float32 \
             else self.lib.mod16_et_f64
         self.check(fn(
             self.handle, cls, ptr_array(drivers), i64_array(dstride),

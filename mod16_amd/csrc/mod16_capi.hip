@@ -27,6 +27,8 @@ constexpr int64_t kTilePixels = int64_t(1) << 21;   // HOST mode: pixels per sta
 constexpr int kDiagBlocks = 1024;
 constexpr int kSlots = 12;                          // staging slots = host threads of the HOST mode
 constexpr size_t kStagger = 33 * 1024;              // see RasterEngine.STAGGER_BYTES
+constexpr int kSmallPixels = 65536;                 // HOST mode: calls up to this size take the copy-free path
+constexpr int kSmallPixelsMax = 1 << 18;             // ... and what MOD16_SMALL_PIXELS may raise it to
 }  // namespace
 
 // Workspace of the per-run diagnostics partials of et_stream_kernel (and of the
@@ -87,6 +89,12 @@ struct mod16_ctx {
     hipStream_t streams[kSlots] = {};
     std::mutex launch_mu;            // HOST mode: kernel launches of the staging threads
     void* scalars = nullptr;         // device copies of broadcast scalars
+    // HOST mode, small calls (a flux-tower site, a year of one pixel): one page-locked buffer the
+    // kernel reads its inputs from and writes its outputs to over the link -- no copy commands at all
+    int small_pixels = kSmallPixels; // MOD16_SMALL_PIXELS: calls of at most this many pixels go that way (0: none)
+    void* small_host = nullptr;      // hipHostMalloc'ed
+    void* small_dev = nullptr;       // ... as the device addresses it
+    size_t small_bytes = 0;
     unsigned long long* force_counter = nullptr;   // ticket counter to use instead of the ring (graph capture)
     void* bc_buf = nullptr;          // HOST mode: device copies of (N,) / (T, 1) inputs (mod16_et2_*)
     size_t bc_bytes = 0;
@@ -156,6 +164,7 @@ extern "C" int mod16_destroy(mod16_ctx* ctx) {
         if (ctx->streams[s]) (void)hipStreamDestroy(ctx->streams[s]);
     }
     if (ctx->scalars) (void)hipFree(ctx->scalars);
+    if (ctx->small_host) (void)hipHostFree(ctx->small_host);
     if (ctx->batch_buf) (void)hipFree(ctx->batch_buf);
     if (ctx->bc_buf) (void)hipFree(ctx->bc_buf);
     if (ctx->lut64) (void)hipFree(ctx->lut64);
@@ -195,6 +204,8 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
         ctx->cus = prop.multiProcessorCount;
         // the one documented tuning knob of the shipped library: staging threads of the HOST mode
         if (const char* g = getenv("MOD16_HOST_THREADS")) ctx->host_threads = std::max(1, std::min(kSlots, atoi(g)));
+        // ... and where the HOST mode's copy-free path for small calls ends (0: every call is staged)
+        if (const char* g = getenv("MOD16_SMALL_PIXELS")) ctx->small_pixels = std::max(0, std::min(kSmallPixelsMax, atoi(g))) / 4 * 4;
 #ifdef MOD16_EXPERIMENTS
         // launch-geometry overrides of the experiments build (libmod16hip_exp.so: tools/, and the
         // tests that put the flag record through the other schedules); never in the shipped library
@@ -844,10 +855,108 @@ static int stage_tile(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags, const 
     return MOD16_OK;
 }
 
+// The page-locked buffer of the small calls: 256 bytes of scalars, `arrays` arrays of `elem`-byte
+// values and one of bytes, for n pixels. It grows with the largest call seen (powers of two from 1024
+// pixels: a caller of scalars pins 0.3 MB, one of 256 x 256 windows 18 MB). Also makes sure of streams[0].
+static int small_reserve(mod16_ctx* ctx, int64_t n, size_t elem, int arrays, size_t* per_arr) {
+    int64_t cap = 1024;
+    while (cap < n) cap *= 2;
+    *per_arr = (size_t)cap * elem;
+    const size_t need = 256 + *per_arr * arrays + (size_t)cap + 256;
+    if (ctx->small_bytes < need) {
+        if (ctx->small_host) HIPCHK(ctx, hipHostFree(ctx->small_host));
+        ctx->small_host = ctx->small_dev = nullptr;
+        ctx->small_bytes = 0;
+        HIPCHK(ctx, hipHostMalloc(&ctx->small_host, need, hipHostMallocDefault));
+        HIPCHK(ctx, hipHostGetDevicePointer(&ctx->small_dev, ctx->small_host, 0));
+        ctx->small_bytes = need;
+    }
+    if (!ctx->streams[0]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking));
+    return MOD16_OK;
+}
+
+// HOST mode, small calls. The staged path costs a dozen copy commands whatever the size (each
+// dense input its own, pageable memory: the runtime stages and waits), a status read-back and
+// three synchronisations -- 64 us for ONE pixel, where the reference's numpy takes 86 us for its
+// whole forward run (BASELINE.json configs[0]: a flux-tower site), ~290 us up to 16 k pixels.
+// Measured against it (tools/smallcall.py, profiles/r05_small_calls.jsonl): 18 us against 64 for one
+// pixel, 102 against 273 at 100 x 100, 371 against 420 at 256 x 256, even at ~90 k pixels, slower
+// beyond (the CPU's copies into the buffer grow faster than the runtime's DMA): kSmallPixels.
+// Here the inputs are copied by
+// the CPU into one page-locked buffer, the kernel reads them from there and writes its outputs
+// there (host memory is in the device's address space: a few KB over the link), and the CPU
+// copies the outputs on: one launch, one synchronisation, the same kernels on the same values --
+// the same bits as the staged path gives. Class codes are checked here instead of by the kernel
+// (the staged path reads the kernel's status word back).
+template <typename T>
+static int run_host_small(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
+    const int64_t n = h.n;
+    size_t per_arr = 0;
+    int rc0 = small_reserve(ctx, n, sizeof(T), 14 + 11 + 10, &per_arr);
+    if (rc0 != MOD16_OK) return rc0;
+    hipStream_t st = ctx->streams[0];
+    if (h.cls) {       // (dense: a broadcast class raster is has_rows_or_cols' business)
+        for (int64_t i = 0; i < n; ++i)
+            if (h.cls[i] >= MOD16_N_CLASSES)
+                return fail(ctx, MOD16_ERR_CLASS_RANGE, "class raster holds a code >= 13 (numpy would raise IndexError)");
+    }
+    char* hb = static_cast<char*>(ctx->small_host);
+    char* db = static_cast<char*>(ctx->small_dev);
+    T* hs = reinterpret_cast<T*>(hb);              // 25 broadcast scalars in the first 256 bytes
+    const T* dscal = reinterpret_cast<const T*>(db);
+    EtArgs<T> d = h;
+    d.base = 0;
+    // whole 16-byte vectors: a ragged end would cost a second launch (the one-pixel-per-thread
+    // kernel behind the vector kernel) -- the buffer has the room, the pad pixels repeat the last
+    // pixel (so they are no new case for the domain guard), and their outputs stay in the buffer
+    constexpr int V = VecOf<T>::v;
+    const int64_t npad = (n + V - 1) / V * V;
+    d.n = npad;
+    auto arr = [&](int k) { return (size_t)256 + per_arr * k; };
+    auto put = [&](size_t off, const void* src, size_t elem) {
+        memcpy(hb + off, src, elem * n);
+        for (int64_t i = n; i < npad; ++i) memcpy(hb + off + elem * i, static_cast<const char*>(src) + elem * (n - 1), elem);
+    };
+    for (int k = 0; k < 14; ++k) {
+        if ((h.dense_drv >> k) & 1u) {
+            put(arr(k), h.drv[k], sizeof(T));
+            d.drv[k] = reinterpret_cast<const T*>(db + arr(k));
+        } else {
+            hs[k] = h.drv[k][0];
+            d.drv[k] = dscal + k;
+        }
+    }
+    if (h.cls) {
+        const size_t off = arr(35);
+        put(off, h.cls, 1);
+        d.cls = reinterpret_cast<const uint8_t*>(db + off);
+    } else {
+        for (int k = 0; k < 11; ++k) {
+            if ((h.dense_par >> k) & 1u) {
+                put(arr(14 + k), h.par[k], sizeof(T));
+                d.par[k] = reinterpret_cast<const T*>(db + arr(14 + k));
+            } else {
+                hs[14 + k] = h.par[k][0];
+                d.par[k] = dscal + 14 + k;
+            }
+        }
+    }
+    for (int k = 0; k < 10; ++k)
+        d.out[k] = h.out[k] ? reinterpret_cast<T*>(db + arr(25 + k)) : nullptr;
+    int rc = launch_et<T>(ctx, d, flags, st);
+    if (rc != MOD16_OK) return rc;
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    for (int k = 0; k < 10; ++k)
+        if (h.out[k]) memcpy(h.out[k], hb + arr(25 + k), sizeof(T) * n);
+    return MOD16_OK;
+}
+
 template <typename T>
 static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags, double* tile_diag = nullptr) {
     const int64_t n = h.n;
     if (n == 0) return MOD16_OK;
+    if (n <= ctx->small_pixels && !tile_diag && !has_rows_or_cols(h)) return run_host_small<T>(ctx, h, flags);
     const int64_t tile = std::min<int64_t>(n, kTilePixels);
     const int64_t ntiles = (n + tile - 1) / tile;
     const int nslots = (int)std::min<int64_t>(ntiles, ctx->host_threads);
@@ -1348,7 +1457,49 @@ static int method_entry(mod16_ctx* ctx, int method, const T* const* in, const in
         return MOD16_OK;
     }
     if (where != MOD16_HOST) return fail(ctx, MOD16_ERR_ARG, "mod16_method: bad `where`");
-    // HOST: one slab, tile by tile (these calls are small; no double buffering)
+    if (n <= ctx->small_pixels) {
+        // small calls (what the class surface is used for: scalars, a site's series): no copy
+        // commands, the kernel reads and writes one page-locked buffer (run_host_small)
+        size_t per_arr = 0;
+        int rc = small_reserve(ctx, n, sizeof(T), kMethodMaxIn + 11 + 2, &per_arr);
+        if (rc != MOD16_OK) return rc;
+        hipStream_t st = ctx->streams[0];
+        char* hb = static_cast<char*>(ctx->small_host);
+        char* db = static_cast<char*>(ctx->small_dev);
+        T* hs = reinterpret_cast<T*>(hb);
+        const T* dscal = reinterpret_cast<const T*>(db);
+        static_assert(sizeof(double) * (kMethodMaxIn + 11) <= 256, "scalars of a method call fit the buffer's head");
+        auto arr = [&](int k) { return (size_t)256 + per_arr * k; };
+        MethodArgs<T> d = a;
+        for (int k = 0; k < kMethodMaxIn; ++k) {
+            if (!a.in[k]) continue;
+            if ((a.dense_in >> k) & 1u) {
+                memcpy(hb + arr(k), a.in[k], sizeof(T) * n);
+                d.in[k] = reinterpret_cast<const T*>(db + arr(k));
+            } else {
+                hs[k] = a.in[k][0];
+                d.in[k] = dscal + k;
+            }
+        }
+        for (int k = 0; k < 11; ++k) {
+            if (a.par[k] && ((a.dense_par >> k) & 1u)) {
+                memcpy(hb + arr(kMethodMaxIn + k), a.par[k], sizeof(T) * n);
+                d.par[k] = reinterpret_cast<const T*>(db + arr(kMethodMaxIn + k));
+            } else {
+                hs[kMethodMaxIn + k] = a.par[k] ? a.par[k][0] : nan_param;
+                d.par[k] = dscal + kMethodMaxIn + k;
+            }
+        }
+        for (int k = 0; k < 2; ++k)
+            d.out[k] = a.out[k] ? reinterpret_cast<T*>(db + arr(kMethodMaxIn + 11 + k)) : nullptr;
+        launch(d, st);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        for (int k = 0; k < 2; ++k)
+            if (a.out[k]) memcpy(a.out[k], hb + arr(kMethodMaxIn + 11 + k), sizeof(T) * n);
+        return MOD16_OK;
+    }
+    // HOST: one slab, tile by tile (no double buffering)
     const int64_t tile = std::min<int64_t>(n, kTilePixels);
     const size_t per_arr = (((size_t)tile * sizeof(T)) + 255) / 256 * 256;
     const size_t need = per_arr * (14 + 11 + 8) + (size_t)tile + 256;

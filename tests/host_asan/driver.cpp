@@ -217,6 +217,29 @@ static void host_cases(mod16_ctx* ctx, const char* what) {
         double folded[8];
         EXPECT(mod16_fold_diag_host(tile_diag.data(), (int64_t)tile_diag.size() / 8, folded) == MOD16_OK);
     }
+    // small calls: the copy-free path (page-locked buffer read and written by the kernel) up to its
+    // limit, the staged path one pixel above it; parameters as arrays / scalars, every output set,
+    // a class code the reference would refuse
+    for (int64_t n : {(int64_t)1, (int64_t)365, (int64_t)1025, (int64_t)65535, (int64_t)65536, (int64_t)65537}) {
+        std::vector<std::vector<T>> drv(14, std::vector<T>(n, T(1))), par(11, std::vector<T>(n, T(2)));
+        std::vector<std::vector<T>> outs(6, std::vector<T>(n));
+        std::vector<uint8_t> cls(n, 1);
+        std::vector<T> day(n), night(n);
+        const T *dp[14], *pp[11];
+        int64_t ds[14], ps[11];
+        T one = T(300);
+        for (int k = 0; k < 14; ++k) { dp[k] = k % 3 ? drv[k].data() : &one; ds[k] = k % 3 ? 1 : 0; }
+        for (int k = 0; k < 11; ++k) { pp[k] = k % 2 ? par[k].data() : &one; ps[k] = k % 2 ? 1 : 0; }
+        T* sep[6];
+        for (int k = 0; k < 6; ++k) sep[k] = outs[k].data();
+        OK(TypeOps<T>::et(ctx, nullptr, dp, ds, pp, ps, n, day.data(), night.data(), nullptr, MOD16_MATH_FAST, MOD16_HOST));
+        OK(TypeOps<T>::et(ctx, nullptr, dp, ds, pp, ps, n, nullptr, nullptr, sep, MOD16_MATH_EXACT, MOD16_HOST));
+        OK(TypeOps<T>::et(ctx, cls.data(), dp, ds, nullptr, nullptr, n, day.data(), night.data(), sep, MOD16_MATH_FAST, MOD16_HOST));
+        if (n <= 65536) {    // (above it the kernel reports the code; the stand-in's kernels report nothing)
+            cls[n - 1] = 13;
+            EXPECT(TypeOps<T>::et(ctx, cls.data(), dp, ds, nullptr, nullptr, n, day.data(), night.data(), nullptr, MOD16_MATH_FAST, MOD16_HOST) == MOD16_ERR_CLASS_RANGE);
+        }
+    }
     // raw drivers through the same staging (threads and slots since round 5), hours dense / scalar / absent
     for (int64_t n : {(int64_t)7, (int64_t)2 * tile + 4321}) {
         std::vector<std::vector<T>> raw(14, std::vector<T>(n, T(280)));

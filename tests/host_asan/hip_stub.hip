@@ -334,8 +334,15 @@ hipError_t hipMalloc(void** p, size_t bytes) { *p = stub::alloc(bytes); return *
 hipError_t hipFree(void* p) { return stub::release(p); }
 hipError_t hipMallocAsync(void** p, size_t bytes, hipStream_t) { return hipMalloc(p, bytes); }
 hipError_t hipFreeAsync(void* p, hipStream_t) { return stub::release(p); }
-hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { *p = malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+// page-locked host memory is in the device's address space too (the HOST mode's small calls hand it
+// to their kernels): a tracked block like any other, always real memory
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
+    if (bytes >= stub::kRealBelow) stub::die("hipHostMalloc of %zu bytes: the library pins small buffers only", bytes);
+    *p = stub::alloc(bytes);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipHostFree(void* p) { return stub::release(p); }
+hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) { *dev = host; return hipSuccess; }
 
 static hipError_t copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
     // the device side of a copy must be a device allocation; host sides are plain memory under ASan

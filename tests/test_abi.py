@@ -156,9 +156,9 @@ def test_form_table_matches_the_library():
 
 def test_shipped_library_reads_no_experiment_switch(lib):
     """Launch-geometry overrides and measurement paths exist only in -DMOD16_EXPERIMENTS builds
-    (libmod16hip_exp.so, tools/): the shipped library names ONE environment variable, the
-    documented MOD16_HOST_THREADS, and the sources refuse to compile a measurement switch
-    without the experiments define."""
+    (libmod16hip_exp.so, tools/): the shipped library names TWO environment variables, the
+    documented knobs of its HOST mode (MOD16_HOST_THREADS, MOD16_SMALL_PIXELS), and the sources
+    refuse to compile a measurement switch without the experiments define."""
     import shutil
     import subprocess
 
@@ -168,13 +168,13 @@ def test_shipped_library_reads_no_experiment_switch(lib):
     switches = {'MOD16_NO_DMA', 'MOD16_RUN_SHIFT', 'MOD16_STATIC_BELOW', 'MOD16_STREAM_BLOCKS',
                 'MOD16_PITCH', 'MOD16_GRID_MULT', 'MOD16_POISON_TICKET'}
     shipped = env_names(lib.LIB_PATH)      # (the rest are enum names inside error messages)
-    assert 'MOD16_HOST_THREADS' in shipped and not (shipped & switches), shipped
+    assert {'MOD16_HOST_THREADS', 'MOD16_SMALL_PIXELS'} <= shipped and not (shipped & switches), shipped
     assert not any(n.startswith(('MOD16_NO_', 'MOD16_EXPERIMENT', 'MOD16_TRIVIAL', 'MOD16_PRIO', 'MOD16_DYN'))
                    for n in shipped), shipped
     assert switches | {'MOD16_HOST_THREADS'} <= env_names(lib.EXP_LIB_PATH)
     src = open(os.path.join(ROOT, 'mod16_amd', 'csrc', 'mod16_capi.hip')).read()
     product = re.sub(r'#ifdef MOD16_EXPERIMENTS.*?#endif', '', src, flags=re.S)
-    assert re.findall(r'getenv\("(\w+)"\)', product) == ['MOD16_HOST_THREADS']
+    assert re.findall(r'getenv\("(\w+)"\)', product) == ['MOD16_HOST_THREADS', 'MOD16_SMALL_PIXELS']
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if os.path.exists(hipcc):
         for switch in ('-DMOD16_NO_GUARD', '-DMOD16_TRIVIAL_BODY', '-DMOD16_DYN_RUN=4'):

@@ -638,3 +638,103 @@ def test_special_value_pairs_fast_kernel(m16, golden):
     for g3, w3, period in zip(got6, want6, ('day', 'night')):
         for g, w, part in zip(g3, w3, ('canopy', 'soil', 'transpiration')):
             assert_parity(g, w, 1e-8, period + ' ' + part)
+
+
+def _in_a_fresh_thread(fn, env):
+    """Runs fn in a new thread -- a new context (mod16_amd._lib.context is per thread), created
+    with `env` in the environment (the library reads its two knobs when a context is made)."""
+    import os
+    import threading
+    box = {}
+
+    def body():
+        try:
+            box['value'] = fn()
+        except BaseException as exc:      # handed to the caller
+            box['error'] = exc
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        t = threading.Thread(target=body)
+        t.start()
+        t.join()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    if 'error' in box:
+        raise box['error']
+    return box['value']
+
+
+def _same_bits(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 5, 365, 1025, 65535, 65536, 65537])
+def test_small_calls_give_the_bits_of_the_staged_path(m16, golden, n):
+    """HOST mode, calls of up to 65536 pixels: no copy commands -- the kernel reads its inputs
+    from a page-locked buffer and writes its outputs there (run_host_small, mod16_capi.hip).
+    Same kernels, same values: every output of every form equals the staged path's
+    (MOD16_SMALL_PIXELS=0) bit for bit, float64 and float32, class raster and parameter
+    arrays, ragged sizes (the buffer pads to whole vectors), one pixel above the limit."""
+    f = golden('f3_random64_f64')
+    table = f['table']
+    cls, drv = synth.drivers((n,), seed=1000 + n)
+    params = [table[cls.astype(int) % 13, j] if j % 2 else float(table[7, j]) for j in range(11)]
+    def run(dtype):
+        d = [a.astype(dtype) for a in drv]
+        model = m16.MOD16(dict(zip(oracle.PARAM_NAMES, [np.asarray(p, dtype) if np.ndim(p) else p for p in params])))
+        scal = list(d)
+        scal[7] = float(d[7][0])        # a broadcast scalar among the dense drivers
+        out = list(m16.evapotranspiration_raster(table, cls, *d))
+        out += list(m16.evapotranspiration_raster(table, cls, *scal))
+        sep = m16.evapotranspiration_raster(table, cls, *d, separate=True)
+        out += list(sep[0]) + list(sep[1])
+        out += list(model.evapotranspiration(*d))
+        sep = model.evapotranspiration(*scal, separate=True)
+        out += list(sep[0]) + list(sep[1])
+        out += list(model.evapotranspiration_and_pet(*d))
+        out.append(model.evaporation_soil(d[11], d[5], d[9], d[12], np.abs(d[2])))
+        out.append(m16.MOD16.rhumidity(d[5], d[9]))
+        return out
+
+    for dtype in (np.float64, np.float32):
+        small = run(dtype)
+        staged = _in_a_fresh_thread(lambda: run(dtype), {'MOD16_SMALL_PIXELS': '0'})
+        assert len(small) == len(staged) == 26
+        for i, (a, b) in enumerate(zip(small, staged)):
+            assert a.dtype == dtype and _same_bits(a, b), (n, dtype, i)
+    # and the oracle, value by value (the staged path's own tests hold it elsewhere)
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    wd, wn = oracle.evapotranspiration_raster(bplut, cls, *drv)
+    small_f64 = m16.evapotranspiration_raster(table, cls, *drv)[0]
+    assert_parity(small_f64, wd, RTOL['fast'], 'day')
+    # a class code numpy would refuse: IndexError from both paths, nothing left behind
+    bad = cls.copy()
+    bad[n // 2] = 13
+    for env in ({}, {'MOD16_SMALL_PIXELS': '0'}):
+        with pytest.raises(IndexError):
+            _in_a_fresh_thread(lambda: m16.evapotranspiration_raster(table, bad, *drv), env)
+    assert _same_bits(m16.evapotranspiration_raster(table, cls, *drv)[0], small_f64)
+
+
+def test_scalar_site_call_through_the_small_path(m16, golden):
+    """BASELINE.json configs[0]: the flux-tower scalars of the reference's tests (F1) -- numpy
+    scalars out, the reference's values, and the same again after calls of other sizes and
+    dtypes have reshaped the page-locked buffer."""
+    f = golden('f1_tests_scalars')
+    m = model(m16, f['params'], 'fast')
+    drivers = [float(x) for x in f['drivers']]
+    for _ in range(2):
+        day, night = m.evapotranspiration(*drivers)
+        assert np.ndim(day) == 0 and isinstance(day, np.floating)
+        assert_parity(np.asarray(day), f['day'], RTOL['fast'], 'day')
+        assert_parity(np.asarray(night), f['night'], RTOL['fast'], 'night')
+        big = [np.full(3000, x, np.float32) for x in drivers]
+        d32, _ = m.evapotranspiration(*big)
+        assert d32.dtype == np.float32 and d32.shape == (3000,)
+        assert abs(float(d32[0]) / float(day) - 1) < 1e-6

@@ -96,10 +96,22 @@ def test_marshal_strides_and_broadcast():
     vals = [3.0, np.arange(5.0), np.ones(shape), np.float32(2)]
     keep, ptrs, strides = mod16_amd._marshal(vals, shape, np.float64)
     assert strides == [0, 1, 1, 0]
-    assert keep[1].shape == shape and keep[1].flags.c_contiguous
-    assert np.array_equal(keep[1][2], np.arange(5.0))
+    # the size-1 inputs share one small array (slot i of it for value i), the others follow
+    scal, row, ones = keep
+    assert scal[0] == 3.0 and scal[3] == 2.0
+    assert ptrs[0] == scal.ctypes.data and ptrs[3] == scal.ctypes.data + 3 * 8
+    assert row.shape == shape and row.flags.c_contiguous
+    assert np.array_equal(row[2], np.arange(5.0))
     assert all(k.dtype == np.float64 for k in keep)
-    assert ptrs[2] == keep[2].ctypes.data
+    assert ptrs[1] == row.ctypes.data and ptrs[2] == ones.ctypes.data
+    # float32 results: the scalars are stored as float32
+    keep, ptrs, strides = mod16_amd._marshal([0.1, np.ones(3, np.float32)], (3,), np.float32)
+    assert keep[0].dtype == np.float32 and keep[0][0] == np.float32(0.1) and strides == [0, 1]
+    # a read-only dense input (a broadcast view made contiguous, a memory map opened 'r')
+    ro = np.ones(shape)
+    ro.flags.writeable = False
+    keep, ptrs, strides = mod16_amd._marshal([ro], shape, np.float64)
+    assert ptrs[0] == ro.ctypes.data and keep[0] is ro
 
 
 def test_result_arrays_fall_back_to_numpy_without_a_gpu():
@@ -141,11 +153,11 @@ def test_broadcast_kinds_are_not_made_dense():
               np.ones((1, N), np.float32)]
     keep, ptrs, kinds = mod16_amd._marshal(values, (T, N), np.float64, kinds=True)
     assert kinds == [_lib.BC_DENSE, _lib.BC_ROW, _lib.BC_COL, _lib.BC_SCALAR, _lib.BC_ROW]
-    assert [a.size for a in keep] == [T * N, N, T, 1, N]
+    assert [a.size for a in keep] == [T * N, N, T, len(values), N]      # (the size-1 inputs share one array)
     assert all(a.flags.c_contiguous and a.dtype == np.float64 for a in keep)
     # without the switch everything but scalars is dense, as before
     keep, ptrs, strides = mod16_amd._marshal(values, (T, N), np.float64)
-    assert strides == [1, 1, 1, 0, 1] and [a.size for a in keep] == [T * N, T * N, T * N, 1, T * N]
+    assert strides == [1, 1, 1, 0, 1] and [a.size for a in keep] == [T * N, T * N, T * N, len(values), T * N]
 
 
 def test_pmc_traffic_belongs_to_the_build(tmp_path):
