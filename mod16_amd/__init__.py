@@ -508,8 +508,7 @@ class MOD16(object):
         rc = list(r_corr_list) if r_corr_list is not None else []
         values = drivers + params + rc
         dtype = _result_dtype(values)
-        shape = np.broadcast_shapes(*[np.shape(v) for v in values])
-        n = int(np.prod(shape, dtype=np.int64))
+        shape, n = _broadcast([_shape(v) for v in values])
         keep_d, dptr, dstr = _marshal(drivers, shape, dtype)
         keep_p, pptr, pstr = _marshal(params, shape, dtype)
         keep_r, rptr, rstr = _marshal(rc, shape, dtype) if rc else (None, None, None)
@@ -522,8 +521,8 @@ class MOD16(object):
                 ctx.handle, _lib.ptr_array(dptr), _lib.i64_array(dstr),
                 _lib.ptr_array(pptr), _lib.i64_array(pstr),
                 _lib.ptr_array(rptr) if rc else None,
-                _lib.i64_array(rstr) if rc else None, n, day.ctypes.data,
-                night.ctypes.data, float(tiny), _lib.HOST, None))
+                _lib.i64_array(rstr) if rc else None, n, _address(day),
+                _address(night), float(tiny), _lib.HOST, None))
         if not shape:
             return [day[()], night[()]]
         return [day, night]

@@ -1783,6 +1783,30 @@ extern "C" int mod16_et_raw_f32(mod16_ctx* ctx, const uint8_t* cls, const float*
 }
 
 // ------------------------------------------- vectorised calibration path (N2)
+// HOST-mode workspace of the calibration entry points, kept in the context between calls (a
+// calibration loop repeats the same shape thousands of times): it only grows; above kBatchKeepBytes
+// it is given back after the call.
+constexpr size_t kBatchKeepBytes = size_t(8) << 30;
+static int batch_reserve(mod16_ctx* ctx, size_t total) {
+    if (ctx->batch_bytes >= total) return MOD16_OK;
+    if (ctx->batch_buf) HIPCHK(ctx, hipFree(ctx->batch_buf));
+    ctx->batch_buf = nullptr;
+    ctx->batch_bytes = 0;
+    if (hipMalloc(&ctx->batch_buf, total) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->batch_buf = nullptr;
+        return fail(ctx, MOD16_ERR_NOMEM, "mod16_et_static*: device memory for the calibration workspace");
+    }
+    ctx->batch_bytes = total;
+    return MOD16_OK;
+}
+static void batch_trim(mod16_ctx* ctx) {
+    if (ctx->batch_bytes <= kBatchKeepBytes) return;
+    (void)hipFree(ctx->batch_buf);
+    ctx->batch_buf = nullptr;
+    ctx->batch_bytes = 0;
+}
+
 template <typename T>
 static int static_entry(mod16_ctx* ctx, const T* const* drivers, const int64_t* dstride,
                         const T* const* params, const int64_t* pstride, const T* const* rcorr,
@@ -1830,18 +1854,48 @@ static int static_entry(mod16_ctx* ctx, const T* const* drivers, const int64_t* 
         return MOD16_OK;
     }
     if (where != MOD16_HOST) return fail(ctx, MOD16_ERR_ARG, "mod16_et_static: bad `where`");
+    constexpr int kArr = 14 + 11 + 2 + 2;
+    if (n <= ctx->small_pixels) {
+        // what a sampler calls once per draw (a few sites x a year): no allocation, no copy commands --
+        // the two kernels read the page-locked buffer and write their outputs there (run_host_small)
+        size_t per_arr = 0;
+        int rc = small_reserve(ctx, n, sizeof(T), kArr, &per_arr);
+        if (rc != MOD16_OK) return rc;
+        hipStream_t st = ctx->streams[0];
+        char* hb = static_cast<char*>(ctx->small_host);
+        char* db = static_cast<char*>(ctx->small_dev);
+        StaticArgs<T> d = a;
+        int slot = 0;
+        auto put = [&](const T* src, bool dense) -> const T* {
+            const size_t off = 256 + per_arr * slot++;
+            memcpy(hb + off, src, sizeof(T) * (dense ? n : 1));
+            return reinterpret_cast<const T*>(db + off);
+        };
+        for (int k = 0; k < 14; ++k) d.drv[k] = put(a.drv[k], (a.dense_drv >> k) & 1u);
+        for (int k = 0; k < 11; ++k) d.par[k] = put(a.par[k], (a.dense_par >> k) & 1u);
+        for (int k = 0; k < 2; ++k) d.rc[k] = a.rc[k] ? put(a.rc[k], (a.dense_rc >> k) & 1u) : nullptr;
+        const size_t o0 = 256 + per_arr * 27, o1 = 256 + per_arr * 28;
+        d.out[0] = reinterpret_cast<T*>(db + o0);
+        d.out[1] = reinterpret_cast<T*>(db + o1);
+        HIPCHK(ctx, hipMemsetAsync(d.flag, 0, sizeof(unsigned), st));
+        hipLaunchKernelGGL((static_flag_kernel<T>), dim3(grid_of(n)), dim3(kBlock), 0, st, d);
+        hipLaunchKernelGGL((static_kernel<T>), dim3(grid_of(n)), dim3(kBlock), 0, st, d);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        memcpy(out_day, hb + o0, sizeof(T) * n);
+        memcpy(out_night, hb + o1, sizeof(T) * n);
+        return MOD16_OK;
+    }
     // HOST: the whole-array branch needs every pixel before any output, so the
     // inputs are made resident once (calibration-sized arrays, not rasters)
-    constexpr int kArr = 14 + 11 + 2 + 2;
     const size_t per_arr = (((size_t)n * sizeof(T)) + 255) / 256 * 256;
-    void* buf = nullptr;
-    HIPCHK(ctx, hipMalloc(&buf, per_arr * kArr));
-    if (!ctx->streams[0]) {
-        hipError_t e = hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking);
-        if (e != hipSuccess) { (void)hipFree(buf); ctx->err = "hipStreamCreate failed"; return MOD16_ERR_HIP; }
-    }
+    // the workspace the context keeps between calibration calls (mod16_et_static_batch_* shares it;
+    // until round 5 this entry point allocated and freed its own on every call)
+    int rcw = batch_reserve(ctx, per_arr * kArr);
+    if (rcw != MOD16_OK) return rcw;
+    if (!ctx->streams[0]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking));
     hipStream_t st = ctx->streams[0];
-    char* base = static_cast<char*>(buf);
+    char* base = static_cast<char*>(ctx->batch_buf);
     StaticArgs<T> d = a;
     int slot = 0;
     int rc_status = MOD16_OK;
@@ -1866,7 +1920,7 @@ static int static_entry(mod16_ctx* ctx, const T* const* drivers, const int64_t* 
         if (hipMemcpyAsync(out_night, d.out[1], sizeof(T) * n, hipMemcpyDeviceToHost, st) != hipSuccess) rc_status = MOD16_ERR_HIP;
     }
     if (hipStreamSynchronize(st) != hipSuccess) rc_status = MOD16_ERR_HIP;
-    (void)hipFree(buf);
+    batch_trim(ctx);
     if (rc_status != MOD16_OK) ctx->err = "mod16_et_static: HIP call failed";
     return rc_status;
 }
@@ -1989,17 +2043,9 @@ static int static_batch_entry(mod16_ctx* ctx, const T* const* drivers, const int
     // workspace kept in the context between calls (a calibration loop repeats the same
     // shape thousands of times -- better still: mod16_static_batch_bind_*); it only grows, up to
     // kBatchKeepBytes it is kept
-    constexpr size_t kBatchKeepBytes = size_t(8) << 30;
-    if (ctx->batch_bytes < total) {
-        if (ctx->batch_buf) HIPCHK(ctx, hipFree(ctx->batch_buf));
-        ctx->batch_buf = nullptr;
-        ctx->batch_bytes = 0;
-        if (hipMalloc(&ctx->batch_buf, total) != hipSuccess) {
-            (void)hipGetLastError();
-            ctx->batch_buf = nullptr;
-            return fail(ctx, MOD16_ERR_NOMEM, "mod16_et_static_batch: device memory for the [ndraw][n] outputs");
-        }
-        ctx->batch_bytes = total;
+    {
+        int rcw = batch_reserve(ctx, total);
+        if (rcw != MOD16_OK) return rcw;
     }
     char* base = static_cast<char*>(ctx->batch_buf);
     int rc = MOD16_OK;
@@ -2036,11 +2082,7 @@ static int static_batch_entry(mod16_ctx* ctx, const T* const* drivers, const int
         }
     }
     chk(hipStreamSynchronize(st));
-    if (ctx->batch_bytes > kBatchKeepBytes) {
-        (void)hipFree(ctx->batch_buf);
-        ctx->batch_buf = nullptr;
-        ctx->batch_bytes = 0;
-    }
+    batch_trim(ctx);
     return rc;
 }
 

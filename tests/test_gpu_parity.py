@@ -700,12 +700,15 @@ def test_small_calls_give_the_bits_of_the_staged_path(m16, golden, n):
         out += list(model.evapotranspiration_and_pet(*d))
         out.append(model.evaporation_soil(d[11], d[5], d[9], d[12], np.abs(d[2])))
         out.append(m16.MOD16.rhumidity(d[5], d[9]))
+        # the calibration interface (mod16_et_static_*: its own small path, two kernels)
+        plist = [np.asarray(p, dtype) if np.ndim(p) else p for p in params]
+        out += list(m16.MOD16._evapotranspiration(plist, *d))
         return out
 
     for dtype in (np.float64, np.float32):
         small = run(dtype)
         staged = _in_a_fresh_thread(lambda: run(dtype), {'MOD16_SMALL_PIXELS': '0'})
-        assert len(small) == len(staged) == 24
+        assert len(small) == len(staged) == 26
         for i, (a, b) in enumerate(zip(small, staged)):
             assert a.dtype == dtype and _same_bits(a, b), (n, dtype, i)
     # and the oracle, value by value (the staged path's own tests hold it elsewhere)

@@ -87,5 +87,19 @@ def split():
     pstats.Stats(pr).sort_stats('tottime').print_stats(14)
 
 
+def static():
+    """MOD16._et (the calibration interface a sampler calls once per draw): a year of 1, 10, 30 and 120 sites."""
+    rng = np.random.default_rng(16)
+    par = [PARAMS[k] for k in mod16_amd.MOD16.required_parameters]
+    for sites in (1, 10, 30, 120, 400):
+        shape = (365, sites)
+        drv = [np.asarray(v, np.float64) * (1 + 0.01 * rng.uniform(-1, 1, shape)) for v in SITE]
+        mod16_amd.MOD16._et(par, *drv)
+        best, med = timed(lambda: mod16_amd.MOD16._et(par, *drv), 100)
+        print(json.dumps({'case': '_et, 365 days x %d sites' % sites, 'pixels': 365 * sites, 'gpu_call_us_best': round(best * 1e6, 1),
+                          'gpu_call_us_median': round(med * 1e6, 1),
+                          'small_pixels': os.environ.get('MOD16_SMALL_PIXELS', 'default')}), flush=True)
+
+
 if __name__ == '__main__':
-    split() if 'split' in sys.argv[1:] else main()
+    {'split': split, 'static': static}.get(sys.argv[1] if len(sys.argv) > 1 else '', main)()
