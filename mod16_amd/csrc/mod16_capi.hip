@@ -856,13 +856,13 @@ static int stage_tile(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags, const 
 }
 
 // The page-locked buffer of the small calls: 256 bytes of scalars, `arrays` arrays of `elem`-byte
-// values and one of bytes, for n pixels. It grows with the largest call seen (powers of two from 1024
+// values and up to three of bytes behind them, for n pixels. It grows with the largest call seen (powers of two from 1024
 // pixels: a caller of scalars pins 0.3 MB, one of 256 x 256 windows 18 MB). Also makes sure of streams[0].
 static int small_reserve(mod16_ctx* ctx, int64_t n, size_t elem, int arrays, size_t* per_arr) {
     int64_t cap = 1024;
     while (cap < n) cap *= 2;
     *per_arr = (size_t)cap * elem;
-    const size_t need = 256 + *per_arr * arrays + (size_t)cap + 256;
+    const size_t need = 256 + *per_arr * arrays + 3 * (size_t)cap + 256;
     if (ctx->small_bytes < need) {
         if (ctx->small_host) HIPCHK(ctx, hipHostFree(ctx->small_host));
         ctx->small_host = ctx->small_dev = nullptr;
@@ -1666,6 +1666,65 @@ static int raw_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* raw,
         return MOD16_OK;
     }
     if (where != MOD16_HOST) return fail(ctx, MOD16_ERR_ARG, "mod16_et_raw: bad `where`");
+    if (n <= ctx->small_pixels) {
+        // small calls: no copy commands, the kernel reads and writes one page-locked buffer
+        // (run_host_small; whole vectors, the pad pixels repeat the last one; classes checked here)
+        for (int64_t i = 0; i < n; ++i)
+            if (cls[i] >= MOD16_N_CLASSES)
+                return fail(ctx, MOD16_ERR_CLASS_RANGE, "class raster holds a code >= 13 (numpy would raise IndexError)");
+        size_t per_arr = 0;
+        int rc = small_reserve(ctx, n, sizeof(T), 14 + 1 + 3, &per_arr);
+        if (rc != MOD16_OK) return rc;
+        hipStream_t st = ctx->streams[0];
+        char* hb = static_cast<char*>(ctx->small_host);
+        char* db = static_cast<char*>(ctx->small_dev);
+        T* hsc = reinterpret_cast<T*>(hb);
+        const T* dscal = reinterpret_cast<const T*>(db);
+        constexpr int V = VecOf<T>::v;
+        const int64_t npad = (n + V - 1) / V * V;
+        const size_t per_b = per_arr / sizeof(T);       // the buffer's capacity in pixels
+        auto arr = [&](int k) { return (size_t)256 + per_arr * k; };
+        auto put = [&](size_t off, const void* src, size_t elem) {
+            memcpy(hb + off, src, elem * n);
+            for (int64_t i = n; i < npad; ++i) memcpy(hb + off + elem * i, static_cast<const char*>(src) + elem * (n - 1), elem);
+        };
+        RawArgs<T> d = a;
+        d.n = npad;
+        for (int k = 0; k < 14; ++k) {
+            if ((a.dense_drv >> k) & 1u) {
+                put(arr(k), a.drv[k], sizeof(T));
+                d.drv[k] = reinterpret_cast<const T*>(db + arr(k));
+            } else {
+                hsc[k] = a.drv[k][0];
+                d.drv[k] = dscal + k;
+            }
+        }
+        T host_hours = T(0);
+        if (a.day_hours) {
+            if (a.dense_hours) {
+                put(arr(14), a.day_hours, sizeof(T));
+                d.day_hours = reinterpret_cast<const T*>(db + arr(14));
+            } else {
+                host_hours = hsc[14] = a.day_hours[0];
+                d.day_hours = dscal + 14;
+            }
+        }
+        const uint8_t* hbytes[3] = {a.fpar_pct, a.lai_x10, a.cls};
+        const uint8_t** dbytes[3] = {&d.fpar_pct, &d.lai_x10, &d.cls};
+        for (int k = 0; k < 3; ++k) {
+            const size_t off = arr(18) + per_b * k;
+            put(off, hbytes[k], 1);
+            *dbytes[k] = reinterpret_cast<const uint8_t*>(db + off);
+        }
+        for (int k = 0; k < 3; ++k) d.out[k] = a.out[k] ? reinterpret_cast<T*>(db + arr(15 + k)) : nullptr;
+        rc = launch(d, st, (a.day_hours && !a.dense_hours) ? &host_hours : nullptr);
+        if (rc != MOD16_OK) return rc;
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        for (int k = 0; k < 3; ++k)
+            if (a.out[k]) memcpy(a.out[k], hb + arr(15 + k), sizeof(T) * n);
+        return MOD16_OK;
+    }
     // HOST: tiles of kTilePixels staged through the context's slabs, one host thread and one stream
     // per slot, as run_host does for the processed drivers (round 5; one slab and one thread before:
     // the copies from pageable memory, which the runtime stages on the calling thread, are what bounds

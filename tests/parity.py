@@ -57,3 +57,45 @@ def assert_mixed_parity(got, want, what='', rtol=1e-3, atol_of_max=1e-6):
         bound = np.maximum(rtol * np.abs(w[ok]), atol_of_max * np.abs(w[ok]).max())
         worst = float((err / bound).max())
         assert worst <= 1, '%s: %.3g x the mixed form\'s tolerance' % (what, worst)
+
+
+def in_a_fresh_thread(fn, env):
+    """Runs fn in a new thread -- a new context (mod16_amd._lib.context is per thread), created
+    with `env` in the environment (the library reads its two knobs when a context is made)."""
+    import os
+    import threading
+    box = {}
+
+    def body():
+        try:
+            box['value'] = fn()
+        except BaseException as exc:      # handed to the caller
+            box['error'] = exc
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        t = threading.Thread(target=body)
+        t.start()
+        t.join()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    if 'error' in box:
+        raise box['error']
+    return box['value']
+
+
+def same_bits(a, b):
+    """Same shape, dtype, NaN positions, and the same BITS in every other value (signed zeros told
+    apart). NaN payloads are not compared: which NaN an invalid pixel yields is not part of the result."""
+    a, b = np.atleast_1d(np.asarray(a)), np.atleast_1d(np.asarray(b))
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    na, nb = np.isnan(a), np.isnan(b)
+    if not np.array_equal(na, nb):
+        return False
+    u = {4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+    return bool(np.array_equal(np.ascontiguousarray(a).view(u)[~na], np.ascontiguousarray(b).view(u)[~nb]))

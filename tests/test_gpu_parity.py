@@ -12,7 +12,7 @@ import pytest
 
 from oracle import mod16_oracle as oracle
 from oracle import synth
-from parity import assert_mixed_parity, assert_parity
+from parity import assert_mixed_parity, assert_parity, in_a_fresh_thread, same_bits
 
 pytestmark = pytest.mark.gpu
 
@@ -640,40 +640,6 @@ def test_special_value_pairs_fast_kernel(m16, golden):
             assert_parity(g, w, 1e-8, period + ' ' + part)
 
 
-def _in_a_fresh_thread(fn, env):
-    """Runs fn in a new thread -- a new context (mod16_amd._lib.context is per thread), created
-    with `env` in the environment (the library reads its two knobs when a context is made)."""
-    import os
-    import threading
-    box = {}
-
-    def body():
-        try:
-            box['value'] = fn()
-        except BaseException as exc:      # handed to the caller
-            box['error'] = exc
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        t = threading.Thread(target=body)
-        t.start()
-        t.join()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    if 'error' in box:
-        raise box['error']
-    return box['value']
-
-
-def _same_bits(a, b):
-    a, b = np.asarray(a), np.asarray(b)
-    return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
-
-
 @pytest.mark.parametrize('n', [1, 2, 3, 5, 365, 1025, 65535, 65536, 65537])
 def test_small_calls_give_the_bits_of_the_staged_path(m16, golden, n):
     """HOST mode, calls of up to 65536 pixels: no copy commands -- the kernel reads its inputs
@@ -707,10 +673,10 @@ def test_small_calls_give_the_bits_of_the_staged_path(m16, golden, n):
 
     for dtype in (np.float64, np.float32):
         small = run(dtype)
-        staged = _in_a_fresh_thread(lambda: run(dtype), {'MOD16_SMALL_PIXELS': '0'})
+        staged = in_a_fresh_thread(lambda: run(dtype), {'MOD16_SMALL_PIXELS': '0'})
         assert len(small) == len(staged) == 26
         for i, (a, b) in enumerate(zip(small, staged)):
-            assert a.dtype == dtype and _same_bits(a, b), (n, dtype, i)
+            assert a.dtype == dtype and same_bits(a, b), (n, dtype, i)
     # and the oracle, value by value (the staged path's own tests hold it elsewhere)
     bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
     wd, wn = oracle.evapotranspiration_raster(bplut, cls, *drv)
@@ -721,8 +687,8 @@ def test_small_calls_give_the_bits_of_the_staged_path(m16, golden, n):
     bad[n // 2] = 13
     for env in ({}, {'MOD16_SMALL_PIXELS': '0'}):
         with pytest.raises(IndexError):
-            _in_a_fresh_thread(lambda: m16.evapotranspiration_raster(table, bad, *drv), env)
-    assert _same_bits(m16.evapotranspiration_raster(table, cls, *drv)[0], small_f64)
+            in_a_fresh_thread(lambda: m16.evapotranspiration_raster(table, bad, *drv), env)
+    assert same_bits(m16.evapotranspiration_raster(table, cls, *drv)[0], small_f64)
 
 
 def test_scalar_site_call_through_the_small_path(m16, golden):

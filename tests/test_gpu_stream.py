@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 from oracle import mod16_oracle as oracle
-from parity import assert_parity
+from parity import assert_parity, in_a_fresh_thread, same_bits
 
 pytestmark = pytest.mark.gpu
 
@@ -239,3 +239,44 @@ def test_pipeline_at_piece_run_and_chip_boundaries(env, dtype):
             want = plain.run_raw(rcls[:n], [a[:n] for a in raw], fpar[:n], lai[:n], day_hours=h)
             for a, b in zip(got, want):
                 assert_same_bits(a.cpu().numpy(), b.cpu().numpy(), 'raw drivers, n = %d' % n)
+
+
+@pytest.mark.parametrize('n', [1, 7, 365, 4099, 65536])
+def test_small_raw_calls_give_the_bits_of_the_staged_path(env, n):
+    """evapotranspiration_raw on numpy arrays of up to 65536 pixels: the kernel reads and writes one
+    page-locked buffer (the small path of mod16_et_raw_*, mod16_capi.hip) -- the staged path's bits
+    (MOD16_SMALL_PIXELS=0), every hours-of-daylight form, float64 and float32 (FAST and MIXED);
+    a class code numpy would refuse is an IndexError from both."""
+    torch, RasterEngine, table = env
+    import mod16_amd
+    _lib = mod16_amd._lib
+
+    def run(dtype, math):
+        cls, raw, fpar, lai, hours = raw_inputs(n, 77 + n, dtype)
+        scal = list(raw)
+        scal[13] = float(raw[13][0])           # elevation as a broadcast scalar
+        out = list(mod16_amd.evapotranspiration_raw(table, cls, *raw, fpar, lai, day_hours=hours, math=math))
+        out += list(mod16_amd.evapotranspiration_raw(table, cls, *scal, fpar, lai, day_hours=11.5, math=math))
+        out += list(mod16_amd.evapotranspiration_raw(table, cls, *raw, fpar, lai, math=math))
+        return out
+
+    for dtype, math in ((np.float64, _lib.MATH_FAST), (np.float64, _lib.MATH_EXACT),
+                        (np.float32, _lib.MATH_FAST), (np.float32, _lib.MATH_MIXED)):
+        small = run(dtype, math)
+        staged = in_a_fresh_thread(lambda: run(dtype, math), {'MOD16_SMALL_PIXELS': '0'})
+        assert len(small) == len(staged) == 8
+        for i, (a, b) in enumerate(zip(small, staged)):
+            assert a.dtype == dtype
+            if math == _lib.MATH_MIXED:
+                # (a ragged end is computed by the one-pixel kernel in float64 arithmetic on the staged
+                # path and, padded to whole vectors, by the mixed-precision pipeline here: the mixed
+                # form's own tolerance between them, not bits)
+                assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a == 0, b == 0), (n, i)
+                assert np.allclose(a, b, rtol=2e-3, atol=1e-6 * np.nanmax(np.abs(b), initial=0.0), equal_nan=True), (n, i)
+            else:
+                assert same_bits(a, b), (n, dtype, math, i)
+    cls, raw, fpar, lai, hours = raw_inputs(n, 77 + n, np.float64)
+    cls[n - 1] = 13
+    for envv in ({}, {'MOD16_SMALL_PIXELS': '0'}):
+        with pytest.raises(IndexError):
+            in_a_fresh_thread(lambda: mod16_amd.evapotranspiration_raw(table, cls, *raw, fpar, lai), envv)
