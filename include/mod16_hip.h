@@ -18,6 +18,12 @@
  *   - `where` says whether the data pointers are HOST (pageable or pinned
  *     memory; the call stages tiles through the GPU and is synchronous) or
  *     DEVICE (zero-copy, asynchronous on `stream`, a hipStream_t or NULL);
+ *     HOST calls of at most MOD16_SMALL_PIXELS pixels (environment, default
+ *     65536, 0 = never; mod16_et_*, mod16_et_raw_*, mod16_method_*,
+ *     mod16_et_static_*) issue no copy commands: the kernel reads its inputs
+ *     from a page-locked buffer of the ctx and writes its outputs there (one
+ *     launch, one synchronisation; same kernels, same results), and a class
+ *     code >= 13 is found before anything is launched;
  *   - a ctx serialises the calls made on it (every entry point holds the ctx's
  *     mutex), so sharing one between host threads is safe; for concurrency use
  *     one ctx per host thread and GPU (each owns its staging slabs, streams,
