@@ -24,6 +24,12 @@
  *     from a page-locked buffer of the ctx and writes its outputs there (one
  *     launch, one synchronisation; same kernels, same results), and a class
  *     code >= 13 is found before anything is launched;
+ *   - DEVICE launches of one ctx share its diagnostics workspace: on ONE stream
+ *     they are ordered anyway and nothing is added between them; the first
+ *     launch a ctx makes on a second stream waits for the device once, and
+ *     from then on every launch records an event the next one on another
+ *     stream waits for (a stream may be destroyed by its owner at any time:
+ *     the library never touches a stream it is not launching on);
  *   - a ctx serialises the calls made on it (every entry point holds the ctx's
  *     mutex), so sharing one between host threads is safe; for concurrency use
  *     one ctx per host thread and GPU (each owns its staging slabs, streams,
