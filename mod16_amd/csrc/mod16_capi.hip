@@ -28,7 +28,8 @@ constexpr int kDiagBlocks = 1024;
 constexpr int kSlots = 12;                          // staging slots = host threads of the HOST mode
 constexpr size_t kStagger = 33 * 1024;              // see RasterEngine.STAGGER_BYTES
 constexpr int kSmallPixels = 65536;                 // HOST mode: calls up to this size take the copy-free path
-constexpr int kSmallPixelsMax = 1 << 18;             // ... and what MOD16_SMALL_PIXELS may raise it to
+constexpr int kSmallPixelsMax = 1 << 18;
+constexpr int kSmallUnavailable = 1;                // run_host_small: no page-locked buffer -- the caller stages the call             // ... and what MOD16_SMALL_PIXELS may raise it to
 }  // namespace
 
 // Workspace of the per-run diagnostics partials of et_stream_kernel (and of the
@@ -858,21 +859,30 @@ static int stage_tile(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags, const 
 // The page-locked buffer of the small calls: 256 bytes of scalars, `arrays` arrays of `elem`-byte
 // values and up to three of bytes behind them, for n pixels. It grows with the largest call seen (powers of two from 1024
 // pixels: a caller of scalars pins 0.3 MB, one of 256 x 256 windows 18 MB). Also makes sure of streams[0].
-static int small_reserve(mod16_ctx* ctx, int64_t n, size_t elem, int arrays, size_t* per_arr) {
+// -> false: no page-locked memory to be had (the context stops asking: its calls are staged from now on).
+static bool small_reserve(mod16_ctx* ctx, int64_t n, size_t elem, int arrays, size_t* per_arr) {
     int64_t cap = 1024;
     while (cap < n) cap *= 2;
     *per_arr = (size_t)cap * elem;
     const size_t need = 256 + *per_arr * arrays + 3 * (size_t)cap + 256;
+    bool ok = true;
     if (ctx->small_bytes < need) {
-        if (ctx->small_host) HIPCHK(ctx, hipHostFree(ctx->small_host));
+        if (ctx->small_host) (void)hipHostFree(ctx->small_host);
         ctx->small_host = ctx->small_dev = nullptr;
         ctx->small_bytes = 0;
-        HIPCHK(ctx, hipHostMalloc(&ctx->small_host, need, hipHostMallocDefault));
-        HIPCHK(ctx, hipHostGetDevicePointer(&ctx->small_dev, ctx->small_host, 0));
-        ctx->small_bytes = need;
+        ok = hipHostMalloc(&ctx->small_host, need, hipHostMallocDefault) == hipSuccess &&
+             hipHostGetDevicePointer(&ctx->small_dev, ctx->small_host, 0) == hipSuccess;
+        if (ok) ctx->small_bytes = need;
     }
-    if (!ctx->streams[0]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking));
-    return MOD16_OK;
+    if (ok && !ctx->streams[0]) ok = hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        if (ctx->small_host) (void)hipHostFree(ctx->small_host);
+        ctx->small_host = ctx->small_dev = nullptr;
+        ctx->small_bytes = 0;
+        ctx->small_pixels = 0;
+    }
+    return ok;
 }
 
 // HOST mode, small calls. The staged path costs a dozen copy commands whatever the size (each
@@ -892,8 +902,7 @@ template <typename T>
 static int run_host_small(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
     const int64_t n = h.n;
     size_t per_arr = 0;
-    int rc0 = small_reserve(ctx, n, sizeof(T), 14 + 11 + 10, &per_arr);
-    if (rc0 != MOD16_OK) return rc0;
+    if (!small_reserve(ctx, n, sizeof(T), 14 + 11 + 10, &per_arr)) return kSmallUnavailable;
     hipStream_t st = ctx->streams[0];
     if (h.cls) {       // (dense: a broadcast class raster is has_rows_or_cols' business)
         for (int64_t i = 0; i < n; ++i)
@@ -956,7 +965,10 @@ template <typename T>
 static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags, double* tile_diag = nullptr) {
     const int64_t n = h.n;
     if (n == 0) return MOD16_OK;
-    if (n <= ctx->small_pixels && !tile_diag && !has_rows_or_cols(h)) return run_host_small<T>(ctx, h, flags);
+    if (n <= ctx->small_pixels && !tile_diag && !has_rows_or_cols(h)) {
+        const int rc = run_host_small<T>(ctx, h, flags);
+        if (rc != kSmallUnavailable) return rc;
+    }
     const int64_t tile = std::min<int64_t>(n, kTilePixels);
     const int64_t ntiles = (n + tile - 1) / tile;
     const int nslots = (int)std::min<int64_t>(ntiles, ctx->host_threads);
@@ -1457,12 +1469,11 @@ static int method_entry(mod16_ctx* ctx, int method, const T* const* in, const in
         return MOD16_OK;
     }
     if (where != MOD16_HOST) return fail(ctx, MOD16_ERR_ARG, "mod16_method: bad `where`");
-    if (n <= ctx->small_pixels) {
+    size_t per_arr_small = 0;
+    if (n <= ctx->small_pixels && small_reserve(ctx, n, sizeof(T), kMethodMaxIn + 11 + 2, &per_arr_small)) {
+        const size_t per_arr = per_arr_small;
         // small calls (what the class surface is used for: scalars, a site's series): no copy
         // commands, the kernel reads and writes one page-locked buffer (run_host_small)
-        size_t per_arr = 0;
-        int rc = small_reserve(ctx, n, sizeof(T), kMethodMaxIn + 11 + 2, &per_arr);
-        if (rc != MOD16_OK) return rc;
         hipStream_t st = ctx->streams[0];
         char* hb = static_cast<char*>(ctx->small_host);
         char* db = static_cast<char*>(ctx->small_dev);
@@ -1666,15 +1677,15 @@ static int raw_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* raw,
         return MOD16_OK;
     }
     if (where != MOD16_HOST) return fail(ctx, MOD16_ERR_ARG, "mod16_et_raw: bad `where`");
-    if (n <= ctx->small_pixels) {
+    size_t per_arr_small = 0;
+    if (n <= ctx->small_pixels && small_reserve(ctx, n, sizeof(T), 14 + 1 + 3, &per_arr_small)) {
         // small calls: no copy commands, the kernel reads and writes one page-locked buffer
         // (run_host_small; whole vectors, the pad pixels repeat the last one; classes checked here)
         for (int64_t i = 0; i < n; ++i)
             if (cls[i] >= MOD16_N_CLASSES)
                 return fail(ctx, MOD16_ERR_CLASS_RANGE, "class raster holds a code >= 13 (numpy would raise IndexError)");
-        size_t per_arr = 0;
-        int rc = small_reserve(ctx, n, sizeof(T), 14 + 1 + 3, &per_arr);
-        if (rc != MOD16_OK) return rc;
+        const size_t per_arr = per_arr_small;
+        int rc = MOD16_OK;
         hipStream_t st = ctx->streams[0];
         char* hb = static_cast<char*>(ctx->small_host);
         char* db = static_cast<char*>(ctx->small_dev);
@@ -1914,12 +1925,11 @@ static int static_entry(mod16_ctx* ctx, const T* const* drivers, const int64_t* 
     }
     if (where != MOD16_HOST) return fail(ctx, MOD16_ERR_ARG, "mod16_et_static: bad `where`");
     constexpr int kArr = 14 + 11 + 2 + 2;
-    if (n <= ctx->small_pixels) {
+    size_t per_arr_small = 0;
+    if (n <= ctx->small_pixels && small_reserve(ctx, n, sizeof(T), kArr, &per_arr_small)) {
         // what a sampler calls once per draw (a few sites x a year): no allocation, no copy commands --
         // the two kernels read the page-locked buffer and write their outputs there (run_host_small)
-        size_t per_arr = 0;
-        int rc = small_reserve(ctx, n, sizeof(T), kArr, &per_arr);
-        if (rc != MOD16_OK) return rc;
+        const size_t per_arr = per_arr_small;
         hipStream_t st = ctx->streams[0];
         char* hb = static_cast<char*>(ctx->small_host);
         char* db = static_cast<char*>(ctx->small_dev);

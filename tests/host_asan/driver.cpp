@@ -16,6 +16,7 @@
 
 extern "C" void mod16_stub_report(FILE* f);
 extern "C" size_t mod16_stub_live_allocations(void);
+extern "C" void mod16_stub_fail_host_malloc(int k);
 
 static int g_checks = 0;
 #define EXPECT(cond)                                                                       \
@@ -335,6 +336,31 @@ int main(int argc, char** argv) {
                                      cnt.data(), MOD16_MATH_EXACT, MOD16_HOST, nullptr));
     }
     EXPECT(mod16_destroy(ctx) == MOD16_OK);
+    {   // no page-locked memory for the small calls' buffer: the call is staged instead (and the
+        // context stops asking), every entry point that has the small path
+        mod16_ctx* c2 = nullptr;
+        EXPECT(mod16_create(0, &c2) == MOD16_OK && c2);
+        ctx = c2;
+        OK(mod16_set_bplut_f64(ctx, lut));
+        const int64_t n = 9;
+        std::vector<std::vector<double>> drv(14, std::vector<double>(n, 280.0)), par(11, std::vector<double>(n, 2.0));
+        std::vector<uint8_t> cls(n, 1), fpar(n, 50), lai(n, 20);
+        std::vector<double> day(n), night(n);
+        const double *dp[14], *pp[11];
+        int64_t ds[14], ps[11];
+        for (int k = 0; k < 14; ++k) { dp[k] = drv[k].data(); ds[k] = 1; }
+        for (int k = 0; k < 11; ++k) { pp[k] = par[k].data(); ps[k] = 1; }
+        mod16_stub_fail_host_malloc(1000);
+        OK(mod16_et_f64(ctx, cls.data(), dp, ds, nullptr, nullptr, n, day.data(), night.data(), nullptr, MOD16_MATH_FAST, MOD16_HOST, nullptr));
+        OK(mod16_et_static_f64(ctx, dp, ds, pp, ps, nullptr, nullptr, n, day.data(), night.data(), 1e-7, MOD16_HOST, nullptr));
+        OK(mod16_et_raw_f64(ctx, cls.data(), dp, ds, fpar.data(), lai.data(), nullptr, 0, n, day.data(), night.data(), nullptr, MOD16_MATH_FAST, MOD16_HOST, nullptr));
+        const double* in[13] = {dp[5], dp[9]};
+        int64_t is[13] = {1, 1};
+        double* outs[2] = {day.data(), nullptr};
+        OK(mod16_method_f64(ctx, MOD16_M_RHUMIDITY, in, is, nullptr, nullptr, n, outs, 1.26, 1e-7, MOD16_HOST, nullptr));
+        mod16_stub_fail_host_malloc(0);
+        EXPECT(mod16_destroy(ctx) == MOD16_OK);
+    }
     mod16_stub_report(stdout);
     // everything the library allocated is gone with its context
     EXPECT(mod16_stub_live_allocations() == 0);

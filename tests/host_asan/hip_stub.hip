@@ -336,7 +336,10 @@ hipError_t hipMallocAsync(void** p, size_t bytes, hipStream_t) { return hipMallo
 hipError_t hipFreeAsync(void* p, hipStream_t) { return stub::release(p); }
 // page-locked host memory is in the device's address space too (the HOST mode's small calls hand it
 // to their kernels): a tracked block like any other, always real memory
+static int g_fail_host_malloc = 0;      // mod16_stub_fail_host_malloc(k): the next k hipHostMalloc calls fail
+extern "C" void mod16_stub_fail_host_malloc(int k) { g_fail_host_malloc = k; }
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
+    if (g_fail_host_malloc > 0) { --g_fail_host_malloc; *p = nullptr; return hipErrorOutOfMemory; }
     if (bytes >= stub::kRealBelow) stub::die("hipHostMalloc of %zu bytes: the library pins small buffers only", bytes);
     *p = stub::alloc(bytes);
     return *p ? hipSuccess : hipErrorOutOfMemory;
