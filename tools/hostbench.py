@@ -18,7 +18,7 @@ from _drivers import drivers as synth_drivers  # noqa: E402
 
 def main():
     table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
-    for shape in ((600, 600), (1200, 1200), (2400, 2400), (4800, 4800), (9600, 9600)):
+    for shape in ((400, 400), (600, 600), (800, 800), (1200, 1200), (1440, 1440), (2400, 2400), (4800, 4800), (9600, 9600)):
         cls, drv = synth_drivers(shape, seed=16)
         mod16_amd.evapotranspiration_raster(table, cls, *drv)      # warm-up (allocations)
         ts = []
