@@ -91,6 +91,39 @@ def test_result_dtype_follows_numpy_rules():
     assert rd([1.0, 2.0]) == f64
 
 
+def test_cheap_marshalling_helpers_agree_with_numpy():
+    """The call on a flux-tower site's scalars spends its time in the marshalling, so the dtype
+    rule, the shapes and the broadcast are computed without numpy's general machinery where the
+    answer is obvious -- and must be numpy's answer everywhere: every combination of up to three
+    of these inputs."""
+    import itertools
+    cands = [1.0, 2, True, np.float32(1), np.float64(1), np.ones(3, np.float32), np.ones(3),
+             np.ones(3, np.uint8), np.ones(3, np.int16), np.ones(3, np.float16), np.int64(3),
+             [1.0, 2.0, 3.0], np.ones((2, 3), np.float32), np.ones((2, 1)), np.ones(()), np.ma.masked_array([1.0, 2.0, 3.0])]
+
+    def numpy_rule(values):
+        strong = [np.asarray(v).dtype for v in values if isinstance(v, (np.ndarray, np.generic))]
+        if strong and np.result_type(*strong) == np.float32:
+            return np.dtype(np.float32)
+        return np.dtype(np.float64)
+    for r in (1, 2, 3):
+        for combo in itertools.product(cands, repeat=r):
+            assert mod16_amd._result_dtype(combo) == numpy_rule(combo), [type(c) for c in combo]
+            shapes = [mod16_amd._shape(v) for v in combo]
+            assert shapes == [np.shape(v) for v in combo]
+            shape, n = mod16_amd._broadcast(shapes)
+            assert shape == np.broadcast_shapes(*shapes) and n == int(np.prod(shape, dtype=np.int64))
+    assert mod16_amd._broadcast([(0, 3), (1, 3)]) == ((0, 3), 0)
+    with pytest.raises(ValueError):
+        mod16_amd._broadcast([(2,), (3,)])
+    # addresses: the buffer protocol where it applies, the array interface otherwise -- the same number
+    for a in (np.ones(5), np.ones((2, 3), np.float32), np.ones(0), np.broadcast_to(np.ones(3), (2, 3)).copy()):
+        assert mod16_amd._address(a) == a.ctypes.data
+    ro = np.ones(4)
+    ro.flags.writeable = False
+    assert mod16_amd._address(ro) == ro.ctypes.data
+
+
 def test_marshal_strides_and_broadcast():
     shape = (4, 5)
     vals = [3.0, np.arange(5.0), np.ones(shape), np.float32(2)]
