@@ -707,3 +707,38 @@ def test_scalar_site_call_through_the_small_path(m16, golden):
         d32, _ = m.evapotranspiration(*big)
         assert d32.dtype == np.float32 and d32.shape == (3000,)
         assert abs(float(d32[0]) / float(day) - 1) < 1e-6
+
+
+def test_small_calls_from_several_threads(m16, golden):
+    """The reference's functions are pure and may be called from several threads (SURVEY.md
+    section 8b): every thread has its own context -- and its own page-locked buffer for small
+    calls. Four threads, interleaved scalar / site-year / window calls with their own inputs:
+    each result equals the one the main thread computes for those inputs."""
+    import threading
+    f = golden('f1_tests_scalars')
+    m = model(m16, [float(p) for p in f['params']], 'fast')
+    base = [float(x) for x in f['drivers']]
+
+    def inputs(seed, shape):
+        rng = np.random.default_rng(seed)
+        return [b * (1 + 0.01 * rng.uniform(-1, 1, shape)) if shape else b * (1 + 0.001 * seed) for b in base]
+    cases = [(seed, shape) for seed in range(12) for shape in ((), (365,), (40, 50))]
+    want = {c: m.evapotranspiration(*inputs(*c)) for c in cases}
+    errors = []
+
+    def worker(k):
+        try:
+            for rep in range(20):
+                for c in cases[k::4]:
+                    got = m.evapotranspiration(*inputs(*c))
+                    for g, w in zip(got, want[c]):
+                        if not same_bits(g, w):
+                            errors.append((k, c))
+        except BaseException as exc:      # noqa: BLE001 -- reported below
+            errors.append((k, repr(exc)))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
