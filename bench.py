@@ -842,6 +842,7 @@ def build_summary(line):
         'plain_ms': roof.get('plain_ms'), 'plain_frac': roof.get('plain_frac'),
         'c1_scalar_call_us': _dig(c1, 'scalars', 'call_us'), 'c1_scalar_numpy_us': _dig(c1, 'scalars', 'numpy_oracle_us'),
         'c1_year_call_us': _dig(c1, 'site_year_365', 'call_us'), 'c1_year_numpy_us': _dig(c1, 'site_year_365', 'numpy_oracle_us'),
+        'c1_et_static_call_us': _dig(c1, 'et_static_365x30', 'call_us'), 'c1_et_static_numpy_us': _dig(c1, 'et_static_365x30', 'numpy_oracle_us'),
         'c2_us': c2.get('tile_us_per_launch'), 'c2_us_no_diag': c2.get('tile_us_per_launch_without_diagnostics'),
         'c2_batch64_us_per_tile': c2.get('batch64_us_per_tile'),
         'c4_ms_per_step': c4.get('ms_per_step'),
@@ -984,6 +985,17 @@ def single_site_config(np, oracle):
         obest, omed = timed(lambda: oracle.evapotranspiration(params, *drv), 30)
         out[name] = {'pixels': int(np.prod(shape, dtype=np.int64)) if shape else 1, 'call_us': best, 'call_us_median': med,
                      'numpy_oracle_us': obest, 'numpy_oracle_us_median': omed, 'max_rel_err_vs_oracle': err}
+    # the calibration interface a sampler calls once per draw (reference mod16/__init__.py:162-193): a year of 30 sites
+    plist = [params[k] for k in mod16_amd.MOD16.required_parameters]
+    drv = [float(v) * (1 + 0.01 * rng.uniform(-1, 1, (365, 30))) for v in f1['drivers']]
+    got = mod16_amd.MOD16._et(plist, *drv)
+    want = oracle.et_static(plist, *drv)
+    ok = np.isfinite(want) & (want != 0)
+    err = float(np.max(np.abs(got[ok] - want[ok]) / np.abs(want[ok])))
+    best, med = timed(lambda: mod16_amd.MOD16._et(plist, *drv), 100)
+    obest, omed = timed(lambda: oracle.et_static(plist, *drv), 10)
+    out['et_static_365x30'] = {'pixels': 365 * 30, 'call_us': best, 'call_us_median': med, 'numpy_oracle_us': obest,
+                               'numpy_oracle_us_median': omed, 'max_rel_err_vs_oracle': err}
     out['note'] = ('wall clock of one MOD16.evapotranspiration() call (numpy in, numpy out, PCIe and Python included); '
                    'round 4 took 124 us for the scalars -- slower than the reference\'s numpy (86 us)')
     return out
