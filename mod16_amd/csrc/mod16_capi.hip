@@ -28,8 +28,8 @@ constexpr int kDiagBlocks = 1024;
 constexpr int kSlots = 12;                          // staging slots = host threads of the HOST mode
 constexpr size_t kStagger = 33 * 1024;              // see RasterEngine.STAGGER_BYTES
 constexpr int kSmallPixels = 65536;                 // HOST mode: calls up to this size take the copy-free path
-constexpr int kSmallPixelsMax = 1 << 18;
-constexpr int kSmallUnavailable = 1;                // run_host_small: no page-locked buffer -- the caller stages the call             // ... and what MOD16_SMALL_PIXELS may raise it to
+constexpr int kSmallPixelsMax = 1 << 18;            // ... and what MOD16_SMALL_PIXELS may raise it to
+constexpr int kSmallUnavailable = 1;                // run_host_small: no page-locked buffer -- the caller stages the call
 }  // namespace
 
 // Workspace of the per-run diagnostics partials of et_stream_kernel (and of the
@@ -857,9 +857,10 @@ static int stage_tile(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags, const 
 }
 
 // The page-locked buffer of the small calls: 256 bytes of scalars, `arrays` arrays of `elem`-byte
-// values and up to three of bytes behind them, for n pixels. It grows with the largest call seen (powers of two from 1024
-// pixels: a caller of scalars pins 0.3 MB, one of 256 x 256 windows 18 MB). Also makes sure of streams[0].
-// -> false: no page-locked memory to be had (the context stops asking: its calls are staged from now on).
+// values and up to three of bytes behind them, for n pixels. It grows with the largest call seen
+// (powers of two from 1024 pixels: a caller of scalars pins 0.3 MB, one of 256 x 256 windows 18 MB).
+// Also makes sure of streams[0]. -> false: no page-locked memory to be had (the context stops
+// asking: its calls are staged from now on).
 static bool small_reserve(mod16_ctx* ctx, int64_t n, size_t elem, int arrays, size_t* per_arr) {
     int64_t cap = 1024;
     while (cap < n) cap *= 2;
@@ -892,12 +893,11 @@ static bool small_reserve(mod16_ctx* ctx, int64_t n, size_t elem, int arrays, si
 // Measured against it (tools/smallcall.py, profiles/r05_small_calls.jsonl): 18 us against 64 for one
 // pixel, 102 against 273 at 100 x 100, 371 against 420 at 256 x 256, even at ~90 k pixels, slower
 // beyond (the CPU's copies into the buffer grow faster than the runtime's DMA): kSmallPixels.
-// Here the inputs are copied by
-// the CPU into one page-locked buffer, the kernel reads them from there and writes its outputs
-// there (host memory is in the device's address space: a few KB over the link), and the CPU
-// copies the outputs on: one launch, one synchronisation, the same kernels on the same values --
-// the same bits as the staged path gives. Class codes are checked here instead of by the kernel
-// (the staged path reads the kernel's status word back).
+// Here the CPU copies the inputs into one page-locked buffer, the kernel reads them from there and
+// writes its outputs there (host memory is in the device's address space: a few KB over the link),
+// and the CPU copies the outputs on: one launch, one synchronisation, the same kernels on the same
+// values -- the same bits as the staged path gives. Class codes are checked here instead of by the
+// kernel (the staged path reads the kernel's status word back).
 template <typename T>
 static int run_host_small(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags) {
     const int64_t n = h.n;
