@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """How much of a step the vector pipe's ISSUE slots account for: a wave64 VALU instruction occupies
 its SIMD for 4 cycles (16 lanes per cycle; float64 and packed float32 alike on gfx950), so a kernel
-of I vector instructions per wave-iteration of P pixels per lane cannot take fewer than
+of I vector instructions EXECUTED per wave-iteration of P pixels per lane (SQ_INSTS_VALU / wave-iterations:
+tools/run_sq_counters.sh -- the loop body's static count includes branches a wave does not take) cannot take fewer than
 pixels / (64 P) x I x 4 / (4 SIMDs x CUs) shader cycles. Against the measured cycles of the step
 (kernel_ms x the shader clock read under load, both from a bench line) that is the share of the
 step the vector pipe is issuing -- what is left is memory time not hidden behind it.
