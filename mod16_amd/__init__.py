@@ -311,6 +311,77 @@ def _forward(cls, drivers, params, separate, flags, device, pet=False, out=None,
     return (outs[0], outs[1])
 
 
+def _is_device_tensor(v):
+    return getattr(v, 'is_cuda', False) and hasattr(v, 'data_ptr')
+
+
+def _forward_device(drivers, params, separate, flags, pet=False):
+    '''``MOD16.evapotranspiration`` on ``torch`` tensors that live on the GPU (extension): the
+    same entry points in DEVICE mode -- zero-copy, asynchronous on the current stream of the
+    tensors' device -- and ``torch`` tensors back, shaped as the reference shapes its arrays.
+    Inputs are device tensors (broadcast against each other as numpy would) and plain numbers
+    (Python / numpy scalars, weak as in the dtype rule: float32 only if every tensor is); host
+    arrays cannot be mixed in. Nothing is checked on the host afterwards: the result is valid when
+    the stream has run (``torch.cuda.synchronize()`` or any stream-ordered use).'''
+    import torch
+    values = list(drivers) + list(params)
+    tens = [v for v in values if _is_device_tensor(v)]
+    dev = tens[0].device
+    for v in values:
+        if _is_device_tensor(v):
+            if v.device != dev:
+                raise ValueError('device tensors on different GPUs: %s and %s' % (dev, v.device))
+        elif np.size(v) != 1:
+            raise TypeError('device tensors and host arrays cannot be mixed in one call '
+                            '(move the arrays to %s, or the tensors to the host)' % (dev,))
+    f32 = all(t.dtype == torch.float32 for t in tens)
+    dtype, np_dtype = (torch.float32, _F32) if f32 else (torch.float64, _F64)
+    esz = np_dtype.itemsize
+    shape = tuple(torch.broadcast_shapes(*[tuple(t.shape) for t in tens]))
+    n = 1
+    for extent in shape:
+        n *= int(extent)
+    host_scalars = [float(np.asarray(v).reshape(())) if not _is_device_tensor(v) else 0.0 for v in values]
+    with torch.cuda.device(dev):
+        scal = torch.tensor(host_scalars, dtype=dtype).to(dev, non_blocking=False)
+        keep, ptrs, strides = [scal], [], []
+        for i, v in enumerate(values):
+            if not _is_device_tensor(v):
+                ptrs.append(scal.data_ptr() + i * esz)
+                strides.append(0)
+                continue
+            t = v if v.dtype == dtype else v.to(dtype)
+            if t.numel() == 1:
+                strides.append(0)
+            else:
+                if tuple(t.shape) != shape:
+                    t = t.expand(shape)
+                t = t.contiguous()
+                strides.append(1)
+            keep.append(t)
+            ptrs.append(t.data_ptr())
+        nout = 4 if pet else (6 if separate else 2)
+        outs = [torch.empty(shape, dtype=dtype, device=dev) for _ in range(nout)]
+        if n:
+            ctx = _lib.context(dev.index if dev.index is not None else torch.cuda.current_device())
+            stream = _ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            optr = [o.data_ptr() for o in outs]
+            dptr, dstr, pptr, pstr = ptrs[:14], strides[:14], ptrs[14:], strides[14:]
+            if pet:
+                fn = ctx.lib.mod16_et_pet_f32 if f32 else ctx.lib.mod16_et_pet_f64
+                ctx.check(fn(ctx.handle, None, _lib.ptr_array(dptr), _lib.i64_array(dstr), _lib.ptr_array(pptr),
+                             _lib.i64_array(pstr), n, optr[0], optr[1], optr[2], optr[3], int(flags), _lib.DEVICE, stream))
+            else:
+                day, night, sep = (None, None, optr) if separate else (optr[0], optr[1], None)
+                ctx.et(np_dtype, None, dptr, dstr, pptr, pstr, n, day, night, sep, flags=flags, where=_lib.DEVICE,
+                       stream=stream)
+    if pet:
+        return tuple(outs)
+    if separate:
+        return (tuple(outs[0:3]), tuple(outs[3:6]))
+    return (outs[0], outs[1])
+
+
 def _call_method(method, inputs, params=None, nout=1, alpha=1.26, device=0, tiny=1e-7):
     '''Runs one sub-method of the class surface on the GPU (``mod16_method_*``,
     reference operation order). ``inputs`` follows the reference signature,
@@ -449,6 +520,8 @@ class MOD16(object):
             lw_net_day, lw_net_night, sw_rad_day, sw_rad_night, sw_albedo,
             temp_day, temp_night, temp_annual, tmin, vpd_day, vpd_night,
             pressure, fpar, lai)
+        if any(_is_device_tensor(v) for v in drivers):
+            return _forward_device(drivers, self._param_values(), separate, self.math)
         return _forward(
             None, drivers, self._param_values(), separate, self.math,
             self.device, devices=self.devices)
@@ -475,6 +548,8 @@ class MOD16(object):
             lw_net_day, lw_net_night, sw_rad_day, sw_rad_night, sw_albedo,
             temp_day, temp_night, temp_annual, tmin, vpd_day, vpd_night,
             pressure, fpar, lai)
+        if any(_is_device_tensor(v) for v in drivers):
+            return _forward_device(drivers, self._param_values(), False, self.math, pet=True)
         return _forward(None, drivers, self._param_values(), False, self.math,
                         self.device, pet=True, devices=self.devices)
 

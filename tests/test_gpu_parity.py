@@ -742,3 +742,52 @@ def test_small_calls_from_several_threads(m16, golden):
     for t in threads:
         t.join()
     assert not errors, errors[:5]
+
+
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_device_tensors_through_the_class(m16, golden, dtype):
+    """MOD16.evapotranspiration on torch tensors that live on the GPU (extension): DEVICE mode of
+    the same entry points, torch tensors back -- the numpy call's bits for the same values, with
+    the reference's shapes: scalars among the tensors, a (1, N) row against (T, N), a tensor
+    parameter, separate components, potential ET, a side stream."""
+    import torch
+    f = golden('f1_tests_scalars')
+    T, N = 37, 211
+    rng = np.random.default_rng(5)
+    np_dtype = np.dtype(dtype)
+    host = [np.asarray(float(x) * (1 + 0.02 * rng.uniform(-1, 1, (T, N))), np_dtype) for x in f['drivers']]
+    host[7] = np.ascontiguousarray(host[7][:1])              # temp_annual: a (1, N) row
+    host[11] = float(f['drivers'][11])                       # pressure: a Python number
+    params = [float(p) for p in f['params']]
+    m = model(m16, params, 'fast')
+    dev = [torch.from_numpy(a).cuda() if isinstance(a, np.ndarray) else a for a in host]
+    want = m.evapotranspiration(*host)
+    got = m.evapotranspiration(*dev)
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert g.is_cuda and g.dtype == getattr(torch, dtype) and tuple(g.shape) == (T, N)
+        assert same_bits(g.cpu().numpy(), w)
+    ws = m.evapotranspiration(*host, separate=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        gs = m.evapotranspiration(*dev, separate=True)
+        gp = m.evapotranspiration_and_pet(*dev)
+    side.synchronize()
+    for g, w in zip(list(gs[0]) + list(gs[1]), list(ws[0]) + list(ws[1])):
+        assert same_bits(g.cpu().numpy(), w)
+    for g, w in zip(gp, m.evapotranspiration_and_pet(*host)):
+        assert same_bits(g.cpu().numpy(), w)
+    # a per-pixel parameter as a device tensor, a 0-d tensor among the drivers
+    csl = np.asarray(params[7] * (1 + 0.1 * rng.uniform(-1, 1, (T, N))), np_dtype)
+    pt = dict(zip(oracle.PARAM_NAMES, params))
+    m_host, m_dev = m16.MOD16(dict(pt, csl=csl)), m16.MOD16(dict(pt, csl=torch.from_numpy(csl).cuda()))
+    dev0 = list(dev)
+    dev0[11] = torch.tensor(host[11], dtype=getattr(torch, dtype), device='cuda')
+    for g, w in zip(m_dev.evapotranspiration(*dev0), m_host.evapotranspiration(*host)):
+        assert same_bits(g.cpu().numpy(), w)
+    # host arrays cannot be mixed in
+    mixed = list(dev)
+    mixed[0] = host[0]
+    with pytest.raises(TypeError):
+        m.evapotranspiration(*mixed)
