@@ -786,6 +786,20 @@ def test_device_tensors_through_the_class(m16, golden, dtype):
     dev0[11] = torch.tensor(host[11], dtype=getattr(torch, dtype), device='cuda')
     for g, w in zip(m_dev.evapotranspiration(*dev0), m_host.evapotranspiration(*host)):
         assert same_bits(g.cpu().numpy(), w)
+    # fourteen dense drivers and one set of parameters (the reference's usual call): the production
+    # pipeline behind a class raster of ones -- still the numpy call's bits; then other parameters
+    dense_h = list(host)
+    dense_h[7] = np.ascontiguousarray(np.broadcast_to(host[7], (T, N)))
+    dense_h[11] = np.full((T, N), host[11], np_dtype)
+    dense_d = [torch.from_numpy(a).cuda() for a in dense_h]
+    for mm in (m, model(m16, [p * 1.01 for p in params], 'fast'), m):
+        for g, w in zip(mm.evapotranspiration(*dense_d), mm.evapotranspiration(*dense_h)):
+            assert same_bits(g.cpu().numpy(), w)
+    gs, ws = m.evapotranspiration(*dense_d, separate=True), m.evapotranspiration(*dense_h, separate=True)
+    for g, w in zip(list(gs[0]) + list(gs[1]), list(ws[0]) + list(ws[1])):
+        assert same_bits(g.cpu().numpy(), w)
+    for g, w in zip(m.evapotranspiration_and_pet(*dense_d), m.evapotranspiration_and_pet(*dense_h)):
+        assert same_bits(g.cpu().numpy(), w)
     # host arrays cannot be mixed in
     mixed = list(dev)
     mixed[0] = host[0]
