@@ -315,6 +315,7 @@ def _is_device_tensor(v):
     return getattr(v, 'is_cuda', False) and hasattr(v, 'data_ptr')
 
 
+_SPREAD_SCALARS_FROM = 1 << 20
 _ONES = {}      # device index -> the class raster of ones of the last shape (uint8, n bytes)
 
 
@@ -356,13 +357,23 @@ def _forward_device(drivers, params, separate, flags, pet=False):
     with torch.cuda.device(dev):
         scal = torch.tensor(host_scalars, dtype=dtype).to(dev, non_blocking=False)
         keep, ptrs, strides = [scal], [], []
+        # a large raster with one set of parameters runs the production pipeline (below), which wants
+        # fourteen dense drivers: a scalar among them (a constant pressure, say) is written out -- 8
+        # bytes per pixel more to read, still well ahead of the plain kernel
+        spread = n >= _SPREAD_SCALARS_FROM and not any(_is_device_tensor(v) for v in params)
         for i, v in enumerate(values):
             if not _is_device_tensor(v):
+                if spread and i < 14:
+                    t = scal[i].expand(shape).contiguous()
+                    keep.append(t)
+                    ptrs.append(t.data_ptr())
+                    strides.append(1)
+                    continue
                 ptrs.append(scal.data_ptr() + i * esz)
                 strides.append(0)
                 continue
             t = v if v.dtype == dtype else v.to(dtype)
-            if t.numel() == 1:
+            if t.numel() == 1 and not (spread and i < 14):
                 strides.append(0)
             else:
                 if tuple(t.shape) != shape:

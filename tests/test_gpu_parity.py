@@ -800,6 +800,14 @@ def test_device_tensors_through_the_class(m16, golden, dtype):
         assert same_bits(g.cpu().numpy(), w)
     for g, w in zip(m.evapotranspiration_and_pet(*dense_d), m.evapotranspiration_and_pet(*dense_h)):
         assert same_bits(g.cpu().numpy(), w)
+    # ... and a LARGE raster with a scalar among its drivers: the scalar is written out for the pipeline
+    big = (1025, 1024)
+    big_h = [np.asarray(float(x) * (1 + 0.02 * rng.uniform(-1, 1, big)), np_dtype) for x in f['drivers']]
+    big_h[11] = float(f['drivers'][11])
+    big_h[4] = np.asarray([[float(f['drivers'][4])]], np_dtype)          # a (1, 1) array: one value as well
+    big_d = [torch.from_numpy(a).cuda() if isinstance(a, np.ndarray) else a for a in big_h]
+    for g, w in zip(m.evapotranspiration(*big_d), m.evapotranspiration(*big_h)):
+        assert tuple(g.shape) == big and same_bits(g.cpu().numpy(), w)
     # host arrays cannot be mixed in
     mixed = list(dev)
     mixed[0] = host[0]
