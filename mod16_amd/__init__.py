@@ -319,6 +319,12 @@ _SPREAD_SCALARS_FROM = 1 << 20
 _ONES = {}      # device index -> the class raster of ones of the last shape (uint8, n bytes)
 
 
+def release_device_cache():
+    '''Frees what the device-tensor path keeps between calls (per GPU one class raster of ones,
+    one byte per pixel of the largest raster seen).'''
+    _ONES.clear()
+
+
 def _class_of_ones(torch, dev, index, n):
     t = _ONES.get(index)
     if t is None or t.numel() < n:
