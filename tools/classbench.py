@@ -9,7 +9,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import mod16_amd  # noqa: E402
 from mod16_amd.raster import RasterEngine  # noqa: E402
