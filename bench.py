@@ -81,6 +81,20 @@ def rank_env(base, rank, gpus, port):
     return env
 
 
+def too_few_devices(gpus):
+    """One line of text if this node shows fewer GPUs than the run has ranks (None otherwise, and
+    for the rehearsals that need none or one: MOD16_BENCH_PLUMBING, MOD16_BENCH_ONE_DEVICE).
+    Counting devices does not initialise the GPU (the parent of a multi-GPU run never does)."""
+    if os.environ.get('MOD16_BENCH_PLUMBING') == '1' or os.environ.get('MOD16_BENCH_ONE_DEVICE') == '1':
+        return None
+    import torch
+    visible = torch.cuda.device_count()
+    if visible >= gpus:
+        return None
+    return ('bench.py: --gpus %d needs %d visible GPUs, this node shows %d (one rank per GPU; '
+            'MOD16_BENCH_ONE_DEVICE=1 rehearses the ranks on one device over gloo)' % (gpus, gpus, visible))
+
+
 def spawn(argv, gpus):
     """Parent of a multi-GPU run started as plain `python bench.py --gpus N`: starts the N
     ranks itself as child processes (never an exec: this process must stay clear of the GPU
@@ -90,6 +104,10 @@ def spawn(argv, gpus):
     GPU process more than the ranks -- on the one-GPU boxes, which allow six, that silently
     ended the 6-rank rehearsal of round 2. Under torch.distributed.run
     (the driver's launch line) this function is not involved: the process is a rank."""
+    short = too_few_devices(gpus)
+    if short:
+        sys.stderr.write(short + '\n')
+        return 2
     port = free_port()
     script = os.path.join(ROOT, 'bench.py')
     procs = []
@@ -461,6 +479,10 @@ def main():
     rehearsal = os.environ.get('MOD16_BENCH_ONE_DEVICE') == '1'
     if rehearsal:
         local_rank = 0
+    short = too_few_devices(max(world, 1) if not rehearsal else 1)
+    if short:                      # (under torch.distributed.run every rank says so and leaves)
+        sys.stderr.write(short + '\n')
+        return 2
     torch.cuda.set_device(local_rank)
     grouped = world > 1 or force_group
     backend = None

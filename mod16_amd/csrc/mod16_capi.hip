@@ -61,6 +61,7 @@ struct mod16_ctx {
     int stream_blocks = 2;           // blocks of the pipeline kernel per CU (1 = one wave per SIMD)
     int static_below = 8;            // runs per wave below which runs are dealt out statically (0: never)
     int use_pitch = 1;               // scalar base + pitch addressing for slab layouts
+    int poison_byte = -1;            // ... MOD16_POISON_BYTE=b: the byte every byte of that ticket is set to (default: the ticket becomes 2^40)
     int poison_ticket = 0;           // experiments build, MOD16_POISON_TICKET=k: the k-th dynamically scheduled launch finds
                                      // its ticket counter in use (what an abandoned launch leaves behind): the test of kStatusIncomplete
     unsigned long long* dyn_counters = nullptr;   // ring of ticket counters, 128 B apart
@@ -217,6 +218,7 @@ extern "C" int mod16_create(int device, mod16_ctx** out) {
         if (const char* g = getenv("MOD16_STATIC_BELOW")) ctx->static_below = std::max(0, std::min(64, atoi(g)));
         if (const char* g = getenv("MOD16_STREAM_BLOCKS")) ctx->stream_blocks = std::max(1, std::min(2, atoi(g)));
         if (const char* g = getenv("MOD16_POISON_TICKET")) ctx->poison_ticket = std::max(0, atoi(g));
+        if (const char* g = getenv("MOD16_POISON_BYTE")) ctx->poison_byte = std::max(-1, std::min(255, atoi(g)));
 #endif
         HIPCHK(ctx, hipMalloc(&ctx->dyn_counters, 64 * 128));
         {   // ticket = 0, blocks done = 0, and a serial number (word [3]) that starts somewhere else in
@@ -495,6 +497,10 @@ static StreamGeom stream_geom(const mod16_ctx* ctx, int64_t n, int V, int tile_s
     return g;
 }
 constexpr int kStage = 1024;     // slices of the two-level sum of the per-run partials
+// workspace of a pipeline launch, in partials (64 bytes): one per run, the stage of the two-level sum,
+// and one more per run -- the run's cancellation list (mixed-precision forms, mod16_stream.hpp)
+static_assert(kCancelCap * sizeof(uint16_t) == kDiag * sizeof(double), "a cancellation list is the size of a partial");
+static int64_t stream_ws_blocks(int64_t nruns) { return 2 * nruns + kStage; }
 constexpr int64_t kFuseFinalBelow = 16384;   // partials up to which the pipeline kernel sums them itself
 
 // The production pipeline for dense class rasters (mod16_stream.hpp). s.n must
@@ -525,7 +531,11 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
         // -- zero between launches -- becomes 2^40: "every run has been claimed", as a counter left
         // behind by an abandoned launch says: the waves process their first, statically assigned
         // runs and find nothing to claim
-        HIPCHK(ctx, hipMemsetAsync(reinterpret_cast<char*>(ctr) + 5, 1, 1, st));
+        // MOD16_POISON_BYTE=b (round 6): all eight bytes of the ticket become b instead -- 0x3f is the
+        // pattern whose (nwaves + ticket) << run_shift overflowed into a negative base in round 5 (a
+        // wild read and a wild store); 0xff is -1. The kernel clamps the ticket before it forms a base.
+        if (ctx->poison_byte >= 0) HIPCHK(ctx, hipMemsetAsync(ctr, ctx->poison_byte, 8, st));
+        else HIPCHK(ctx, hipMemsetAsync(reinterpret_cast<char*>(ctr) + 5, 1, 1, st));
     }
 #endif
     s.run_shift = g.run_shift;
@@ -534,11 +544,12 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     // partials: one per run, or (static schedule) one per block
     const int64_t nruns = g.static_sched ? grid : g.nruns;
     DiagWs* ws = nullptr;
-    int rc = reserve_diag(ctx, nruns + kStage, &ws);
+    int rc = reserve_diag(ctx, stream_ws_blocks(nruns), &ws);
     if (rc != MOD16_OK) return rc;
     rc = ws_acquire(ctx, st);
     if (rc != MOD16_OK) return rc;
     s.diag_partial = ws->partial;
+    s.cancel_list = reinterpret_cast<uint16_t*>(ws->partial + (nruns + kStage) * kDiag);
     // few partials: the kernel's last block adds them up itself (two dispatches less)
     // (only under the static schedule: a dynamically scheduled raster's flagged pieces are
     // revisited by the kernel BEHIND this one, which corrects the partials before they are summed)
@@ -569,19 +580,24 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     if (ddiag && !fused_final) {
         const double* fin = ws->partial;
         int64_t count = nruns;
+        // (a trusted launch has no kernel behind it that looks at every run: the kernel that reads
+        // the runs' own partials compares every run's marker)
+        bool check = !GUARD && !g.static_sched;
+        const unsigned* serial_word = reinterpret_cast<const unsigned*>(ctr) + 3;
         if (count > 4 * kStage) {   // two-level: 1024 fixed slices, then one block
             double* stage = ws->partial + nruns * kDiag;
             const int64_t per = (count + kStage - 1) / kStage;
-            hipLaunchKernelGGL(diag_stage_kernel, dim3(kStage), dim3(kBlock), 0, st, fin, count, per, stage);
+            hipLaunchKernelGGL(diag_stage_kernel, dim3(kStage), dim3(kBlock), 0, st, fin, count, per, stage,
+                               check ? serial_word : (const unsigned*)nullptr,
+                               check ? ctx->status : (unsigned*)nullptr);
             fin = stage;
             count = (count + per - 1) / per;
+            check = false;
         }
-        // (a trusted launch has no kernel behind it that looks at every run: the sum checks the markers)
-        const bool check = !GUARD && !g.static_sched;
         hipLaunchKernelGGL(diag_final_fused_kernel, dim3(1), dim3(kFinalBlock), 0, st,
                            fin, (int)count, s.n, ddiag,
-                           check ? reinterpret_cast<const unsigned*>(ctr) + 3 : (const unsigned*)nullptr,
-                           check ? ctx->status : (unsigned*)nullptr, nruns);
+                           check ? serial_word : (const unsigned*)nullptr,
+                           check ? ctx->status : (unsigned*)nullptr);
     }
     return ws_release(ctx, st);
 }
@@ -1243,7 +1259,7 @@ static int graph_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drive
         ctx->force_counter = g->counter;
         // the graph's kernel nodes keep pointing at this workspace for as long as
         // the graph lives, whatever the context's own workspace does meanwhile
-        HIPCHK(ctx, ws_alloc(g->ws, std::max<int64_t>(kDiagBlocks, stream_geom(ctx, std::max<int64_t>(n, 0), VecOf<T>::v).nruns + kStage)));
+        HIPCHK(ctx, ws_alloc(g->ws, std::max<int64_t>(kDiagBlocks, stream_ws_blocks(stream_geom(ctx, std::max<int64_t>(n, 0), VecOf<T>::v).nruns))));
         ctx->force_ws = &g->ws;
         HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         int r = et_diag_entry<T>(ctx, cls, drivers, dstride, n, out_day, out_night, flags, ddiag, st);
@@ -2878,7 +2894,7 @@ static int graph_tiled_entry(mod16_ctx* ctx, const mod16_layout* lay, const uint
         int pv = 0, tsh = lay->tile > 0 ? tile_log2(lay->tile, 1) : -1;
         while ((1 << pv) < 64 * VecOf<T>::v) ++pv;
         if (tsh < pv) return fail(ctx, MOD16_ERR_ARG, "mod16_graph_et_tiled: bad tile");
-        HIPCHK(ctx, ws_alloc(g->ws, std::max<int64_t>(kDiagBlocks, stream_geom(ctx, std::max<int64_t>(n, 0), VecOf<T>::v, tsh - pv).nruns + kStage)));
+        HIPCHK(ctx, ws_alloc(g->ws, std::max<int64_t>(kDiagBlocks, stream_ws_blocks(stream_geom(ctx, std::max<int64_t>(n, 0), VecOf<T>::v, tsh - pv).nruns))));
         ctx->force_ws = &g->ws;
         HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         int r = tiled_entry<T>(ctx, lay, cls, drivers, n, out_day, out_night, flags, ddiag, st);

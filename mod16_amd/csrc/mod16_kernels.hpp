@@ -352,17 +352,27 @@ __global__ void __launch_bounds__(kBlock) diag_final_kernel(const double* partia
 
 // One stage of the fixed-order reduction of per-run partials: block b reduces
 // partials [b * per, (b + 1) * per) to out[b].
+// serial_word / status (trusted launches): see diag_final_fused_kernel -- the kernel that reads the
+// runs' own partials compares every run's marker.
 __global__ void __launch_bounds__(kBlock) diag_stage_kernel(const double* partial, int64_t count,
-                                                            int64_t per, double* out) {
+                                                            int64_t per, double* out,
+                                                            const unsigned* serial_word = nullptr,
+                                                            unsigned* status = nullptr) {
     double acc[kDiag] = {0, 0, 0, 0, 0, 0, -__builtin_huge_val(), -__builtin_huge_val()};
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = (lo + per < count) ? lo + per : count;
+    double marker = 0.0;
+    if (serial_word)
+        marker = launch_marker(__hip_atomic_load(serial_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u);
+    bool stale = false;
     for (int64_t b = lo + threadIdx.x; b < hi; b += kBlock) {
         double o[kDiag];
 #pragma unroll
         for (int k = 0; k < kDiag; ++k) o[k] = partial[b * kDiag + k];
+        stale |= o[kSerialField] != marker;
         diag_merge(acc, o);
     }
+    if (serial_word && stale) atomicOr(status, kStatusIncomplete);
     diag_block_reduce(acc, out + (int64_t)blockIdx.x * kDiag);
 }
 
@@ -370,22 +380,30 @@ __global__ void __launch_bounds__(kBlock) diag_stage_kernel(const double* partia
 // t adds partials t, t + 1024, ...; then a fixed wave / block tree);
 // n_valid = n - n_nan. 1024 threads keep the dependent-load chain short.
 constexpr int kFinalBlock = 1024;
-// serial_word / status / nruns (trusted launches, which have no kernel behind them that revisits the
-// runs): the launch's serial number AFTER the pipeline kernel incremented it, the status word and the
-// number of runs -- field kSerialField of the partials must add up to nruns markers.
+// serial_word / status (trusted launches, which have no kernel behind them that revisits the runs;
+// given to the kernel that reads the runs' OWN partials -- this one, or diag_stage_kernel for a
+// two-level sum): the launch's serial number AFTER the pipeline kernel incremented it and the status
+// word -- field kSerialField of every partial must hold this launch's marker.
 __global__ void __launch_bounds__(kFinalBlock) diag_final_fused_kernel(const double* partial,
                                                                        int nblocks, int64_t n,
                                                                        double* out,
                                                                        const unsigned* serial_word = nullptr,
-                                                                       unsigned* status = nullptr,
-                                                                       int64_t nruns = 0) {
+                                                                       unsigned* status = nullptr) {
     double acc[kDiag] = {0, 0, 0, 0, 0, 0, -__builtin_huge_val(), -__builtin_huge_val()};
+    // EVERY run's marker is compared (round 6; a sum of the markers against nruns * marker passed
+    // stale partials whose markers lay m - 1 and m + 1 in equal number)
+    double marker = 0.0;
+    if (serial_word)
+        marker = launch_marker(__hip_atomic_load(serial_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u);
+    bool stale = false;
     for (int b = threadIdx.x; b < nblocks; b += kFinalBlock) {
         double o[kDiag];
 #pragma unroll
         for (int k = 0; k < kDiag; ++k) o[k] = partial[(int64_t)b * kDiag + k];
+        stale |= o[kSerialField] != marker;
         diag_merge(acc, o);
     }
+    if (serial_word && stale) atomicOr(status, kStatusIncomplete);
     __shared__ double sm[kFinalBlock / 64][kDiag];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -412,10 +430,6 @@ __global__ void __launch_bounds__(kFinalBlock) diag_final_fused_kernel(const dou
         out[5] = acc[5];
         out[6] = acc[6];
         out[7] = acc[7];
-        if (serial_word) {
-            const unsigned serial = __hip_atomic_load(serial_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
-            if (acc[kSerialField] != (double)nruns * launch_marker(serial)) atomicOr(status, kStatusIncomplete);
-        }
     }
 }
 

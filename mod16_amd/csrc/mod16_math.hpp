@@ -18,7 +18,7 @@
 #if defined(MOD16_TRIVIAL_BODY) || defined(MOD16_NO_GUARD) || defined(MOD16_EXPERIMENT_SEED_RCP) || \
     defined(MOD16_PRIO) || defined(MOD16_REPRO_V4) || defined(MOD16_NO_FUSED_FINAL) ||                \
     defined(MOD16_NO_REDO_LAUNCH) || defined(MOD16_KK_M) || defined(MOD16_NO_FMA_KK) ||               \
-    defined(MOD16_DYN_RUN)
+    defined(MOD16_DYN_RUN) || defined(MOD16_MIXED_NO_CANCEL) || defined(MOD16_MIXED_CANCEL)
 #error "MOD16_* measurement switches need -DMOD16_EXPERIMENTS (they are not part of the product build)"
 #endif
 #endif

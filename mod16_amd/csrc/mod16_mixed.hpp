@@ -47,6 +47,14 @@ __device__ __forceinline__ f2 rcp2(f2 x) {
     f2 e = __builtin_elementwise_fma(-x, r, f2{1.f, 1.f});
     return __builtin_elementwise_fma(r, e, r);
 }
+// 1/x of a value that cannot be zero or infinite inside the form's domain (a temperature offset,
+// N t of the air density): the hardware reciprocal alone, 1 ulp (round 6)
+__device__ __forceinline__ f2 rcp2_plain(f2 x) { return f2{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+// min(max(x, 0), 1) as ONE v_med3_f32 per value (round 6: the three ramps were two compares and two
+// selects per value). A NaN x gives 0 (v_med3 returns the minimum then): see the callers.
+__device__ __forceinline__ f2 clamp01(f2 x) {
+    return f2{__builtin_amdgcn_fmed3f(x.x, 0.f, 1.f), __builtin_amdgcn_fmed3f(x.y, 0.f, 1.f)};
+}
 __device__ __forceinline__ f2 exp2_2(f2 x) { return f2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
 __device__ __forceinline__ f2 log2_2(f2 x) { return f2{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)}; }
 // Predicates of the two pixels are pairs of plain bools (x_0, x_1), not an int vector: each
@@ -59,12 +67,21 @@ __device__ __forceinline__ f2 sel(bool m0, bool m1, f2 a, f2 b) { return f2{m0 ?
 
 // class parameters of the two pixels, float32 (the LDS table is float64:
 // rounded on the way in, 15 conversions per pixel)
+// One float32 of the table in LDS as ONE ds_read_b32 into a register of its own: read as plain
+// loads hipcc pairs the rows of a pixel into ds_read2_b32 and then moves every value into the
+// (pixel 0, pixel 1) register pair the packed arithmetic wants -- 18 v_mov_b32 per pair of pixels
+// (round 6). volatile keeps the loads apart; the LDS address space is spelled out (a volatile
+// generic pointer becomes a flat load, which would also count against the pipeline's vmcnt).
+__device__ __forceinline__ float lds_f32(const float* p) {
+    return *(const volatile __attribute__((address_space(3))) float*)p;
+}
+constexpr int kLutDrbl = 13;     // row of the float32 table that holds rbl_max - rbl_min (mod16_stream.hpp fills it)
 struct ClassPar2 {
-    f2 vpd_open, vpd_close, gl_sh, gl_wv, g_cut, csl, rbl_min, rbl_max, inv_dvpd, rbl_slope, inv_beta;
+    f2 vpd_open, gl_sh, gl_wv, g_cut, rbl_min, inv_dvpd, drbl, inv_beta;     // drbl = rbl_max - rbl_min
 };
 
 struct Shared2 {
-    f2 fpar, omf, p_rel, k_p, p_mbar_k, glsh_l, glwv_l, glsh_lai, m_tmin;
+    f2 fpar, omf, p_rel, k_p, p_mbar_k, glwv_l, glsh_lai, csl_m;     // csl_m = csl x the Tmin ramp
     bool lai_pos[2], lai_tiny[2];
 };
 
@@ -133,11 +150,35 @@ __device__ __forceinline__ void humid64_tail(double esat, double vpd, float& esa
     esat_f = (float)esat; rh_f = (float)rh; fwet_f = (float)fwet; omw_f = (float)omw;
 }
 
-// the three components of one period [kg m-2 s-1] and, with PET, the potential
-// ET of the period (as period_fast, reference README.md:404-424)
+// the three components of one period [kg m-2 s-1], their sum (mod16/__init__.py:792) and, with
+// PET, the potential ET of the period (as period_fast, reference README.md:404-424)
 struct Parts2 {
-    f2 canopy, soil, trans, pet;
+    f2 canopy, soil, trans, total, pet;
+    f2 zc, zs;     // the cancellation class: negative where the canopy's / the soil's budget exceeds the period's total
 };
+
+// ---- the cancellation class (round 6). Two numerators of a period are DIFFERENCES of products of
+// like size wherever the net radiation is negative (every night): the wet canopy's
+// rho Cp fpar vpd / r_a + s A_c (:952) and the bare soil's s A_soil r_tot + rho Cp (1 - fpar) vpd (r_tot /
+// r_as) (:537). float32 factors resolve such a sum to ~3e-7 of its TERMS, so where it cancels to a
+// hundredth of them the component is right to 3e-5 only -- and where the period's total is that small
+// as well (a dry night over bare ground: the soil term is all there is) the total's relative error
+// has no bound: 2047 values of the global grid were off by more than 1e-3 of themselves, one by
+// 1.29 (profiles/r05d_bench_line.json; r03_mixed_tail_probe.txt). The period therefore carries the
+// size of the radiative term of each numerator through the component's own quotient -- what a
+// relative error of that term does to the component -- and a value whose budget exceeds
+// kMixedCancel x the period's total is computed again in float64 -- not here: inside the pipeline's
+// loop the float64 pixel function's constants cost the loop its scalar registers (+27 v_readlane /
+// v_writelane per iteration, measured on the listing); the pixel is marked (its first output holds
+// kCancelPoison, a NaN no arithmetic produces, and it counts as NaN in the run's diagnostics) and
+// what runs behind the loop -- the machinery of the domain guard, mod16_stream.hpp::redo_piece --
+// puts the FAST form's float64 result in its place. 3e-7 x 100 = 3e-5 is the error a value may
+// keep. Masked components (a 0 of :959 / :961 / :858-861) carry no budget.
+#ifndef MOD16_MIXED_CANCEL
+#define MOD16_MIXED_CANCEL 128.0
+#endif
+constexpr float kMixedCancel = (float)(MOD16_MIXED_CANCEL);
+constexpr unsigned kCancelPoison = 0x7fc16a5du;      // a quiet NaN with a payload
 
 template <bool DAY, bool PET = false>
 __device__ __forceinline__ Parts2 period_mixed(const ClassPar2& p, const Shared2& sh, const Humid2& h,
@@ -145,7 +186,7 @@ __device__ __forceinline__ Parts2 period_mixed(const ClassPar2& p, const Shared2
     const f2 zero = splat(0.f), one = splat(1.f), tiny = splat(1e-7f);
     f2 tc = t - splat(273.15f);
     f2 ta = t - splat(34.15f);                                              // (239 + T) - 273.15, :1395
-    f2 rta = rcp2(ta);
+    f2 rta = rcp2_plain(ta);                                                // (t > 90 K inside the domain)
     f2 s = (splat((float)(17.38 * 239.0)) * h.esat) * (rta * rta);          // :1395-1397
     f2 lhv = __builtin_elementwise_fma(tc, splat(-0.002361e6f), splat(2.501e6f));   // (2.501 - 0.002361 tc) 1e6, :121
     f2 slhv = s * lhv;
@@ -156,45 +197,53 @@ __device__ __forceinline__ Parts2 period_mixed(const ClassPar2& p, const Shared2
     // rho Cp and 4 sigma T^3 / (rho Cp) from one reciprocal, :408-412, :947
     // (N carries the factor Cp, as in period_fast: rho Cp = N / T, 1/r_r = 4 sigma T^4 / N)
     f2 nn = sh.p_mbar_k - h.rh * __builtin_elementwise_fma(tc, splat((float)(0.252 * 1013.0)), splat((float)(-2.0582 * 1013.0)));   // Cp (rh 100)(0.00252 tc - 0.020582)
-    f2 u = rcp2(nn * t);
+    f2 u = rcp2_plain(nn * t);
     f2 rho_cp = (nn * nn) * u;
     f2 t2 = t * t;
     f2 g_rr = splat((float)(4.0 * 5.67e-8)) * ((t2 * t2) * t) * u;
     f2 rcfv = rho_cp * vpd;
+    f2 rf = rcfv * sh.fpar;
     f2 radc_raw = sh.fpar * rad_net;
+    f2 s_radc = s * radc_raw;
 
     // wet canopy, :866-961
-    // (:934 replaces fwet = 0 by `tiny` to keep 1 / (gl fwet) finite; nothing divides by fwet here and
-    // the dry pixel's result is the 0 of :961 whatever its quotient: no replacement, as in period_fast)
+    // (:934-935 replace fwet = 0 and lai = 0 by `tiny` to keep 1 / (gl lai fwet) finite; nothing
+    // divides by either here and such a pixel's result is the 0 of :961 whatever its quotient:
+    // no replacement, as in period_fast)
     f2 fw = h.fwet;
-    f2 g_h = sh.glsh_l * fw, g_e = sh.glwv_l * fw, g_a = g_h + g_rr;
-    f2 numer = fw * ((rcfv * sh.fpar) * g_a + s * radc_raw);
-    f2 den = slhv * g_e + sh.k_p * g_a;
-    f2 evap = (numer * g_e) * rcp2(den);
-    // numer < 0 -> 0 (:959), fw <= tiny (<=> dry) or lai <= tiny -> 0 (:961): one select
-    f2 canopy = sel((numer.x < 0.f) | h.dry[0] | sh.lai_tiny[0], (numer.y < 0.f) | h.dry[1] | sh.lai_tiny[1], zero, evap);
+    f2 g_e = sh.glwv_l * fw, g_a = __builtin_elementwise_fma(sh.glsh_lai, fw, g_rr);
+    f2 csum = __builtin_elementwise_fma(rf, g_a, s_radc);              // numer / fwet
+    f2 den = __builtin_elementwise_fma(slhv, g_e, sh.k_p * g_a);
+    f2 k_c = (fw * g_e) * rcp2(den);
+    // numer < 0 -> 0 (:959; fwet > 0 where it counts, and a NaN fwet comes with a NaN sum), fw <=
+    // tiny (<=> dry) or lai <= tiny -> 0 (:961): one select
+    const bool cm0 = (csum.x < 0.f) | h.dry[0] | sh.lai_tiny[0];
+    const bool cm1 = (csum.y < 0.f) | h.dry[1] | sh.lai_tiny[1];
+    f2 ev = csum * k_c;
+    f2 canopy = sel(cm0, cm1, zero, ev);
 
     // bare soil, :449-544, :795-864
-    f2 r0 = sel(vpd.x <= p.vpd_open.x, vpd.y <= p.vpd_open.y, p.rbl_min,
-                sel(vpd.x >= p.vpd_close.x, vpd.y >= p.vpd_close.y, p.rbl_max,
-                    p.rbl_max - (p.vpd_close - vpd) * p.rbl_slope));
+    // r_tot of :527-531 as rbl_min + (rbl_max - rbl_min) clamp01((vpd - vpd_open) / (vpd_close -
+    // vpd_open)): exactly rbl_min up to vpd_open, rbl_max to an ulp from vpd_close on (a continuous
+    // ramp: nothing is decided here). A NaN vpd leaves the clamp as 0 -- and the period as NaN
+    // through rho Cp vpd.
+    f2 ramp = clamp01((vpd - p.vpd_open) * p.inv_dvpd);
+    f2 r0 = __builtin_elementwise_fma(ramp, p.drbl, p.rbl_min);
     f2 r_tot = r0 * inv_rcorr;
-    f2 w = r_tot * g_rr + one;
-    f2 num = (s * rad_soil) * r_tot + (rcfv * sh.omf) * w;
-    f2 dens = r_tot * (sh.k_p * w + slhv);
-    f2 q = num * rcp2(dens);
+    f2 w = __builtin_elementwise_fma(r_tot, g_rr, one);
+    f2 s_t1 = (s * rad_soil) * r_tot;
+    f2 num = __builtin_elementwise_fma(rcfv * sh.omf, w, s_t1);
+    f2 rdens = rcp2(r_tot * __builtin_elementwise_fma(sh.k_p, w, slhv));
+    f2 q = num * rdens;
     f2 pw = exp2_2((vpd * p.inv_beta) * log2_2(h.rh));                      // rh ** (vpd / beta), :861
-    f2 e = q * (h.omw * pw + h.fwet);
-    f2 soil = sel(q.x < 0.f, q.y < 0.f, zero, e);
+    f2 wet = __builtin_elementwise_fma(h.omw, pw, h.fwet);
+    const bool sm0 = q.x < 0.f, sm1 = q.y < 0.f;
+    f2 es = q * wet;
+    f2 soil = sel(sm0, sm1, zero, es);
 
     // transpiration, :1152-1258
     f2 g_s = zero;
-    if (DAY) {
-        f2 m_vpd = sel(vpd.x >= p.vpd_close.x, vpd.y >= p.vpd_close.y, zero,
-                       sel(vpd.x < p.vpd_open.x, vpd.y < p.vpd_open.y, one,
-                           one - (vpd - p.vpd_open) * p.inv_dvpd));
-        g_s = ((p.csl * sh.m_tmin) * m_vpd) * inv_rcorr;
-    }
+    if (DAY) g_s = (sh.csl_m * (one - ramp)) * inv_rcorr;                   // :1148-1150, :1237
     f2 gsc = g_s + p.g_cut * inv_rcorr;
     f2 g_bl = sh.glsh_lai * h.omw;
     f2 p1 = g_bl * gsc, s1 = g_bl + gsc;
@@ -203,22 +252,40 @@ __device__ __forceinline__ Parts2 period_mixed(const ClassPar2& p, const Shared2
     const bool shut0 = !(sh.lai_pos[0] & h.open_w[0]) | (p1.x <= lim.x);
     const bool shut1 = !(sh.lai_pos[1] & h.open_w[1]) | (p1.y <= lim.y);
     f2 g_d = p.gl_sh + g_rr;
-    f2 rad_c = sel(radc_raw.x < 0.f, radc_raw.y < 0.f, zero, radc_raw);                         // :1251
-    f2 numt = (h.omw * ((rcfv * sh.fpar) * g_d + s * rad_c)) * p1;
+    // s max(A_c, 0), :1251 (a NaN A_c stays; a NaN s comes with a NaN rho Cp)
+    f2 s_radp = sel(radc_raw.x < 0.f, radc_raw.y < 0.f, zero, s_radc);
+    f2 numt = (h.omw * __builtin_elementwise_fma(rf, g_d, s_radp)) * p1;
     f2 dent = slhv * p1 + sh.k_p * (g_d * s1 + p1);
     f2 tr = numt * rcp2(dent);
     Parts2 o;
     o.canopy = canopy;
     o.soil = soil;
     o.trans = sel(shut0, shut1, zero, tr);
+    o.total = (o.canopy + o.soil) + o.trans;                                // :792
     o.pet = zero;
     if (PET) {
         // sat + unsat without the rh^(vpd/beta) factor (two products, so that inf * 0 is
         // NaN as in :541-543) + Priestley-Taylor potential transpiration (:546-602)
-        f2 pot_soil = sel(q.x < 0.f, q.y < 0.f, zero, __builtin_elementwise_fma(q, h.fwet, q * h.omw));
-        f2 pot_tr = (splat((float)kPriestleyTaylorAlpha) * (s * radc_raw) * h.omw) * rcp2(slhv + sh.k_p);
+        f2 pot_soil = sel(sm0, sm1, zero, __builtin_elementwise_fma(q, h.fwet, q * h.omw));
+        f2 pot_tr = (splat((float)kPriestleyTaylorAlpha) * s_radc * h.omw) * rcp2(slhv + sh.k_p);
         o.pet = (canopy + pot_soil) + pot_tr;
     }
+    // the cancellation budgets against the total, all in the vector pipe (as lane masks the tests
+    // cost six scalar instructions per value, and at two waves per SIMD a scalar instruction is worth
+    // two thirds of a vector one: measured). z = budget + kMixedCancel x (total - (value before its
+    // mask - value)): the bracket is the total where the component is not masked; where a NEGATIVE
+    // numerator masked it (:959, :858-861) it grows by that negative value -- a component confidently
+    // below zero is the same exact 0 in every arithmetic and carries no risk, one within rounding of
+    // zero may be a small positive number in float64 (the one value of the global grid that was still
+    // off by 0.9 of itself) and keeps its budget. A NaN never flags (v_min3 passes it over).
+    o.zc = o.zs = zero;
+#ifndef MOD16_MIXED_NO_CANCEL       // (measurement builds: what the detection costs)
+    {
+        const f2 k = splat(kMixedCancel);
+        o.zc = __builtin_elementwise_fma((o.total + canopy) - ev, k, s_radc * k_c);
+        o.zs = __builtin_elementwise_fma((o.total + soil) - es, k, (s_t1 * rdens) * wet);
+    }
+#endif
     return o;
 }
 
@@ -235,18 +302,27 @@ __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], co
                                                     Parts2& day, Parts2& night,
                                                     const double (*vpd64)[2] = nullptr,
                                                     const float* f0 = nullptr, const float* f1 = nullptr,
-                                                    const Humid2* hraw = nullptr) {
+                                                    const Humid2* hraw = nullptr, bool* cancel = nullptr) {
     const f2 zero = splat(0.f);
     auto col = [&](int k) { return f2{in[k][0], in[k][1]}; };
     auto par = [&](int row) {
-        if constexpr (LUTF) return f2{f0[row * ls], f1[row * ls]};
+        if constexpr (LUTF) return f2{lds_f32(f0 + row * ls), lds_f32(f1 + row * ls)};
         else return f2{(float)l0[row * ls], (float)l1[row * ls]};
+    };
+    // rbl_max - rbl_min: row kLutDrbl of the float32 copy of the table (its row of the float64 table,
+    // the slope of the float64 forms, is not used by this form)
+    auto par_drbl = [&]() {
+        if constexpr (LUTF) return f2{lds_f32(f0 + kLutDrbl * ls), lds_f32(f1 + kLutDrbl * ls)};
+        else return f2{(float)(l0[9 * ls] - l0[8 * ls]), (float)(l1[9 * ls] - l1[8 * ls])};
     };
     // ---- radiation received by the soil, :963-1119, float32
     const f2 lw_d = col(0), lw_n = col(1), sw_d = col(2), sw_n = col(3), alb = col(4);
     const f2 t_d = col(5), t_n = col(6), t_ann = col(7), fpar = col(12);
-    const f2 oma = splat(1.f) - alb, omf = splat(1.f) - fpar;
-    f2 a_d = __builtin_elementwise_fma(sw_d, oma, lw_d);
+    const f2 omf = splat(1.f) - fpar;
+    // A = sw (1 - albedo) + lw as (sw + lw) - sw albedo: where the two cancel (an overcast winter
+    // day: A a hundredth of its terms) 1 - albedo rounded to float32 would cost A 5e-8 of sw (round 6:
+    // the next-worst values of the global grid, 9e-4 off, were these)
+    f2 a_d = __builtin_elementwise_fma(-sw_d, alb, sw_d + lw_d);
     const f2 a_n = lw_n;
     // x < 298.15 (float64) <=> x < RU(298.15); x >= 273.15 + tmin_close <=> x >= row 15 of
     // the table; t_d - t_n is exact in float32 for temperatures within a factor 2
@@ -267,7 +343,7 @@ __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], co
     const f2 dn = (a_n - gn1) + splat(0.5f) * a_d;
     const f2 gn2 = sel((a_d.x > 0.f) & (dn.x < 0.f), (a_d.y > 0.f) & (dn.y < 0.f), a_n + splat(0.5f) * a_d, gn1);
     f2 rs_d = omf * (a_d - gd2), rs_n = omf * (a_n - gn2);
-    f2 rn_n = __builtin_elementwise_fma(sw_n, oma, lw_n);
+    f2 rn_n = __builtin_elementwise_fma(-sw_n, alb, sw_n + lw_n);
     // near-ties of the computed comparisons: operands within 1e-3 W m-2 (their float32
     // errors are below 1e-4) -> this wave redoes the balance in float64 for these pixels
     const f2 tol = splat(1e-3f);
@@ -326,9 +402,9 @@ __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], co
 
     // ---- float32, packed
     ClassPar2 p;
-    p.vpd_open = par(2); p.vpd_close = par(3); p.gl_sh = par(4); p.gl_wv = par(5);
-    p.g_cut = par(6); p.csl = par(7); p.rbl_min = par(8); p.rbl_max = par(9);
-    p.inv_dvpd = par(12); p.rbl_slope = par(13); p.inv_beta = par(14);
+    p.vpd_open = par(2); p.gl_sh = par(4); p.gl_wv = par(5);
+    p.g_cut = par(6); p.rbl_min = par(8);
+    p.inv_dvpd = par(12); p.drbl = par_drbl(); p.inv_beta = par(14);
     const f2 pa = col(11), lai = col(13);
     Shared2 sh;
     sh.fpar = fpar;
@@ -336,24 +412,35 @@ __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], co
     sh.p_rel = pa * splat((float)(1.0 / 101300.0));
     sh.k_p = pa * splat((float)(1013.0 / 0.622));
     sh.p_mbar_k = pa * splat((float)(1013.0 * 0.348444 / 100.0));
-    const f2 l_wet = sel(lai.x == 0.f, lai.y == 0.f, splat(1e-7f), lai);              // :935
-    // lai <= tiny (:961) is asked in float64 of the float32 value: float32(1e-7) is ABOVE 1e-7,
-    // so a LAI of exactly that float is not masked by the reference (pair fuzz, round 3):
-    // x <= 1e-7  <=>  x <= 0x1.ad7f28p-24f, the largest float32 below; LAI = 0 became tiny above
+    // lai <= tiny (:961; a LAI of 0 became `tiny` at :935 and is one of them) is asked in float64 of
+    // the float32 value: float32(1e-7) is ABOVE 1e-7, so a LAI of exactly that float is not masked by
+    // the reference (pair fuzz, round 3): x <= 1e-7  <=>  x <= 0x1.ad7f28p-24f, the largest float32 below
     constexpr float kTinyBelow = 0x1.ad7f28p-24f;
-    sh.lai_tiny[0] = (lai.x == 0.f) | (lai.x <= kTinyBelow);
-    sh.lai_tiny[1] = (lai.y == 0.f) | (lai.y <= kTinyBelow);
+    sh.lai_tiny[0] = lai.x <= kTinyBelow;
+    sh.lai_tiny[1] = lai.y <= kTinyBelow;
     sh.lai_pos[0] = lai.x > 0.f; sh.lai_pos[1] = lai.y > 0.f;
-    sh.glsh_l = p.gl_sh * l_wet;
-    sh.glwv_l = p.gl_wv * l_wet;
+    sh.glwv_l = p.gl_wv * lai;
     sh.glsh_lai = p.gl_sh * lai;
-    // Tmin ramp, :1148 (continuous: a float32 tie decides nothing)
-    const f2 tm = (col(8) - splat(273.f)) - splat(0.15f);
-    const f2 tmin_close = par(0), tmin_open = par(1);
-    sh.m_tmin = sel(tm.x >= tmin_open.x, tm.y >= tmin_open.y, splat(1.f),
-                    sel(tm.x < tmin_close.x, tm.y < tmin_close.y, zero, (tm - tmin_close) * par(11)));
+    // csl x the Tmin ramp, :1148: clamp01((tmin - 273.15 - tmin_close) / (tmin_open - tmin_close)),
+    // continuous (a float32 tie decides nothing). The clamp drops a NaN Tmin, which the reference
+    // carries into the day's transpiration: tmin * 0 brings it back (an INFINITE Tmin -- 1 or 0 in the
+    // reference -- is outside the form's domain since round 6: pair_out_of_domain).
+    const f2 tmin = col(8);
+    const f2 tm = (tmin - splat(273.f)) - splat(0.15f);
+    sh.csl_m = __builtin_elementwise_fma(par(7), clamp01((tm - par(0)) * par(11)), tmin * zero);
     day = period_mixed<true, PET>(p, sh, hd, t_d, col(9), a_d, rs_d);
     night = period_mixed<false, PET>(p, sh, hn, t_n, col(10), rn_n, rs_n);
+    // the cancellation class (see period_mixed): the caller marks these pixels for the pass behind the
+    // pipeline's loop, which computes them in float64
+    if (cancel) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float m;
+            asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(day.zc[e]), "v"(day.zs[e]), "v"(night.zc[e]));
+            asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(night.zs[e]));
+            cancel[e] = m < 0.f;
+        }
+    }
 }
 
 // Raw drivers (calibration.py:380-423) for the mixed form: the
@@ -394,10 +481,10 @@ __device__ __forceinline__ void raw_pair_mixed(const float (&raw)[14][2], const 
 // meant for physical drivers, so its domain is drawn tightly around them (mapped with
 // tests/fuzz_domain.py: outside it NaN / zero masks start to differ from the float64
 // arithmetic's, or values by more than 1e-3):
-//     |lw|, |sw|, |albedo|, |vpd|, |fpar|, |lai| < 1e5;  1e3 <= pressure < 1e7 Pa;
+//     |lw|, |sw|, |albedo|, |vpd|, |fpar|, |lai|, |tmin| < 1e5;  1e3 <= pressure < 1e7 Pa;
 //     90 K < temp_day, temp_night < 1332 K                  (NaN anywhere: inside)
 // Every condition is brought to the form |y| >= 1e5 -- the temperatures and the pressure by
-// one packed fma for both pixels -- and the twelve values of a pixel go through one chain of
+// one packed fma for both pixels -- and the thirteen values of a pixel go through one chain of
 // v_max3_f32 with |.| modifiers, which ignores NaN operands: 8.5 vector instructions per pixel.
 // A flagged pixel is computed again by et_pixel_exact<double> on the widened inputs, like a
 // flagged pixel of the FAST form on a float32 raster (mod16_stream.hpp).
@@ -435,9 +522,9 @@ __device__ __forceinline__ f2 guard_scale_p(f2 p) {
 }
 __device__ __forceinline__ unsigned pair_out_of_domain(const float (&in)[14][2]) {
     auto col = [&](int k) { return f2{in[k][0], in[k][1]}; };
-    const f2 y[12] = {col(0), col(1), col(2), col(3), col(4), col(9), col(10), col(12), col(13),
-                      guard_scale_t(col(5)), guard_scale_t(col(6)), guard_scale_p(col(11))};
-    return pair_guard<12>(y);
+    const f2 y[13] = {col(0), col(1), col(2), col(3), col(4), col(9), col(10), col(12), col(13),
+                      guard_scale_t(col(5)), guard_scale_t(col(6)), guard_scale_p(col(11)), col(8)};
+    return pair_guard<13>(y);
 }
 // raw drivers (raw_pair_mixed): the fields that pass through as above; specific humidity
 // below 1 kg/kg, the surface pressures like the air pressure, |elevation| below 25 km (the air
@@ -450,11 +537,11 @@ __device__ __forceinline__ f2 guard_scale_traw(f2 t) {
 }
 __device__ __forceinline__ unsigned raw_pair_out_of_domain(const float (&raw)[14][2]) {
     auto col = [&](int k) { return f2{raw[k][0], raw[k][1]}; };
-    const f2 y[12] = {col(0), col(1), col(2), col(3), col(4), col(9) * splat(kGuardMixed),
+    const f2 y[13] = {col(0), col(1), col(2), col(3), col(4), col(9) * splat(kGuardMixed),
                       col(10) * splat(kGuardMixed), col(13) * splat(4.f),
                       guard_scale_traw(col(5)), guard_scale_traw(col(6)), guard_scale_p(col(11)),
-                      guard_scale_p(col(12))};
-    return pair_guard<12>(y);
+                      guard_scale_p(col(12)), col(8)};
+    return pair_guard<13>(y);
 }
 
 // The same two guards for ONE pixel given as (widened) float64 values -- the slow branch
@@ -479,21 +566,22 @@ __device__ __forceinline__ bool out_of_domain_f32(const PixelIn<double>& x) {
 #ifdef MOD16_NO_GUARD
     return false;
 #else
-    const float y[12] = {(float)x.lw_d, (float)x.lw_n, (float)x.sw_d, (float)x.sw_n, (float)x.alb,
+    const float y[13] = {(float)x.lw_d, (float)x.lw_n, (float)x.sw_d, (float)x.sw_n, (float)x.alb,
                          (float)x.vpd_d, (float)x.vpd_n, (float)x.fpar, (float)x.lai,
-                         guard_scale_t1((float)x.t_d), guard_scale_t1((float)x.t_n), guard_scale_p1((float)x.pa)};
-    return guard_list_f32(y, 12);
+                         guard_scale_t1((float)x.t_d), guard_scale_t1((float)x.t_n), guard_scale_p1((float)x.pa),
+                         (float)x.tmin};
+    return guard_list_f32(y, 13);
 #endif
 }
 __device__ __forceinline__ bool raw_out_of_domain_f32(const RawIn<double>& r) {
 #ifdef MOD16_NO_GUARD
     return false;
 #else
-    const float y[12] = {(float)r.lw_d, (float)r.lw_n, (float)r.sw_d, (float)r.sw_n, (float)r.alb,
+    const float y[13] = {(float)r.lw_d, (float)r.lw_n, (float)r.sw_d, (float)r.sw_n, (float)r.alb,
                          (float)r.qv_d * kGuardMixed, (float)r.qv_n * kGuardMixed, (float)r.elev * 4.f,
                          guard_scale_traw1((float)r.t_d), guard_scale_traw1((float)r.t_n),
-                         guard_scale_p1((float)r.ps_d), guard_scale_p1((float)r.ps_n)};
-    return guard_list_f32(y, 12);
+                         guard_scale_p1((float)r.ps_d), guard_scale_p1((float)r.ps_n), (float)r.tmin};
+    return guard_list_f32(y, 13);
 #endif
 }
 
@@ -503,8 +591,8 @@ __device__ __forceinline__ void et_pair_mixed(const float (&in)[14][2], const do
                                               f2& day, f2& night) {
     Parts2 d, n;
     et_pair_mixed_parts<false>(in, l0, l1, ls, tb, d, n);
-    day = (d.canopy + d.soil) + d.trans;
-    night = (n.canopy + n.soil) + n.trans;
+    day = d.total;
+    night = n.total;
 }
 
 }  // namespace mod16

@@ -111,6 +111,10 @@ template <typename T> struct StreamArgs {
     double* diag_out;          // 8 doubles
     unsigned* done_counter;    // blocks finished; the last block leaves it at 0 again
     int64_t nruns;             // partials to add (runs, or waves with work under the static schedule)
+    // Mixed-precision forms, dynamic schedule: [runs][kCancelCap] pixels of the cancellation class
+    // (mod16_mixed.hpp), as (piece of the run << 8 | lane << 2 | pixel of the lane), in the order
+    // (piece, pixel, lane); the count travels in the run's partial (kCancelShift)
+    uint16_t* cancel_list;
 };
 constexpr int kNoTile = 40;    // more pieces per "tile" than any raster has: one tile, plain arrays
 static_assert(__builtin_offsetof(StreamArgs<double>, wide) == 0 &&
@@ -196,11 +200,20 @@ struct RedoAcc {
     unsigned num_d = 0, num_n = 0;      // flagged pixels whose true total is a number (per lane)
 };
 
-template <typename T, int MODE>
-__device__ __forceinline__ void redo_piece(const StreamArgs<T>& a, const double* lut, int64_t piece, int lane,
-                                           RedoAcc& acc) {
+// redo_pixel: ONE pixel again (element offsets ow / oo / ob of the pixel in the wide, output and byte
+// arrays), in float64 whatever the storage type; stores its outputs, returns the totals as stored.
+//   LISTED = false  a pixel of a flagged piece: asks the guard again (exactly the hot path's predicate,
+//                   so exactly the flagged pixels are redone) -> the reference's operation order; with
+//                   `marked` (mixed-precision forms under the static schedule) also a pixel of the
+//                   cancellation class (mod16_mixed.hpp, period_mixed), which the loop marked with
+//                   kCancelPoison in its first output -> the FAST form's float64 arithmetic on the
+//                   widened inputs (`tb`: its exp / log tables): what the FAST kernel stores for it;
+//   LISTED = true   a pixel of a run's cancellation list (dynamic schedule): the FAST form, unasked.
+// Returns false if the pixel needed nothing.
+template <typename T, int MODE, bool LISTED>
+__device__ __forceinline__ bool redo_pixel(const StreamArgs<T>& a, const double* lut, const double* tb,
+                                           int64_t ow, int64_t oo, int64_t ob, bool marked, double& d, double& g) {
     typedef StreamSpec<MODE> S;
-    constexpr int V = 16 / (int)sizeof(T);
     constexpr int NW = S::NW, NB = S::NB;
     constexpr bool kSep6 = MODE == kStreamSep6 || MODE == kStreamSep6Mixed;
     constexpr bool kSep8 = MODE == kStreamSep8 || MODE == kStreamSep8Mixed;
@@ -210,69 +223,100 @@ __device__ __forceinline__ void redo_piece(const StreamArgs<T>& a, const double*
     constexpr bool kRawAny = MODE == kStreamRaw || MODE == kStreamRawTotal || MODE == kStreamRawTotalHours ||
                              MODE == kStreamRawMixed || MODE == kStreamRawTotalMixed ||
                              MODE == kStreamRawTotalHoursMixed;
+    auto wide = [&](int k) -> double { return (double)a.wide[k][ow]; };
+    PixelIn<double> x;
+    RawIn<double> r;
+    bool out = false;
+    if constexpr (kRawAny) {
+        r = RawIn<double>{wide(0), wide(1), wide(2), wide(3), wide(4), wide(5), wide(6),
+                          wide(7), wide(8), wide(9), wide(10), wide(11), wide(12), wide(13),
+                          (unsigned)a.bytes[NB > 1 ? 1 : 0][ob], (unsigned)a.bytes[NB > 2 ? 2 : 0][ob]};
+        if constexpr (!LISTED) {
+            if constexpr (stream_is_mixed(MODE)) out = raw_out_of_domain_f32(r);
+            else out = raw_out_of_domain(r);
+        }
+    } else {
+        x = PixelIn<double>{wide(0), wide(1), wide(2), wide(3), wide(4), wide(5), wide(6),
+                            wide(7), wide(8), wide(9), wide(10), wide(11), wide(12), wide(13)};
+        if constexpr (!LISTED) {
+            if constexpr (stream_is_mixed(MODE)) out = out_of_domain_f32(x);
+            else out = fast_out_of_domain(x);
+        }
+    }
+    bool cancel = LISTED;
+    if constexpr (!LISTED && stream_is_mixed(MODE) && sizeof(T) == 4) {
+        if (marked && !out)
+            cancel = __float_as_uint(__hip_atomic_load(reinterpret_cast<const float*>(a.out[0]) + oo, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT)) == kCancelPoison;
+    }
+    if (!out && !cancel) return false;
+    if constexpr (kRawAny) x = raw_to_pixel_exact<double, true>(r);
+    unsigned c = a.bytes[0][ob];
+    c = c >= 13u ? 13u : c;
+    const double* l = lut + c;
+    ClassPar<double> p;
+    p.tmin_close = l[0 * kLutCols];
+    p.tmin_open = l[1 * kLutCols];
+    p.vpd_open = l[2 * kLutCols];
+    p.vpd_close = l[3 * kLutCols];
+    p.gl_sh = l[4 * kLutCols];
+    p.gl_wv = l[5 * kLutCols];
+    p.g_cut = l[6 * kLutCols];
+    p.csl = l[7 * kLutCols];
+    p.rbl_min = l[8 * kLutCols];
+    p.rbl_max = l[9 * kLutCols];
+    p.beta = l[10 * kLutCols];
+    PixelOut<double> o;
+    if (cancel) {
+        p.inv_dtmin = l[11 * kLutCols];
+        p.inv_dvpd = l[12 * kLutCols];
+        p.rbl_slope = l[13 * kLutCols];
+        p.inv_beta = l[14 * kLutCols];
+        o = et_pixel_fast<double, kPet>(x, p, tb);
+    } else {
+        if constexpr (!LISTED) o = et_pixel_exact<double, kPet, true>(x, p);
+    }
+    const double day = (o.canopy_d + o.soil_d) + o.trans_d;      // :792
+    const double night = (o.canopy_n + o.soil_n) + o.trans_n;
+    auto put = [&](int k, double val) { a.out[k][oo] = (T)val; };
+    if constexpr (kSep6) {
+        put(0, o.canopy_d); put(1, o.soil_d); put(2, o.trans_d);
+        put(3, o.canopy_n); put(4, o.soil_n); put(5, o.trans_n);
+    } else {
+        put(0, day);
+        put(1, night);
+    }
+    if constexpr (kPet) { put(2, o.pet_d); put(3, o.pet_n); }
+    if constexpr (kSep8) {
+        put(2, o.canopy_d); put(3, o.soil_d); put(4, o.trans_d);
+        put(5, o.canopy_n); put(6, o.soil_n); put(7, o.trans_n);
+    }
+    if constexpr (kTotal8) {
+#pragma clang fp contract(off)
+        // tests/verification/verify2.py:113-115
+        double h = a.hours;
+        if constexpr (kHoursArr) h = wide(NW - 1);
+        put(2, (day * h * 8.0 * 60.0 * 60.0) + (night * (24.0 - h) * 8.0 * 60.0 * 60.0));
+    }
+    d = (double)(T)day;      // as stored
+    g = (double)(T)night;
+    return true;
+}
+
+// redo_piece: lane `lane`'s V pixels of piece `piece` (see redo_pixel, LISTED = false), with what
+// the diagnostics must get back accumulated per lane.
+template <typename T, int MODE>
+__device__ __forceinline__ void redo_piece(const StreamArgs<T>& a, const double* lut, const double* tb,
+                                           int64_t piece, int lane, bool marked, RedoAcc& acc) {
+    constexpr int V = 16 / (int)sizeof(T);
     if ((piece * 64 + lane) * V >= a.n) return;          // the ragged last piece
     const int64_t tile = piece >> a.tile_shift;
     const int64_t q = (piece - (tile << a.tile_shift)) * (int64_t)(64 * V) + (int64_t)lane * V;
     const int64_t ow = tile * a.wide_row + q, oo = tile * a.out_row + q, ob = tile * a.byte_row + q;
 #pragma nounroll
     for (int j = 0; j < V; ++j) {
-        auto wide = [&](int k) -> double { return (double)a.wide[k][ow + j]; };
-        PixelIn<double> x;
-        RawIn<double> r;
-        bool out;
-        if constexpr (kRawAny) {
-            r = RawIn<double>{wide(0), wide(1), wide(2), wide(3), wide(4), wide(5), wide(6),
-                              wide(7), wide(8), wide(9), wide(10), wide(11), wide(12), wide(13),
-                              (unsigned)a.bytes[NB > 1 ? 1 : 0][ob + j], (unsigned)a.bytes[NB > 2 ? 2 : 0][ob + j]};
-            if constexpr (stream_is_mixed(MODE)) out = raw_out_of_domain_f32(r);
-            else out = raw_out_of_domain(r);
-        } else {
-            x = PixelIn<double>{wide(0), wide(1), wide(2), wide(3), wide(4), wide(5), wide(6),
-                                wide(7), wide(8), wide(9), wide(10), wide(11), wide(12), wide(13)};
-            if constexpr (stream_is_mixed(MODE)) out = out_of_domain_f32(x);
-            else out = fast_out_of_domain(x);
-        }
-        if (!out) continue;
-        if constexpr (kRawAny) x = raw_to_pixel_exact<double, true>(r);
-        unsigned c = a.bytes[0][ob + j];
-        c = c >= 13u ? 13u : c;
-        const double* l = lut + c;
-        ClassPar<double> p;
-        p.tmin_close = l[0 * kLutCols];
-        p.tmin_open = l[1 * kLutCols];
-        p.vpd_open = l[2 * kLutCols];
-        p.vpd_close = l[3 * kLutCols];
-        p.gl_sh = l[4 * kLutCols];
-        p.gl_wv = l[5 * kLutCols];
-        p.g_cut = l[6 * kLutCols];
-        p.csl = l[7 * kLutCols];
-        p.rbl_min = l[8 * kLutCols];
-        p.rbl_max = l[9 * kLutCols];
-        p.beta = l[10 * kLutCols];
-        const PixelOut<double> o = et_pixel_exact<double, kPet, true>(x, p);
-        const double day = (o.canopy_d + o.soil_d) + o.trans_d;      // :792
-        const double night = (o.canopy_n + o.soil_n) + o.trans_n;
-        auto put = [&](int k, double val) { a.out[k][oo + j] = (T)val; };
-        if constexpr (kSep6) {
-            put(0, o.canopy_d); put(1, o.soil_d); put(2, o.trans_d);
-            put(3, o.canopy_n); put(4, o.soil_n); put(5, o.trans_n);
-        } else {
-            put(0, day);
-            put(1, night);
-        }
-        if constexpr (kPet) { put(2, o.pet_d); put(3, o.pet_n); }
-        if constexpr (kSep8) {
-            put(2, o.canopy_d); put(3, o.soil_d); put(4, o.trans_d);
-            put(5, o.canopy_n); put(6, o.soil_n); put(7, o.trans_n);
-        }
-        if constexpr (kTotal8) {
-#pragma clang fp contract(off)
-            // tests/verification/verify2.py:113-115
-            double h = a.hours;
-            if constexpr (kHoursArr) h = wide(NW - 1);
-            put(2, (day * h * 8.0 * 60.0 * 60.0) + (night * (24.0 - h) * 8.0 * 60.0 * 60.0));
-        }
-        const double d = (double)(T)day, g = (double)(T)night;      // as stored
+        double d, g;
+        if (!redo_pixel<T, MODE, false>(a, lut, tb, ow + j, oo + j, ob + j, marked, d, g)) continue;
         if (d == d) { acc.sum_d += d; acc.num_d += 1u; acc.max_d = d > acc.max_d ? d : acc.max_d; }
         if (g == g) { acc.sum_n += g; acc.num_n += 1u; acc.max_n = g > acc.max_n ? g : acc.max_n; }
     }
@@ -298,6 +342,10 @@ __device__ __forceinline__ double redo_fold(const RedoAcc& acc, int lane, double
 }
 constexpr int kFlagField = 2;        // the field of a diagnostics partial that carries the flags
 constexpr int kFlagBits = 52;        // ... as an exact integer in a double
+// Dynamic schedule, mixed-precision forms: the same field also counts the run's cancellation list
+// (bits kCancelShift ...; piece flags then use the bits below, the last one standing for every later piece)
+constexpr int kCancelShift = 44;
+constexpr int kCancelCap = 32;       // entries per run (64 bytes = one partial's size, behind the partials)
 
 // PITCHED: the wide arrays are equally spaced (one slab, as
 // RasterEngine.alloc_raster lays them out): array k's address is wide[0] +
@@ -381,6 +429,11 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     // where scalar registers are what hipcc runs out of
     unsigned long long flags = 0;
     asm volatile("" : "+v"(flags));
+    // entries of the current run's cancellation list (mixed-precision forms, dynamic schedule);
+    // wave-uniform and in a vector register for the same reason
+    unsigned cancel_cnt = 0;
+    constexpr bool kLists = stream_is_mixed(MODE) && GUARD;
+    if constexpr (kLists) asm volatile("" : "+v"(cancel_cnt));
     // the launch's serial number (word [3] of the ticket counter's block; the last block of a launch
     // increments it): every run's partial carries it, and what runs behind this kernel counts the
     // runs that do -- a launch that met a stale ticket counter and processed only its first runs is
@@ -408,13 +461,17 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         }
         const double cnt_d = (double)__builtin_amdgcn_readfirstlane(nan_d);
         const double cnt_n = (double)__builtin_amdgcn_readfirstlane(nan_n);
-        const double f = lane == 0 ? dsum_d : lane == 1 ? dsum_n : lane == kFlagField ? (double)flags
+        unsigned long long flag_word = flags;
+        if constexpr (kLists)
+            flag_word |= (unsigned long long)(cancel_cnt < (unsigned)kCancelCap ? cancel_cnt : (unsigned)kCancelCap) << kCancelShift;
+        const double f = lane == 0 ? dsum_d : lane == 1 ? dsum_n : lane == kFlagField ? (double)flag_word
                        : lane == kSerialField ? launch_marker(serial)
                        : lane == 4 ? cnt_d : lane == 5 ? cnt_n : lane == 6 ? dmax_d : lane == 7 ? dmax_n : 0.0;
         dsum_d = dsum_n = 0.0;
         dmax_d = dmax_n = -__builtin_huge_val();
         nan_d = nan_n = 0;
         flags = 0;
+        cancel_cnt = 0;
         return f;
     };
     struct Ptrs { const char* w[NW]; const char* b[NB]; };
@@ -479,7 +536,11 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) {
         const double x = a.lut64[i];
         lut[i] = x;
-        if constexpr (stream_is_mixed(MODE)) lut32[i] = (float)x;
+        // (the float32 copy of the mixed form holds rbl_max - rbl_min where the float64 forms keep the
+        // ramp's slope: mod16_mixed.hpp, kLutDrbl)
+        if constexpr (stream_is_mixed(MODE))
+            lut32[i] = i / kLutCols == kLutDrbl ? (float)(a.lut64[9 * kLutCols + i % kLutCols] - a.lut64[8 * kLutCols + i % kLutCols])
+                                                : (float)x;
     }
     for (int i = threadIdx.x; i < kTab; i += kBlock) tab[i] = a.tab[i];
     __syncthreads();
@@ -504,7 +565,14 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
             asm volatile("" : "+v"(ticket));
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ticket);
             const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ticket >> 32));
-            next_base = (nwaves + (int64_t)(((unsigned long long)hi << 32) | lo)) << rs;
+            // WHATEVER 64 bits sat in the counter (round 6): a ticket beyond the raster's pieces says
+            // "nothing left" -- compared unsigned and clamped before the shift, so that no value can
+            // overflow into a base the loop guard accepts (round 5's injected 0x3f3f... did: a wild
+            // DMA read and a wild store). A stale ticket INSIDE the raster only skips runs, which the
+            // markers report (kStatusIncomplete). Scalar, once per run: not in the per-piece path.
+            unsigned long long tk = ((unsigned long long)hi << 32) | lo;
+            tk = tk > (unsigned long long)npiece ? (unsigned long long)npiece : tk;
+            next_base = (nwaves + (int64_t)tk) << rs;
         }
         typedef typename Vec<T, V>::type VT;
         VT in[NW];
@@ -557,6 +625,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                     for (int k = 0; k < 14; ++k) { pin[k][0] = in[k][jj]; pin[k][1] = in[k][jj + 1]; }
                     const unsigned c0 = cls_of[jj], c1 = cls_of[jj + 1];
                     Parts2 pd, pn;
+                    bool cancel2[2] = {false, false};
                     constexpr bool kRawMixed = MODE == kStreamRawMixed || MODE == kStreamRawTotalMixed ||
                                                MODE == kStreamRawTotalHoursMixed;
                     if constexpr (kRawMixed) {
@@ -569,7 +638,8 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                         fp[0] = (b2 & 1u) ? 255u : fp[0];        // a fill code: fPAR = NaN
                         fp[1] = (b2 & 2u) ? 255u : fp[1];
                         raw_pair_mixed(pin, fp, lx, tab, din, hum);
-                        et_pair_mixed_parts<false, true>(din, lut + c0, lut + c1, kLutCols, tab, pd, pn, nullptr, lutf + c0, lutf + c1, hum);
+                        et_pair_mixed_parts<false, true>(din, lut + c0, lut + c1, kLutCols, tab, pd, pn, nullptr, lutf + c0, lutf + c1, hum,
+                                                         GUARD ? cancel2 : nullptr);
                     } else {
                         if constexpr (GUARD) {
                             const unsigned b2 = pair_out_of_domain(pin);
@@ -577,10 +647,47 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                             pin[12][0] = (b2 & 1u) ? __builtin_nanf("") : pin[12][0];
                             pin[12][1] = (b2 & 2u) ? __builtin_nanf("") : pin[12][1];
                         }
-                        et_pair_mixed_parts<MODE == kStreamPetMixed, true>(pin, lut + c0, lut + c1, kLutCols, tab, pd, pn, nullptr, lutf + c0, lutf + c1);
+                        et_pair_mixed_parts<MODE == kStreamPetMixed, true>(pin, lut + c0, lut + c1, kLutCols, tab, pd, pn, nullptr, lutf + c0, lutf + c1,
+                                                                           nullptr, GUARD ? cancel2 : nullptr);
                     }
-                    const f2 day2 = (pd.canopy + pd.soil) + pd.trans;        // :792
-                    const f2 night2 = (pn.canopy + pn.soil) + pn.trans;
+                    f2 day2 = pd.total, night2 = pn.total;                   // :792
+                    if constexpr (GUARD) {
+                        // the cancellation class (mod16_mixed.hpp; about one wave-iteration in ten holds such a
+                        // pixel): it is MARKED -- its first output holds kCancelPoison, both totals count as NaN
+                        // in the run's diagnostics -- and what runs behind the loop puts the float64 result in
+                        // its place. Dynamic schedule: the pixel joins its run's list, in the order (piece,
+                        // pixel, lane), which et_stream_redo_kernel works off with the pixels of 64 runs side by
+                        // side in the lanes of a wave; a run whose list is full leaves the pixel its float32
+                        // value. Static schedule (small rasters): the piece is flagged like one with a pixel
+                        // outside the domain and the wave revisits it behind its loop (redo_piece).
+                        if (__builtin_expect(__any(cancel2[0] | cancel2[1]), 0)) {
+                            bool mark[2] = {cancel2[0], cancel2[1]};
+                            if (a.static_sched) {
+                                bad |= cancel2[0] | cancel2[1];
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 2; ++e) {
+                                    const unsigned long long b = __ballot(cancel2[e]);
+                                    const unsigned slot = cancel_cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+                                    mark[e] = cancel2[e] & (slot < (unsigned)kCancelCap);
+                                    if (mark[e]) {
+                                        // (the list's address: read from the kernel arguments here, in the cold
+                                        // branch, rather than held in a scalar pair all through the loop)
+                                        kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+                                        asm volatile("" : "+s"(ka));
+                                        uint16_t* list = *reinterpret_cast<uint16_t* const __attribute__((address_space(4)))*>(
+                                            ka + __builtin_offsetof(StreamArgs<T>, cancel_list));
+                                        list[(cbase >> rs) * kCancelCap + slot] = (uint16_t)((run << 8) | (lane << 2) | (jj + e));
+                                    }
+                                    cancel_cnt += (unsigned)__builtin_popcountll(b);
+                                }
+                            }
+                            const f2 poison = splat(__uint_as_float(kCancelPoison));
+                            day2 = sel(mark[0], mark[1], poison, day2);
+                            night2 = sel(mark[0], mark[1], poison, night2);
+                            if constexpr (MODE == kStreamSep6Mixed) pd.canopy = sel(mark[0], mark[1], poison, pd.canopy);
+                        }
+                    }
                     auto put = [&](int k, f2 v) { res[k][jj] = v.x; res[k][jj + 1] = v.y; };
                     if constexpr (MODE == kStreamSep6Mixed) {
                         put(0, pd.canopy); put(1, pd.soil); put(2, pd.trans);
@@ -594,7 +701,8 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                         f2 h = splat((float)a.hours);
                         if constexpr (MODE == kStreamRawTotalHoursMixed) h = f2{in[14][jj], in[14][jj + 1]};
                         const f2 k8 = splat(8.f * 3600.f);
-                        put(2, (day2 * h) * k8 + (night2 * (splat(24.f) - h)) * k8);
+                        // (the contraction written out: every instance of the kernel rounds alike)
+                        put(2, __builtin_elementwise_fma(day2 * h, k8, (night2 * (splat(24.f) - h)) * k8));
                     }
                     if constexpr (MODE == kStreamSep8Mixed) {
                         put(2, pd.canopy); put(3, pd.soil); put(4, pd.trans);
@@ -730,7 +838,8 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                 if constexpr (!stream_is_mixed(MODE) && !RAW) bad = gmax >= gc.huge;
                 if (__builtin_expect(__any(bad), 0)) {
                     const int bit = a.static_sched ? iters : run;
-                    flags |= 1ull << (bit < kFlagBits - 1 ? bit : kFlagBits - 1);
+                    const int last = a.static_sched ? kFlagBits - 1 : kCancelShift - 1;
+                    flags |= 1ull << (bit < last ? bit : last);
                 }
             }
         }
@@ -810,7 +919,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                     const int bit = i < kFlagBits - 1 ? i : kFlagBits - 1;
                     if (!((mine >> bit) & 1ull)) continue;
                     const int64_t piece = ((w0 + (int64_t)(i >> rs) * nwaves) << rs) + (i & (rl - 1));
-                    redo_piece<T, MODE>(a, lut, piece, lane, acc);
+                    redo_piece<T, MODE>(a, lut, tab, piece, lane, true, acc);
                 }
                 f = redo_fold(acc, lane, f);
             }
@@ -894,21 +1003,33 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
 #endif
 }
 
-// The flagged pieces of a large raster (dynamic schedule), behind the pipeline kernel: a wave
-// takes 64 runs at a time (lane l reads the flag field of run r0 + l), and for every run with a
-// flag revisits its flagged pieces and corrects the run's partial -- it is the only one touching
-// that run here, and the fixed-order sum over the partials runs behind this kernel. A raster
-// without flagged pixels costs this kernel one 8-byte load per run (global grid: 3.5 MB).
+// What a large raster (dynamic schedule) left for behind the pipeline kernel: a wave takes 64 runs at
+// a time (lane l reads the flag field of run r0 + l).
+//   - Mixed-precision forms: the runs' cancellation lists (see the loop). The pixels of all 64 runs
+//     are computed side by side in the lanes of the wave -- entry e of the concatenated lists by lane
+//     e % 64: one gather and one pass through the float64 pixel function per 64 pixels, where going
+//     run by run cost a pass per run (nine runs in ten hold one or two such pixels: measured 4.6 ms on
+//     the global grid, per flagged piece) -- and every run's owner lane then adds ITS pixels' totals
+//     to its partial in list order: the sums do not depend on which lane computed what.
+//   - Every run with a piece flag: its flagged pieces revisited (pixels outside the domain of the
+//     production arithmetic, redo_piece), the run's partial corrected -- the wave is the only one
+//     touching that run here, and the fixed-order sum over the partials runs behind this kernel.
+// A raster without any of it costs this kernel one 8-byte load per run (global grid: 3.5 MB).
 template <typename T, int MODE>
 __global__ void __launch_bounds__(kBlock) et_stream_redo_kernel(const StreamArgs<T> a) {
     constexpr int V = 16 / (int)sizeof(T);
     ignore_signalling_nans();       // the guard is asked again: the same answer as in the pipeline kernel
     __shared__ double lut[MOD16_LUT_ROWS * kLutCols];
+    // cancellation lists: who[wave][e] = (owner lane << 8 | entry of its list) of entry e of the 64 runs'
+    // concatenated lists; vals[wave][lane] = the totals lane `lane` computed in this batch
+    __shared__ uint16_t who[stream_is_mixed(MODE) ? kBlock / 64 : 1][stream_is_mixed(MODE) ? 64 * kCancelCap : 1];
+    __shared__ double vals[stream_is_mixed(MODE) ? kBlock / 64 : 1][stream_is_mixed(MODE) ? 64 : 1][2];
     for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) lut[i] = a.lut64[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
     const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
-    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + wv;
     const int64_t npiece = (a.n / V + 63) / 64;
     const int rs = a.run_shift;
     // every run's partial must carry the marker of the launch in front of this kernel (which has
@@ -920,18 +1041,69 @@ __global__ void __launch_bounds__(kBlock) et_stream_redo_kernel(const StreamArgs
         const double fl = mine < a.nruns ? a.diag_partial[mine * kDiag + kFlagField] : 0.0;
         const double mk = mine < a.nruns ? a.diag_partial[mine * kDiag + kSerialField] : marker;
         if (__any(mk != marker) && lane == 0) atomicOr(a.status, kStatusIncomplete);
-        unsigned long long any = __ballot(fl != 0.0);
+        const unsigned long long flbits = (unsigned long long)fl;
+        if constexpr (stream_is_mixed(MODE)) {
+            const int cnt = (int)(flbits >> kCancelShift);          // (<= kCancelCap)
+            if (__any(cnt != 0)) {
+                int incl = cnt;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int up = __shfl_up(incl, off, 64);
+                    incl += lane >= off ? up : 0;
+                }
+                const int excl = incl - cnt, total = __shfl(incl, 63, 64);
+                for (int k = 0; k < cnt; ++k) who[wv][excl + k] = (uint16_t)((lane << 8) | k);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (one wave: its LDS accesses are in order)
+                double sum_d = 0.0, sum_n = 0.0, max_d = -__builtin_huge_val(), max_n = -__builtin_huge_val();
+                unsigned num_d = 0, num_n = 0;
+                for (int base = 0; base < total; base += 64) {
+                    const int e = base + lane;
+                    double d = __builtin_nan(""), g = __builtin_nan("");
+                    if (e < total) {
+                        const unsigned w = who[wv][e];
+                        const int64_t run = r0 + (w >> 8);
+                        const unsigned ent = a.cancel_list[run * kCancelCap + (w & 255u)];
+                        const int64_t piece = (run << rs) + (ent >> 8);
+                        const int64_t tile = piece >> a.tile_shift;
+                        const int64_t q = (piece - (tile << a.tile_shift)) * (int64_t)(64 * V) + (int64_t)((ent >> 2) & 63u) * V + (ent & 3u);
+                        redo_pixel<T, MODE, true>(a, lut, a.tab, tile * a.wide_row + q, tile * a.out_row + q, tile * a.byte_row + q, false, d, g);
+                    }
+                    vals[wv][lane][0] = d;
+                    vals[wv][lane][1] = g;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // the owner adds its run's pixels of this batch, in list order
+                    const int lo = excl > base ? excl : base, hi = incl < base + 64 ? incl : base + 64;
+                    for (int i = lo; i < hi; ++i) {
+                        const double vd = vals[wv][i - base][0], vg = vals[wv][i - base][1];
+                        if (vd == vd) { sum_d += vd; num_d += 1u; max_d = vd > max_d ? vd : max_d; }
+                        if (vg == vg) { sum_n += vg; num_n += 1u; max_n = vg > max_n ? vg : max_n; }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (before the next batch overwrites vals)
+                }
+                if (cnt != 0) {
+                    double* part = a.diag_partial + mine * kDiag;
+                    part[0] += sum_d;
+                    part[1] += sum_n;
+                    part[4] -= (double)num_d;
+                    part[5] -= (double)num_n;
+                    part[6] = max_d > part[6] ? max_d : part[6];
+                    part[7] = max_n > part[7] ? max_n : part[7];
+                }
+                __threadfence();         // the piece flags' pass below reads partials through other lanes
+            }
+        }
+        unsigned long long any = __ballot((flbits & ((1ull << kCancelShift) - 1ull)) != 0ull);
         while (any) {
             const int src = __builtin_ctzll(any);
             any &= any - 1ull;
             const int64_t run = r0 + src;
-            const unsigned long long flags = (unsigned long long)__shfl(fl, src, 64);
+            const unsigned long long flags = (unsigned long long)__shfl(fl, src, 64) & ((1ull << kCancelShift) - 1ull);
             RedoAcc acc;
 #pragma nounroll
             for (int i = 0; i < (1 << rs); ++i) {
-                const int bit = i < kFlagBits - 1 ? i : kFlagBits - 1;
+                const int bit = i < kCancelShift - 1 ? i : kCancelShift - 1;
                 const int64_t piece = (run << rs) + i;
-                if (((flags >> bit) & 1ull) && piece < npiece) redo_piece<T, MODE>(a, lut, piece, lane, acc);
+                if (((flags >> bit) & 1ull) && piece < npiece) redo_piece<T, MODE>(a, lut, a.tab, piece, lane, false, acc);
             }
             double* part = a.diag_partial + run * kDiag;
             const double f = lane < kDiag ? part[lane] : 0.0;

@@ -154,6 +154,9 @@ static void shadow_stream(const StreamArgs<T>& a, int mode, bool pitched, dim3 g
     need(a.tab, sizeof(double) * FastMath<double>::kTabDoubles, 16, "exp / log tables", name);
     need(a.status, 4, 4, "status word", name);
     need(a.diag_partial, sizeof(double) * kDiag * (size_t)a.nruns, 8, "diagnostics partials", name);
+    // the runs' cancellation lists (mixed-precision forms under the dynamic schedule write them)
+    if (!a.static_sched && stream_is_mixed(mode))
+        need(a.cancel_list, sizeof(uint16_t) * kCancelCap * (size_t)a.nruns, 2, "cancellation lists", name);
     if (a.diag_out) {
         need(a.diag_out, sizeof(double) * kDiag, 8, "diagnostics vector", name);
         need(a.done_counter, 4, 4, "blocks-done counter", name);
@@ -242,6 +245,7 @@ static void run_shadow(const std::string& name, dim3 grid, dim3 block, void** ar
         } else {
             const auto& a = *static_cast<const StreamArgs<float>*>(args[0]);
             need(a.diag_partial, sizeof(double) * kDiag * (size_t)a.nruns, 8, "diagnostics partials", n);
+            need(a.cancel_list, sizeof(uint16_t) * kCancelCap * (size_t)a.nruns, 2, "cancellation lists", n);
         }
     } else if (has(name, "9et_kernelI")) {
         const size_t at = name.find("9et_kernelI") + 11;

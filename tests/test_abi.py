@@ -166,7 +166,7 @@ def test_shipped_library_reads_no_experiment_switch(lib):
         blob = open(path, 'rb').read()
         return set(m.decode() for m in re.findall(rb'MOD16_[A-Z0-9_]{3,}', blob))
     switches = {'MOD16_NO_DMA', 'MOD16_RUN_SHIFT', 'MOD16_STATIC_BELOW', 'MOD16_STREAM_BLOCKS',
-                'MOD16_PITCH', 'MOD16_GRID_MULT', 'MOD16_POISON_TICKET'}
+                'MOD16_PITCH', 'MOD16_GRID_MULT', 'MOD16_POISON_TICKET', 'MOD16_POISON_BYTE'}
     shipped = env_names(lib.LIB_PATH)      # (the rest are enum names inside error messages)
     assert {'MOD16_HOST_THREADS', 'MOD16_SMALL_PIXELS'} <= shipped and not (shipped & switches), shipped
     assert not any(n.startswith(('MOD16_NO_', 'MOD16_EXPERIMENT', 'MOD16_TRIVIAL', 'MOD16_PRIO', 'MOD16_DYN'))

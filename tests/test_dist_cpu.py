@@ -109,15 +109,38 @@ def test_bench_under_torch_distributed_run():
 
 
 def test_bench_failing_rank_fails_the_parent():
+    """Ranks that die (here: the one-device rehearsal without a device) end the parent non-zero."""
     env = dict(os.environ, OMP_NUM_THREADS='1')
     for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(key, None)
     env['MOD16_BENCH_PLUMBING'] = '0'
+    env['MOD16_BENCH_ONE_DEVICE'] = '1'
     env['CUDA_VISIBLE_DEVICES'] = env['HIP_VISIBLE_DEVICES'] = ''
     proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
                            '--no-cpu-baseline'], env=env, cwd=ROOT, capture_output=True,
                           text=True, timeout=300)
     assert proc.returncode != 0
+    assert 'rank exit codes' in proc.stderr
+
+
+@pytest.mark.parametrize('how', ['parent', 'rank'])
+def test_bench_with_fewer_devices_than_ranks_says_so(how):
+    """`bench.py --gpus N` on a node that shows fewer than N GPUs (this container shows none): one
+    clear line and a non-zero exit -- from the parent before it starts a rank, and from a rank
+    started by torch.distributed.run (the driver's launch line) before it touches a device. Fresh
+    child processes only; nothing here initialises a GPU."""
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MOD16_BENCH_PLUMBING', 'MOD16_BENCH_ONE_DEVICE'):
+        env.pop(key, None)
+    env['CUDA_VISIBLE_DEVICES'] = env['HIP_VISIBLE_DEVICES'] = ''
+    if how == 'rank':
+        env.update(RANK='1', LOCAL_RANK='1', WORLD_SIZE='4', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()))
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--no-cpu-baseline'],
+                          env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 2, (proc.returncode, proc.stderr[-1000:])
+    said = [l for l in proc.stderr.splitlines() if l.startswith('bench.py:')]
+    assert len(said) == 1 and '--gpus 4 needs 4 visible GPUs, this node shows 0' in said[0], proc.stderr[-1000:]
+    assert not [l for l in proc.stdout.splitlines() if l.startswith('{')]
 
 
 def test_bench_sensors_are_optional():

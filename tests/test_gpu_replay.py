@@ -99,3 +99,46 @@ def test_a_launch_that_found_its_ticket_in_use_is_reported(env, trusted, monkeyp
     assert torch.equal(torch.nan_to_num(ras.flat(ras.day), nan=-7.0), torch.nan_to_num(day_ref, nan=-7.0))
     # (the numpy path -- HOST mode -- stages tiles of 2^21 pixels, which are dealt out statically:
     # it never reads a ticket counter)
+
+
+@pytest.mark.parametrize('byte', [0x3f, 0xff])
+def test_no_ticket_value_sends_the_kernel_outside_its_raster(env, byte, monkeypatch):
+    """Round 5's first fault injection wrote 0x3f3f... into the ticket: (nwaves + ticket) << run_shift
+    overflowed into a negative base, the loop guard held, and the kernel read and STORED through a
+    wild piece index (a GPU memory fault). The kernel now compares the ticket unsigned with the
+    raster's pieces before it forms a base: whatever 64 bits sit in the counter, the launch ends,
+    writes nothing outside its raster and is reported as incomplete. (0xff...: -1.)"""
+    torch, RasterEngine, table = env
+    from mod16_amd import _lib
+    monkeypatch.setenv('MOD16_POISON_TICKET', '2')
+    monkeypatch.setenv('MOD16_POISON_BYTE', str(byte))
+    eng = RasterEngine(table, experiments=True)
+    monkeypatch.delenv('MOD16_POISON_TICKET')
+    monkeypatch.delenv('MOD16_POISON_BYTE')
+    # the raster between two guard bands of the same allocation class: a wild store of the kind
+    # round 5 saw would most likely land in a neighbour of the raster's slab
+    before = torch.full((1 << 22,), 7.25, dtype=torch.float64, device='cuda')
+    ras = eng.synth_tiled(eng.alloc_tiled(N), seed=43)
+    after = torch.full((1 << 22,), 7.25, dtype=torch.float64, device='cuda')
+    diag = torch.zeros(8, dtype=torch.float64, device='cuda')
+    ref = torch.zeros(8, dtype=torch.float64, device='cuda')
+    eng.run_tiled(ras, diag=ref)
+    eng.check()
+    day_ref = ras.flat(ras.day)
+    ras.day.zero_()
+    eng.run_tiled(ras, diag=diag)                        # the poisoned one
+    torch.cuda.synchronize()                             # it ENDS
+    if byte == 0xff:
+        # -1: the wave that draws it stops claiming, the counter continues at 0 and the others take
+        # every run -- a complete launch
+        eng.check()
+        assert torch.equal(diag, ref)
+    else:
+        with pytest.raises(_lib.Mod16Error, match='only part of its raster'):
+            eng.check()
+        assert (ras.flat(ras.day) == 0).sum() > N // 2
+    assert bool((before == 7.25).all()) and bool((after == 7.25).all())
+    eng.run_tiled(ras, diag=diag)                        # the counter is at zero again: whole
+    eng.check()
+    assert torch.equal(diag, ref)
+    assert torch.equal(torch.nan_to_num(ras.flat(ras.day), nan=-7.0), torch.nan_to_num(day_ref, nan=-7.0))

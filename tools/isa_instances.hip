@@ -12,6 +12,7 @@ template __global__ void et_stream_kernel<double, kStreamRawTotalHours, true, tr
 #ifdef ISA_F32
 template __global__ void et_stream_kernel<float, kStreamTotals, true, true>(const StreamArgs<float>);
 template __global__ void et_stream_kernel<float, kStreamTotalsMixed, true, true>(const StreamArgs<float>);
+template __global__ void et_stream_kernel<float, kStreamTotalsMixed, true, false>(const StreamArgs<float>);
 template __global__ void et_stream_kernel<float, kStreamRawMixed, true, true>(const StreamArgs<float>);
 template __global__ void et_stream_kernel<float, kStreamRawTotalHoursMixed, true, true>(const StreamArgs<float>);
 template __global__ void et_stream_kernel<float, kStreamRawTotalHours, true, true>(const StreamArgs<float>);
