@@ -572,6 +572,12 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
 #ifndef MOD16_NO_REDO_LAUNCH
     if constexpr (GUARD) if (!g.static_sched) {
         const int64_t groups = (nruns + 63) / 64;
+        // mixed-precision forms: first the runs' cancellation lists (mod16_mixed.hpp, period_mixed)
+        if constexpr (stream_is_mixed(MODE)) {
+            const int cgrid = (int)std::max<int64_t>(1, std::min<int64_t>((groups + kBlock / 64 - 1) / (kBlock / 64),
+                                                                          (int64_t)ctx->cus * 8));
+            hipLaunchKernelGGL((et_stream_cancel_kernel<T, MODE>), dim3(cgrid), dim3(kBlock), 0, st, s);
+        }
         const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>((groups + kBlock / 64 - 1) / (kBlock / 64),
                                                                       (int64_t)ctx->cus * 4));
         hipLaunchKernelGGL((et_stream_redo_kernel<T, MODE>), dim3(rgrid), dim3(kBlock), 0, st, s);

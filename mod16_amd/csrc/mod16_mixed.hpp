@@ -102,7 +102,8 @@ __device__ __forceinline__ void humid64(double t, double vpd, const double* tb, 
     double tc = t - K<double>::t0;
     // exp to 4e-11 (cubic on the table's |r| <= ln2/128): the float32 results below keep 6e-8.
     // (A NaN temperature stays NaN through exp_tab3; an infinite one through the reciprocal.)
-    double esat = (1e3 * 0.6108) * M::exp_tab3s((17.27 * tc) * M::rcp(tc + 237.3), tb);
+    // 17.27 tc / (tc + 237.3) = 17.27 - 17.27 * 237.3 / (tc + 237.3): one fma behind the reciprocal
+    double esat = (1e3 * 0.6108) * M::exp_tab3s(__builtin_fma(M::rcp(tc + 237.3), -(17.27 * 237.3), 17.27), tb);
     humid64_tail(esat, vpd, esat_f, rh_f, fwet_f, omw_f, dry, open_w);
 }
 // Raw drivers (round 5): MOD16.vpd (mod16/__init__.py:604-644; the night value clamped at 0,

@@ -661,27 +661,26 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                         // value. Static schedule (small rasters): the piece is flagged like one with a pixel
                         // outside the domain and the wave revisits it behind its loop (redo_piece).
                         if (__builtin_expect(__any(cancel2[0] | cancel2[1]), 0)) {
-                            bool mark[2] = {cancel2[0], cancel2[1]};
-                            if (a.static_sched) {
-                                bad |= cancel2[0] | cancel2[1];
+                            const unsigned long long b0 = __ballot(cancel2[0]), b1 = __ballot(cancel2[1]);
+                            const unsigned more = (unsigned)__builtin_popcountll(b0) + (unsigned)__builtin_popcountll(b1);
+                            if (a.static_sched | (cancel_cnt + more > (unsigned)kCancelCap)) {
+                                bad |= cancel2[0] | cancel2[1];      // (a full list: the piece is flagged instead)
                             } else {
-#pragma unroll
-                                for (int e = 0; e < 2; ++e) {
-                                    const unsigned long long b = __ballot(cancel2[e]);
-                                    const unsigned slot = cancel_cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
-                                    mark[e] = cancel2[e] & (slot < (unsigned)kCancelCap);
-                                    if (mark[e]) {
-                                        // (the list's address: read from the kernel arguments here, in the cold
-                                        // branch, rather than held in a scalar pair all through the loop)
-                                        kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-                                        asm volatile("" : "+s"(ka));
-                                        uint16_t* list = *reinterpret_cast<uint16_t* const __attribute__((address_space(4)))*>(
-                                            ka + __builtin_offsetof(StreamArgs<T>, cancel_list));
-                                        list[(cbase >> rs) * kCancelCap + slot] = (uint16_t)((run << 8) | (lane << 2) | (jj + e));
-                                    }
-                                    cancel_cnt += (unsigned)__builtin_popcountll(b);
-                                }
+                                // (the list's address: read from the kernel arguments here, in the cold
+                                // branch, rather than held in a scalar pair all through the loop)
+                                kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+                                asm volatile("" : "+s"(ka));
+                                uint16_t* list = *reinterpret_cast<uint16_t* const __attribute__((address_space(4)))*>(
+                                                     ka + __builtin_offsetof(StreamArgs<T>, cancel_list)) +
+                                                 ((cbase >> rs) * kCancelCap + cancel_cnt);
+                                const unsigned r0 = __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0u));
+                                const unsigned r1 = __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0u));
+                                const unsigned ent = (unsigned)((run << 8) | (lane << 2) | jj);
+                                if (cancel2[0]) list[r0] = (uint16_t)ent;
+                                if (cancel2[1]) list[(unsigned)__builtin_popcountll(b0) + r1] = (uint16_t)(ent + 1u);
+                                cancel_cnt += more;
                             }
+                            const bool mark[2] = {cancel2[0], cancel2[1]};
                             const f2 poison = splat(__uint_as_float(kCancelPoison));
                             day2 = sel(mark[0], mark[1], poison, day2);
                             night2 = sel(mark[0], mark[1], poison, night2);
@@ -1003,33 +1002,99 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
 #endif
 }
 
-// What a large raster (dynamic schedule) left for behind the pipeline kernel: a wave takes 64 runs at
-// a time (lane l reads the flag field of run r0 + l).
-//   - Mixed-precision forms: the runs' cancellation lists (see the loop). The pixels of all 64 runs
-//     are computed side by side in the lanes of the wave -- entry e of the concatenated lists by lane
-//     e % 64: one gather and one pass through the float64 pixel function per 64 pixels, where going
-//     run by run cost a pass per run (nine runs in ten hold one or two such pixels: measured 4.6 ms on
-//     the global grid, per flagged piece) -- and every run's owner lane then adds ITS pixels' totals
-//     to its partial in list order: the sums do not depend on which lane computed what.
-//   - Every run with a piece flag: its flagged pieces revisited (pixels outside the domain of the
-//     production arithmetic, redo_piece), the run's partial corrected -- the wave is the only one
-//     touching that run here, and the fixed-order sum over the partials runs behind this kernel.
-// A raster without any of it costs this kernel one 8-byte load per run (global grid: 3.5 MB).
+// The runs' cancellation lists of a mixed-precision launch (dynamic schedule; see the loop), behind
+// the pipeline kernel: a wave takes 64 runs at a time (lane l reads the flag field of run r0 + l), and
+// the pixels of all 64 lists are computed side by side in the lanes of the wave -- entry e of the
+// concatenated lists by lane e % 64: one gather and one pass through the float64 pixel function per 64
+// pixels (going piece by piece, as the domain guard's pass does, cost 4.6 ms on the global grid: nine
+// runs in ten hold such a pixel) -- and every run's owner lane then adds ITS pixels' totals to its
+// partial in list order: the sums do not depend on which lane computed what. Bound by the gather:
+// every listed pixel costs fifteen 64-byte sectors of HBM traffic where the pipeline read 65 bytes
+// (global grid, one pixel in 250 listed: 0.36 ms next to the pipeline's 10.6).
 template <typename T, int MODE>
-__global__ void __launch_bounds__(kBlock) et_stream_redo_kernel(const StreamArgs<T> a) {
+__global__ void __launch_bounds__(kBlock) et_stream_cancel_kernel(const StreamArgs<T> a) {
     constexpr int V = 16 / (int)sizeof(T);
-    ignore_signalling_nans();       // the guard is asked again: the same answer as in the pipeline kernel
     __shared__ double lut[MOD16_LUT_ROWS * kLutCols];
-    // cancellation lists: who[wave][e] = (owner lane << 8 | entry of its list) of entry e of the 64 runs'
-    // concatenated lists; vals[wave][lane] = the totals lane `lane` computed in this batch
-    __shared__ uint16_t who[stream_is_mixed(MODE) ? kBlock / 64 : 1][stream_is_mixed(MODE) ? 64 * kCancelCap : 1];
-    __shared__ double vals[stream_is_mixed(MODE) ? kBlock / 64 : 1][stream_is_mixed(MODE) ? 64 : 1][2];
+    // who[wave][e] = (owner lane << 8 | entry of its list) of entry e of the 64 runs' concatenated
+    // lists; vals[wave][lane] = the totals lane `lane` computed in this batch
+    __shared__ uint16_t who[kBlock / 64][64 * kCancelCap];
+    __shared__ double vals[kBlock / 64][64][2];
     for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) lut[i] = a.lut64[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
     const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + wv;
+    const int rs = a.run_shift;
+    for (int64_t r0 = wave * 64; r0 < a.nruns; r0 += nwaves * 64) {
+        const int64_t mine = r0 + lane;
+        const double fl = mine < a.nruns ? a.diag_partial[mine * kDiag + kFlagField] : 0.0;
+        const int cnt = (int)((unsigned long long)fl >> kCancelShift);          // (<= kCancelCap)
+        if (!__any(cnt != 0)) continue;
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            incl += lane >= off ? up : 0;
+        }
+        const int excl = incl - cnt, total = __shfl(incl, 63, 64);
+        for (int k = 0; k < cnt; ++k) who[wv][excl + k] = (uint16_t)((lane << 8) | k);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (one wave: its LDS accesses are in order)
+        double sum_d = 0.0, sum_n = 0.0, max_d = -__builtin_huge_val(), max_n = -__builtin_huge_val();
+        unsigned num_d = 0, num_n = 0;
+        for (int base = 0; base < total; base += 64) {
+            const int e = base + lane;
+            double d = __builtin_nan(""), g = __builtin_nan("");
+            if (e < total) {
+                const unsigned w = who[wv][e];
+                const int64_t run = r0 + (w >> 8);
+                const unsigned ent = a.cancel_list[run * kCancelCap + (w & 255u)];
+                const int64_t piece = (run << rs) + (ent >> 8);
+                const int64_t tile = piece >> a.tile_shift;
+                const int64_t q = (piece - (tile << a.tile_shift)) * (int64_t)(64 * V) + (int64_t)((ent >> 2) & 63u) * V + (ent & 3u);
+                redo_pixel<T, MODE, true>(a, lut, a.tab, tile * a.wide_row + q, tile * a.out_row + q, tile * a.byte_row + q, false, d, g);
+            }
+            vals[wv][lane][0] = d;
+            vals[wv][lane][1] = g;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // the owner adds its run's pixels of this batch, in list order
+            const int lo = excl > base ? excl : base, hi = incl < base + 64 ? incl : base + 64;
+            for (int i = lo; i < hi; ++i) {
+                const double vd = vals[wv][i - base][0], vg = vals[wv][i - base][1];
+                if (vd == vd) { sum_d += vd; num_d += 1u; max_d = vd > max_d ? vd : max_d; }
+                if (vg == vg) { sum_n += vg; num_n += 1u; max_n = vg > max_n ? vg : max_n; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (before the next batch overwrites vals)
+        }
+        if (cnt != 0) {
+            double* part = a.diag_partial + mine * kDiag;
+            part[0] += sum_d;
+            part[1] += sum_n;
+            part[4] -= (double)num_d;
+            part[5] -= (double)num_n;
+            part[6] = max_d > part[6] ? max_d : part[6];
+            part[7] = max_n > part[7] ? max_n : part[7];
+        }
+    }
+}
+
+// The flagged pieces of a large raster (dynamic schedule), behind the pipeline kernel (and, mixed-
+// precision forms, behind et_stream_cancel_kernel): a wave takes 64 runs at a time (lane l reads the
+// flag field of run r0 + l), and for every run with a piece flag revisits its flagged pieces -- pixels
+// outside the domain of the production arithmetic; mixed-precision forms: also the marked pixels of a
+// run whose list was full (redo_piece) -- and corrects the run's partial: it is the only one touching
+// that run here, and the fixed-order sum over the partials runs behind this kernel. A raster
+// without flagged pixels costs this kernel one 8-byte load per run (global grid: 3.5 MB).
+template <typename T, int MODE>
+__global__ void __launch_bounds__(kBlock) et_stream_redo_kernel(const StreamArgs<T> a) {
+    constexpr int V = 16 / (int)sizeof(T);
+    ignore_signalling_nans();       // the guard is asked again: the same answer as in the pipeline kernel
+    __shared__ double lut[MOD16_LUT_ROWS * kLutCols];
+    for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) lut[i] = a.lut64[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const int64_t npiece = (a.n / V + 63) / 64;
     const int rs = a.run_shift;
     // every run's partial must carry the marker of the launch in front of this kernel (which has
@@ -1041,58 +1106,8 @@ __global__ void __launch_bounds__(kBlock) et_stream_redo_kernel(const StreamArgs
         const double fl = mine < a.nruns ? a.diag_partial[mine * kDiag + kFlagField] : 0.0;
         const double mk = mine < a.nruns ? a.diag_partial[mine * kDiag + kSerialField] : marker;
         if (__any(mk != marker) && lane == 0) atomicOr(a.status, kStatusIncomplete);
-        const unsigned long long flbits = (unsigned long long)fl;
-        if constexpr (stream_is_mixed(MODE)) {
-            const int cnt = (int)(flbits >> kCancelShift);          // (<= kCancelCap)
-            if (__any(cnt != 0)) {
-                int incl = cnt;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int up = __shfl_up(incl, off, 64);
-                    incl += lane >= off ? up : 0;
-                }
-                const int excl = incl - cnt, total = __shfl(incl, 63, 64);
-                for (int k = 0; k < cnt; ++k) who[wv][excl + k] = (uint16_t)((lane << 8) | k);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (one wave: its LDS accesses are in order)
-                double sum_d = 0.0, sum_n = 0.0, max_d = -__builtin_huge_val(), max_n = -__builtin_huge_val();
-                unsigned num_d = 0, num_n = 0;
-                for (int base = 0; base < total; base += 64) {
-                    const int e = base + lane;
-                    double d = __builtin_nan(""), g = __builtin_nan("");
-                    if (e < total) {
-                        const unsigned w = who[wv][e];
-                        const int64_t run = r0 + (w >> 8);
-                        const unsigned ent = a.cancel_list[run * kCancelCap + (w & 255u)];
-                        const int64_t piece = (run << rs) + (ent >> 8);
-                        const int64_t tile = piece >> a.tile_shift;
-                        const int64_t q = (piece - (tile << a.tile_shift)) * (int64_t)(64 * V) + (int64_t)((ent >> 2) & 63u) * V + (ent & 3u);
-                        redo_pixel<T, MODE, true>(a, lut, a.tab, tile * a.wide_row + q, tile * a.out_row + q, tile * a.byte_row + q, false, d, g);
-                    }
-                    vals[wv][lane][0] = d;
-                    vals[wv][lane][1] = g;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    // the owner adds its run's pixels of this batch, in list order
-                    const int lo = excl > base ? excl : base, hi = incl < base + 64 ? incl : base + 64;
-                    for (int i = lo; i < hi; ++i) {
-                        const double vd = vals[wv][i - base][0], vg = vals[wv][i - base][1];
-                        if (vd == vd) { sum_d += vd; num_d += 1u; max_d = vd > max_d ? vd : max_d; }
-                        if (vg == vg) { sum_n += vg; num_n += 1u; max_n = vg > max_n ? vg : max_n; }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (before the next batch overwrites vals)
-                }
-                if (cnt != 0) {
-                    double* part = a.diag_partial + mine * kDiag;
-                    part[0] += sum_d;
-                    part[1] += sum_n;
-                    part[4] -= (double)num_d;
-                    part[5] -= (double)num_n;
-                    part[6] = max_d > part[6] ? max_d : part[6];
-                    part[7] = max_n > part[7] ? max_n : part[7];
-                }
-                __threadfence();         // the piece flags' pass below reads partials through other lanes
-            }
-        }
-        unsigned long long any = __ballot((flbits & ((1ull << kCancelShift) - 1ull)) != 0ull);
+        const unsigned long long flbits = (unsigned long long)fl & ((1ull << kCancelShift) - 1ull);
+        unsigned long long any = __ballot(flbits != 0ull);
         while (any) {
             const int src = __builtin_ctzll(any);
             any &= any - 1ull;
@@ -1103,7 +1118,8 @@ __global__ void __launch_bounds__(kBlock) et_stream_redo_kernel(const StreamArgs
             for (int i = 0; i < (1 << rs); ++i) {
                 const int bit = i < kCancelShift - 1 ? i : kCancelShift - 1;
                 const int64_t piece = (run << rs) + i;
-                if (((flags >> bit) & 1ull) && piece < npiece) redo_piece<T, MODE>(a, lut, a.tab, piece, lane, false, acc);
+                if (((flags >> bit) & 1ull) && piece < npiece)
+                    redo_piece<T, MODE>(a, lut, a.tab, piece, lane, stream_is_mixed(MODE), acc);
             }
             double* part = a.diag_partial + run * kDiag;
             const double f = lane < kDiag ? part[lane] : 0.0;

@@ -247,6 +247,10 @@ static void run_shadow(const std::string& name, dim3 grid, dim3 block, void** ar
             need(a.diag_partial, sizeof(double) * kDiag * (size_t)a.nruns, 8, "diagnostics partials", n);
             need(a.cancel_list, sizeof(uint16_t) * kCancelCap * (size_t)a.nruns, 2, "cancellation lists", n);
         }
+    } else if (has(name, "23et_stream_cancel_kernelI")) {
+        const auto& a = *static_cast<const StreamArgs<float>*>(args[0]);      // (float32 rasters only)
+        need(a.diag_partial, sizeof(double) * kDiag * (size_t)a.nruns, 8, "diagnostics partials", n);
+        need(a.cancel_list, sizeof(uint16_t) * kCancelCap * (size_t)a.nruns, 2, "cancellation lists", n);
     } else if (has(name, "9et_kernelI")) {
         const size_t at = name.find("9et_kernelI") + 11;
         if (name[at] == 'd') shadow_et(*static_cast<const EtArgs<double>*>(args[0]), grid, block, n);
