@@ -32,6 +32,7 @@ __version__ = 'v1.2.0+mi355x.r1'
 import ctypes as _ctypes
 
 import numpy as np
+import threading as _threading
 
 from . import _lib
 
@@ -299,8 +300,11 @@ def _forward(cls, drivers, params, separate, flags, device, pet=False, out=None,
         # tile of the undivided call
         cuts = multi.shards(n, len(devs), inner if two_level else tile)
         multi.run(devs, lambda i, ctx: part(ctx, *cuts[i]))
-    if not shape:      # all-scalar input: numpy scalars, as the reference
-        outs = [o[()] for o in outs]
+    if not shape:
+        # all-scalar input, as the reference returns it: the totals (sums, :792) and the soil component
+        # (e / lhv, :864) are numpy scalars, the canopy and transpiration components -- np.where
+        # results, :961 and :1258 -- stay 0-d arrays
+        outs = [o if separate and k % 3 != 1 else o[()] for k, o in enumerate(outs)]
     if pet:
         return tuple(outs)
     if separate:
@@ -316,21 +320,68 @@ def _is_device_tensor(v):
 
 
 _SPREAD_SCALARS_FROM = 1 << 20
-_ONES = {}      # device index -> the class raster of ones of the last shape (uint8, n bytes)
+# What the device-tensor path keeps between calls. Launches there are ASYNCHRONOUS on the caller's
+# stream, so nothing a launch reads may change or be freed under it:
+#  - per GPU one class raster of ones (uint8, one byte per pixel of the largest raster seen), shared
+#    by the threads of the process and only ever read; it is replaced -- under the lock, behind a
+#    wait for the device -- when a larger raster arrives;
+#  - per thread, GPU and PARAMETER SET one library context whose parameter table is written once,
+#    when the context is made, and never again: the numpy entry points (which set the table of the
+#    thread's own context, _lib.context, with a blocking copy) never touch a table an asynchronous
+#    launch reads, and a loop over plant functional types -- the reference's usual pattern -- pays
+#    no synchronisation and no copy per call. At most _TENSOR_CONTEXTS per thread; the least
+#    recently used one is closed behind a wait for its device.
+_ONES = {}
+_ONES_LOCK = _threading.Lock()
+_TENSOR_CONTEXTS = 16
+_tensor_local = _threading.local()
 
 
 def release_device_cache():
-    '''Frees what the device-tensor path keeps between calls (per GPU one class raster of ones,
-    one byte per pixel of the largest raster seen).'''
-    _ONES.clear()
+    '''Frees what the device-tensor path keeps between calls: the class rasters of ones (all
+    threads) and the calling thread's per-parameter-set contexts. Waits for the devices first.'''
+    import torch
+    with _ONES_LOCK:
+        for index in list(_ONES):
+            torch.cuda.synchronize(index)
+        _ONES.clear()
+    table = getattr(_tensor_local, 'contexts', None)
+    if table:
+        for (index, _), ctx in list(table.items()):
+            torch.cuda.synchronize(index)
+            ctx.close()
+        table.clear()
 
 
 def _class_of_ones(torch, dev, index, n):
-    t = _ONES.get(index)
-    if t is None or t.numel() < n:
-        t = _ONES[index] = torch.ones(n, dtype=torch.uint8, device=dev)
-        torch.cuda.current_stream(dev).synchronize()     # filled before any other stream reads it
-    return t
+    with _ONES_LOCK:
+        t = _ONES.get(index)
+        if t is None or t.numel() < n:
+            if t is not None:
+                torch.cuda.synchronize(dev)      # launches in flight (any stream) still read the old one
+            t = _ONES[index] = torch.ones(n, dtype=torch.uint8, device=dev)
+            torch.cuda.current_stream(dev).synchronize()     # filled before any other stream reads it
+        return t
+
+
+def _tensor_context(torch, dev, index, table):
+    '''The calling thread's context on GPU ``index`` whose parameter table is ``table``.'''
+    import collections
+    cache = getattr(_tensor_local, 'contexts', None)
+    if cache is None:
+        cache = _tensor_local.contexts = collections.OrderedDict()
+    key = (index, table.tobytes())
+    ctx = cache.get(key)
+    if ctx is not None:
+        cache.move_to_end(key)
+        return ctx
+    while len(cache) >= _TENSOR_CONTEXTS:
+        (old_index, _), old = cache.popitem(last=False)
+        torch.cuda.synchronize(old_index)            # its launches may still read its table
+        old.close()
+    ctx = cache[key] = _lib.Context(index)
+    ctx.set_bplut(table)                             # once: nothing has been launched on it yet
+    return ctx
 
 
 def _forward_device(drivers, params, separate, flags, pet=False):
@@ -405,9 +456,8 @@ def _forward_device(drivers, params, separate, flags, pet=False):
                 table = np.full((_lib.N_CLASSES, _lib.N_PARAMS), np.nan)
                 # (float32 rasters take their scalar parameters as float32, as the numpy call does)
                 table[1] = np.asarray(host_scalars[14:], np_dtype)
-                if table.tobytes() != ctx._bplut_key:
-                    torch.cuda.synchronize(dev)      # (a launch in flight may still be reading the table it was given)
-                    ctx.set_bplut(table)
+                # a context of its own per parameter set: its table never changes under a launch
+                ctx = _tensor_context(torch, dev, index, table)
                 cptr = _class_of_ones(torch, dev, index, n).data_ptr()
                 pptr = pstr = None
             if pet:

@@ -9,6 +9,8 @@ reduced in rank order by every rank. Outputs
 stay sharded.
 '''
 
+import threading
+
 GLOBAL_ROWS = 21600
 GLOBAL_COLS = 43200
 
@@ -30,7 +32,7 @@ def pixel_range(rows, cols, rank, world):
     return r0 * cols, (r1 - r0) * cols
 
 
-_GATHER = {}
+_GATHER = threading.local()       # per thread: (device, world) -> the gather buffer
 
 
 def allreduce_diag(diag, group=None, engine=None):
@@ -54,9 +56,12 @@ def allreduce_diag(diag, group=None, engine=None):
         return diag
     world = dist.get_world_size(group)
     key = (diag.device, world)
-    buf = _GATHER.get(key)
+    table = getattr(_GATHER, 'buffers', None)
+    if table is None:
+        table = _GATHER.buffers = {}
+    buf = table.get(key)
     if buf is None:
-        buf = _GATHER[key] = torch.empty(world * 8, dtype=torch.float64, device=diag.device)
+        buf = table[key] = torch.empty(world * 8, dtype=torch.float64, device=diag.device)
     dist.all_gather_into_tensor(buf, diag, group=group)
     if engine is not None and diag.is_cuda:
         return engine.fold_ranks(buf, world, diag)

@@ -813,3 +813,63 @@ def test_device_tensors_through_the_class(m16, golden, dtype):
     mixed[0] = host[0]
     with pytest.raises(TypeError):
         m.evapotranspiration(*mixed)
+
+
+def test_scalar_calls_return_what_the_reference_returns(m16, golden):
+    """All-scalar input (the reference's tests call it that way, tests/tests.py:64-121): the
+    totals (:792) and the soil component (e / lhv, :864) are numpy scalars, the wet-canopy and
+    transpiration components -- np.where results, :961 and :1258 -- are 0-d arrays, as the
+    sub-methods themselves return them."""
+    f = golden('f1_tests_scalars')
+    m = model(m16, [float(p) for p in f['params']], 'fast')
+    drivers = [float(x) for x in f['drivers']]
+    day, night = m.evapotranspiration(*drivers)
+    assert isinstance(day, np.float64) and isinstance(night, np.float64)
+    for period in m.evapotranspiration(*drivers, separate=True):
+        canopy, soil, trans = period
+        assert isinstance(canopy, np.ndarray) and canopy.shape == () and canopy.dtype == np.float64
+        assert isinstance(trans, np.ndarray) and trans.shape == ()
+        assert isinstance(soil, np.float64)
+        assert float((canopy + soil) + trans) in (float(day), float(night))
+
+
+def test_a_loop_over_parameter_sets_on_device_tensors(m16, golden):
+    """The reference's usual pattern on device tensors -- one MOD16 per plant functional type,
+    called in a loop -- with every call ASYNCHRONOUS on a side stream and the numpy entry point (which
+    sets the table of the thread's own context with a blocking copy) called in between: every
+    parameter set has a context of its own whose table is written once (a table
+    changing under a launch in flight gave silently wrong parameters), so each result is the
+    numpy call's, bit for bit, and the second pass over the sets makes no new context."""
+    import torch
+    import mod16_amd
+    from mod16_amd.utils import restore_bplut
+    from mod16_amd.models import COLLECTION61_BPLUT
+    f = golden('f1_tests_scalars')
+    bplut = restore_bplut(COLLECTION61_BPLUT)
+    rng = np.random.default_rng(9)
+    shape = (1100, 1000)                    # > 2^20 pixels: the pipeline behind a class raster of ones
+    host = [np.asarray(float(x) * (1 + 0.02 * rng.uniform(-1, 1, shape))) for x in f['drivers']]
+    dev = [torch.from_numpy(a).cuda() for a in host]
+    pfts = [1, 4, 7, 10, 12]
+    models = [m16.MOD16(dict({k: float(bplut[k][c]) for k in oracle.PARAM_NAMES if k != 'beta'}, beta=250.0))
+              for c in pfts]
+    want = [mm.evapotranspiration(*host) for mm in models]
+    mod16_amd.release_device_cache()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    got = []
+    for rounds in range(2):
+        for mm in models:
+            with torch.cuda.stream(side):
+                got.append(mm.evapotranspiration(*dev))
+            # the numpy path of this thread, with another table, while the launch may still run
+            mm.evapotranspiration(*[a[:7, :9] for a in host])
+        if rounds == 0:
+            made = len(mod16_amd._tensor_local.contexts)
+    assert made == len(pfts) == len(mod16_amd._tensor_local.contexts)
+    side.synchronize()
+    for k, res in enumerate(got):
+        for g, w in zip(res, want[k % len(pfts)]):
+            assert same_bits(g.cpu().numpy(), w), k
+    mod16_amd.release_device_cache()
+    assert not mod16_amd._tensor_local.contexts
