@@ -229,6 +229,10 @@ def cpu_baseline(max_workers):
     out['fused_numpy'] = {'value': tile_px / best2, 'unit': 'pixels/s', 'cores': 1, 'seconds_per_tile': best2,
                           'sample': '3 runs of a 1200x1200 float64 tile (best), shared per-period terms, '
                                     'conductance forms, one division per component'}
+    # the same as flat scalars (the driver's record keeps scalars of this object)
+    out['pool_px_s'] = _dig(out, 'pool', 'value')
+    out['pool_cores'] = _dig(out, 'pool', 'cores')
+    out['fused_px_s'] = out['fused_numpy']['value']
     out['global_grid_seconds_1core'] = 43200 * 21600 / out['value']
     try:
         with open('/proc/cpuinfo') as f:
@@ -891,6 +895,17 @@ def build_summary(line):
         'full_grid_max_rel': full.get('max_rel_err'), 'full_grid_masks_equal': full.get('nan_masks_equal'),
         'full_grid_n_gt_1e-5': full.get('n_rel_err_gt_1e-5'),
         'cpu_px_s_1core': _dig(line, 'cpu_baseline', 'value'),
+        'cpu_pool_px_s': _dig(line, 'cpu_baseline', 'pool', 'value'), 'cpu_pool_cores': _dig(line, 'cpu_baseline', 'pool', 'cores'),
+        'cpu_fused_px_s': _dig(line, 'cpu_baseline', 'fused_numpy', 'value'),
+        'store_gpx_s': _dig(cfg, 'store_on_disk', 'pixels_per_s') / 1e9 if _dig(cfg, 'store_on_disk', 'pixels_per_s') else None,
+        'class_device_f64_frac': _dig(cfg, 'class_surface_device', 'one_pft_float64', 'frac'),
+        'class_device_f32_frac': _dig(cfg, 'class_surface_device', 'one_pft_float32', 'frac'),
+        'class_gather_f64_frac': _dig(cfg, 'class_surface_device', 'pft_gather_float64', 'frac'),
+        'class_gather_f32_frac': _dig(cfg, 'class_surface_device', 'pft_gather_float32', 'frac'),
+        'c5_trusted_frac': c5.get('mixed_trusted_frac'),
+        'c5_n_gt_1e-4': _dig(c5, 'mixed_vs_float64_arithmetic_full_grid', 'n_rel_err_gt_1e-4'),
+        'c5_n_gt_1e-3': _dig(c5, 'mixed_vs_float64_arithmetic_full_grid', 'n_rel_err_gt_1e-3'),
+        'c5_max_rel_err': _dig(c5, 'mixed_vs_float64_arithmetic_full_grid', 'max_rel_err'),
         'build_id': roof.get('library_build_id'),
     }
     return out
@@ -1137,7 +1152,9 @@ def other_configs(args, torch, np, _lib, RasterEngine, table, bplut):
     r = e_mixed.synth_tiled(e_mixed.alloc_tiled(n), seed=SEED)
     ref = e_fast.alloc_tiled(n)
     ref.slab.copy_(r.slab)
-    for name, e, ras in (('mixed', e_mixed, r), ('fast_float64_arithmetic', e_fast, ref)):
+    e_trusted = RasterEngine(table, dtype='float32', math=_lib.MATH_MIXED, trusted=True)
+    # (the guarded form runs LAST on its raster: its values are the ones compared below)
+    for name, e, ras in (('mixed_trusted', e_trusted, r), ('mixed', e_mixed, r), ('fast_float64_arithmetic', e_fast, ref)):
         step = e.bind_tiled(ras, diag)
         step()
         ms = min(step.time(10) for _ in range(2))
@@ -1159,7 +1176,7 @@ def other_configs(args, torch, np, _lib, RasterEngine, table, bplut):
                   'the float64 arithmetic and bounds the ABSOLUTE error; relative error exceeds 1e-5 on the '
                   'counted share of (small) values')
     out['c5_global_grid_float32'] = c5
-    del r, ref, e_mixed, e_fast, e, ras, got, want, res      # (loop variables hold the rasters too)
+    del r, ref, e_mixed, e_fast, e_trusted, e, ras, got, want, res      # (loop variables hold the rasters too)
     import gc
     gc.collect()                 # bound steps and their launch closures are reference cycles
     torch.cuda.empty_cache()
@@ -1170,7 +1187,88 @@ def other_configs(args, torch, np, _lib, RasterEngine, table, bplut):
     out['forms_float64'] = forms_config(torch, np, _lib, RasterEngine, table, bplut, 'float64', _lib.MATH_FAST, 10800)
     out['forms_float32_mixed'] = forms_config(torch, np, _lib, RasterEngine, table, bplut, 'float32', _lib.MATH_MIXED, 10800)
     out['n2_calibration'] = n2_config(np, _lib)
+    out['class_surface_device'] = class_surface_config(torch, np, RasterEngine, table)
+    out['store_on_disk'] = store_config(torch, np, table)
     return out
+
+
+def class_surface_config(torch, np, RasterEngine, table, n=10800 * 21600):
+    """The reference's own signature on rasters resident in HBM (tools/classbench.py):
+    MOD16(params).evapotranspiration(*device tensors), HIP events around 10 calls --
+      one_pft      scalar parameters of one plant functional type: the production pipeline behind a class
+                   raster of ones, on separately allocated tensors;
+      pft_gather   the reference's multi-class idiom (notebook cell 32): MOD16({k: bplut[k][pft_map]}) with
+                   eleven per-pixel parameter TENSORS -- recognised as a gather of the table's rows and run
+                   through the same pipeline with a class raster built on the device (round 6)."""
+    import mod16_amd
+    names = mod16_amd.MOD16.required_parameters
+    out = {'pixels': n}
+    for dtype in ('float64', 'float32'):
+        eng = RasterEngine(table, dtype=dtype)
+        cls, drv = eng.synth(n, seed=SEED)
+        bpp = 129 if dtype == 'float64' else 65
+        models = {'one_pft': mod16_amd.MOD16(dict(zip(names, (float(v) for v in table[7]))))}
+        tt = torch.from_numpy(table).cuda().to(drv[0].dtype)
+        models['pft_gather'] = mod16_amd.MOD16({k: tt[:, j][cls.long()] for j, k in enumerate(names)})
+        del tt
+        for name, model in models.items():
+            res = model.evapotranspiration(*drv)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                res = model.evapotranspiration(*drv)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            out['%s_%s' % (name, dtype)] = {'ms': ms, 'GBps': bpp * n / ms / 1e6, 'frac': bpp * n / ms / 1e6 / HBM_PEAK_GBPS,
+                                            'bytes_per_pixel': bpp}
+            del res
+        del models, model, drv, cls, eng
+        mod16_amd.release_device_cache()
+        torch.cuda.empty_cache()
+    return out
+
+
+def store_config(torch, np, table, pixels=43200 * 432, steps=2):
+    """SURVEY.md 8f N4 with a number in the line: a raster time series on disk (/dev/shm when there is
+    one: the page cache either way) run through mod16_amd.io.run_store -- file -> page-locked buffer ->
+    H2D -> fused raw-driver kernel -> D2H -> file, four pipelines of three readers. float32 raw drivers,
+    `steps` x `pixels`; the set-up (fields written once) is not measured."""
+    import shutil
+    import tempfile
+    from mod16_amd import io
+    base = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else tempfile.gettempdir()
+    root = tempfile.mkdtemp(prefix='mod16_bench_store_', dir=base)
+    try:
+        store = io.RasterStore.create(root, steps, pixels, np.dtype(np.float32))
+        g = torch.Generator(device='cuda').manual_seed(SEED)
+        ranges = {0: (-100, 0), 1: (-50, 0), 2: (0, 360), 4: (0.1, 0.22), 5: (255, 305), 6: (250, 300),
+                  8: (245, 298), 9: (0.001, 0.02), 10: (0.001, 0.02), 11: (70000, 101340), 12: (70000, 101340)}
+        rnd = lambda lo, hi: (torch.rand(pixels, generator=g, device='cuda') * (hi - lo) + lo).cpu().numpy()
+        for t in range(steps):
+            for idx, name in io.DYNAMIC_FIELDS:
+                store.array(name, 'r+')[t] = rnd(*ranges[idx])
+            store.array(io.FPAR, 'r+')[t] = torch.randint(0, 101, (pixels,), generator=g, device='cuda', dtype=torch.uint8).cpu().numpy()
+            store.array(io.LAI, 'r+')[t] = torch.randint(0, 71, (pixels,), generator=g, device='cuda', dtype=torch.uint8).cpu().numpy()
+        store.array('MERRA2/T10M_annual', 'r+')[:] = rnd(265, 300)
+        store.array('state/elevation_m', 'r+')[:] = rnd(-50, 3500)
+        store.array(io.PFT, 'r+')[:] = torch.randint(1, 11, (pixels,), generator=g, device='cuda', dtype=torch.uint8).cpu().numpy()
+        del store
+        best = None
+        for _ in range(2):
+            rep = io.run_store(table, root, workers=4, readers=3)
+            if best is None or rep['pixels_per_s'] > best['pixels_per_s']:
+                best = rep
+        keep = {k: best[k] for k in ('pixels_per_s', 'file_GBps', 'wall_s', 'setup_s') if k in best}
+        keep.update(pixels=pixels, steps=steps, dtype='float32', where=base,
+                    note='mod16_amd.io.run_store: 4 pipelines x 3 readers, raw float32 drivers + uint8 fPAR / LAI in, '
+                         'two float32 rasters out; files in the page cache; best of 2 runs')
+        return keep
+    except Exception as exc:                      # (no room in /dev/shm, ...): recorded, never raised
+        return {'error': '%s: %s' % (type(exc).__name__, exc)}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def series_from_host(torch, eng, args):

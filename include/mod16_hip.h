@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MOD16_ABI_VERSION 4
+#define MOD16_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define MOD16_API __attribute__((visibility("default")))
@@ -693,6 +693,27 @@ MOD16_API const char* mod16_build_id(void);
  */
 MOD16_API int mod16_fold_diag(mod16_ctx* ctx, const double* gathered, int world, double* diag,
                               void* stream);
+
+/*
+ * Parameter rasters -> class raster (round 6). The reference's multi-class idiom gathers the BPLUT
+ * per pixel -- MOD16({k: bplut[k][pft_map]}), mod16/utils.py:81-117 and notebook cell 32 -- and hands
+ * evapotranspiration() eleven parameter rasters that hold, pixel for pixel, one of at most 13 rows.
+ * mod16_classify_* turns DEVICE rasters of that kind back into a class raster: params[11] (order of
+ * MOD16.required_parameters) with pstride 1 (a raster of n values) or 0 (one value); `rows` a HOST
+ * array [nrows][11] of candidate rows, 1 <= nrows <= 13; every pixel whose eleven values equal a row
+ * bit for bit (a NaN row matches itself) gets that row's index in cls[n] (device). *unmatched
+ * receives -1 if every pixel matched, else the smallest index of a pixel that matched no row (the
+ * caller adds that pixel's row and calls again, or gives up: the rasters are not a gather of <= 13
+ * rows). Waits for `stream`. What the Python layer does with it: MOD16.evapotranspiration on device
+ * tensors with per-pixel parameter tensors takes the production pipeline (14 drivers + 1 byte per
+ * pixel) instead of the plain kernel (25 arrays).
+ */
+MOD16_API int mod16_classify_f64(mod16_ctx* ctx, const double* const* params, const int64_t* pstride,
+                                 int64_t n, const double* rows, int nrows, uint8_t* cls,
+                                 int64_t* unmatched, void* stream);
+MOD16_API int mod16_classify_f32(mod16_ctx* ctx, const float* const* params, const int64_t* pstride,
+                                 int64_t n, const float* rows, int nrows, uint8_t* cls,
+                                 int64_t* unmatched, void* stream);
 
 #ifdef __cplusplus
 }

@@ -384,7 +384,76 @@ def _tensor_context(torch, dev, index, table):
     return ctx
 
 
-def _forward_device(drivers, params, separate, flags, pet=False):
+_GATHER_SAMPLE = 1 << 16        # pixels looked at for the candidate rows of a gathered parameter set
+
+
+def _gathered_classes(torch, dev, index, values, shape, n, dtype, np_dtype, cache):
+    '''The reference's multi-class idiom on device tensors -- ``MOD16({k: bplut[k][pft_map]})``,
+    notebook cell 32: eleven parameter rasters that hold, pixel for pixel, one of at most 13 rows of
+    a table. Returns ``(table, cls)`` -- the (13, 11) float64 table of the distinct rows and a uint8
+    class raster on the device -- if ``values[14:]`` are such rasters (tensors of the drivers' shape,
+    or single values), else None. The rows come from a strided sample of the rasters (their bit
+    patterns: a NaN row, an invalid class, is a row like any other); ``mod16_classify_*`` then
+    compares EVERY pixel with them, and a pixel that matches none hands in its row for another
+    pass -- a raster with more than 13 distinct rows is not a gather and takes the plain kernel.
+    The answer is kept in ``cache`` (the model instance's) for as long as the parameter tensors are
+    the same objects, unchanged (``Tensor._version``): a model called once per time step looks at its
+    parameters once.'''
+    pars = values[14:]
+    if not any(_is_device_tensor(v) and v.numel() > 1 for v in pars):
+        return None
+    key = tuple((id(v), v.data_ptr(), v._version, tuple(v.shape), str(v.dtype)) if _is_device_tensor(v)
+                else ('scalar', float(np.asarray(v).reshape(()))) for v in pars) + (shape, str(dtype), index)
+    if cache is not None and cache.get('key') == key:
+        return cache.get('answer')
+    answer = None
+    flat = []
+    for v in pars:
+        if _is_device_tensor(v):
+            t = v if v.dtype == dtype else v.to(dtype)
+            if t.numel() > 1:
+                if tuple(t.shape) != shape:
+                    t = t.expand(shape)
+                t = t.contiguous().reshape(-1)
+            else:
+                t = t.reshape(1)
+        else:
+            t = torch.tensor([float(np.asarray(v).reshape(()))], dtype=dtype, device=dev)
+        flat.append(t)
+    ibits = torch.int64 if dtype == torch.float64 else torch.int32
+    step = max(1, n // _GATHER_SAMPLE)
+    cols = [(t[::step] if t.numel() > 1 else t.expand((n + step - 1) // step)).view(ibits) for t in flat]
+    rows = torch.unique(torch.stack(cols, dim=1), dim=0)
+    if rows.shape[0] <= _lib.N_CLASSES:
+        rows = rows.view(dtype).cpu().numpy()                       # (r, 11), the sample's distinct rows
+        cls = torch.empty(n, dtype=torch.uint8, device=dev)
+        ctx = _lib.context(index)
+        fn = ctx.lib.mod16_classify_f32 if np_dtype == _F32 else ctx.lib.mod16_classify_f64
+        stream = _ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ptrs = _lib.ptr_array([t.data_ptr() for t in flat])
+        strides = _lib.i64_array([1 if t.numel() > 1 else 0 for t in flat])
+        missing = _ctypes.c_int64(-1)
+        while True:
+            host_rows = np.ascontiguousarray(rows, np_dtype)
+            ctx.check(fn(ctx.handle, ptrs, strides, n, host_rows.ctypes.data, int(host_rows.shape[0]),
+                         cls.data_ptr(), _ctypes.byref(missing), stream))
+            if missing.value < 0:
+                table = np.full((_lib.N_CLASSES, _lib.N_PARAMS), np.nan)
+                table[:host_rows.shape[0]] = host_rows.astype(np.float64)
+                answer = (table, cls)
+                break
+            if rows.shape[0] >= _lib.N_CLASSES:
+                break                                               # a 14th row: not a gather of a table
+            i = int(missing.value)
+            extra = np.array([[float(t[i if t.numel() > 1 else 0]) for t in flat]], np_dtype)
+            rows = np.concatenate([rows, extra], axis=0)
+    if cache is not None:
+        cache.clear()
+        cache.update(key=key, answer=answer, keep=pars)     # (the tensors stay alive: ids are not reused under the key)
+    return answer
+
+
+def _forward_device(drivers, params, separate, flags, pet=False, cache=None):
     '''``MOD16.evapotranspiration`` on ``torch`` tensors that live on the GPU (extension): the
     same entry points in DEVICE mode -- zero-copy, asynchronous on the current stream of the
     tensors' device -- and ``torch`` tensors back, shaped as the reference shapes its arrays.
@@ -448,7 +517,18 @@ def _forward_device(drivers, params, separate, flags, pet=False):
             optr = [o.data_ptr() for o in outs]
             dptr, dstr, pptr, pstr = ptrs[:14], strides[:14], ptrs[14:], strides[14:]
             cptr = None
-            if min(dstr) == 1 and not any(_is_device_tensor(v) for v in params):
+            gathered = None
+            if min(dstr) == 1 and n >= _SPREAD_SCALARS_FROM and any(_is_device_tensor(v) for v in params):
+                gathered = _gathered_classes(torch, dev, index, values, shape, n, dtype, np_dtype, cache)
+            if gathered is not None:
+                # per-pixel parameter tensors that are a gather of <= 13 rows (the reference's multi-class
+                # idiom): the production pipeline with the rows as its table and the class raster the
+                # library made of the eleven rasters -- 14 drivers + 1 byte per pixel instead of 25 arrays
+                table, cls_t = gathered
+                ctx = _tensor_context(torch, dev, index, table)
+                cptr = cls_t.data_ptr()
+                pptr = pstr = None
+            elif min(dstr) == 1 and not any(_is_device_tensor(v) for v in params):
                 # Dense drivers, one set of parameters (a MOD16Collection61 of one plant functional
                 # type: the reference's usual call): the production pipeline instead of the plain
                 # kernel (77 instead of 55 % of the HBM peak in float64) -- the parameters as row 1
@@ -616,7 +696,8 @@ class MOD16(object):
             temp_day, temp_night, temp_annual, tmin, vpd_day, vpd_night,
             pressure, fpar, lai)
         if any(_is_device_tensor(v) for v in drivers):
-            return _forward_device(drivers, self._param_values(), separate, self.math)
+            return _forward_device(drivers, self._param_values(), separate, self.math,
+                                   cache=self.__dict__.setdefault('_gather_cache', {}))
         return _forward(
             None, drivers, self._param_values(), separate, self.math,
             self.device, devices=self.devices)
@@ -644,7 +725,8 @@ class MOD16(object):
             temp_day, temp_night, temp_annual, tmin, vpd_day, vpd_night,
             pressure, fpar, lai)
         if any(_is_device_tensor(v) for v in drivers):
-            return _forward_device(drivers, self._param_values(), False, self.math, pet=True)
+            return _forward_device(drivers, self._param_values(), False, self.math, pet=True,
+                                   cache=self.__dict__.setdefault('_gather_cache', {}))
         return _forward(None, drivers, self._param_values(), False, self.math,
                         self.device, pet=True, devices=self.devices)
 

@@ -36,7 +36,7 @@ OK = 0
 ERR_ARG, ERR_HIP, ERR_CLASS_RANGE, ERR_NOMEM, ERR_NO_DEVICE, ERR_NO_BPLUT = \
     -1, -2, -3, -4, -5, -6
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 LIB_NAME = 'libmod16hip.so'
 # MOD16_LIB: alternative build of the same library (kernel experiments only)
 LIB_PATH = os.environ.get('MOD16_LIB') or os.path.join(
@@ -200,6 +200,10 @@ PROTOTYPES = {
     'mod16_measure_copy': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
     'mod16_build_id': (C.c_char_p, []),
     'mod16_fold_diag': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'mod16_classify_f64': (C.c_int, [C.c_void_p, _PP, _I64P, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.POINTER(C.c_int64), C.c_void_p]),
+    'mod16_classify_f32': (C.c_int, [C.c_void_p, _PP, _I64P, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.POINTER(C.c_int64), C.c_void_p]),
     'mod16_time_et': (C.c_int, [
         C.c_void_p, C.c_int, C.c_void_p, _PP, _I64P, _PP, _I64P, C.c_int64,
         C.c_void_p, C.c_void_p, _PP, C.c_uint, C.c_void_p, C.c_int, C.c_void_p,

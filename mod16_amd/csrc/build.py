@@ -41,11 +41,21 @@ def build_id(extra=()):
     return h.hexdigest()[:16]
 
 
-def up_to_date(out):
-    if not os.path.exists(out):
-        return False
-    t = os.path.getmtime(out)
-    return all(os.path.getmtime(d) <= t for d in DEPS + [__file__])
+def built_id(out):
+    '''The build id inside a built library (None: no file, or one from before the marker).'''
+    import re
+    try:
+        with open(out, 'rb') as f:
+            m = re.search(rb'mod16-build-id=([0-9a-f]{16})', f.read())
+    except OSError:
+        return None
+    return m.group(1).decode() if m else None
+
+
+def up_to_date(out, extra=()):
+    '''The library on disk was built from the sources on disk: its id IS their digest (round 5
+    compared file dates, and a snapshot that already held a library never met the compiler).'''
+    return built_id(out) == build_id(extra)
 
 
 def command(out, extra):
@@ -59,7 +69,7 @@ def build(force=False, verbose=True, experiments=True):
     todo = [(OUT, [])] + ([(OUT_EXP, ['-DMOD16_EXPERIMENTS'])] if experiments else [])
     procs = []
     for out, extra in todo:
-        if not force and up_to_date(out):
+        if not force and up_to_date(out, extra):
             continue
         cmd = command(out, extra)
         if verbose:

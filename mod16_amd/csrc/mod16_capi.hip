@@ -131,7 +131,10 @@ extern "C" int mod16_version(void) { return MOD16_ABI_VERSION; }
 #ifndef MOD16_BUILD_ID
 #define MOD16_BUILD_ID "unknown"
 #endif
-extern "C" const char* mod16_build_id(void) { return MOD16_BUILD_ID; }
+// (behind a marker that build.py finds in the file: a library whose id is not the digest of the
+// sources next to it is rebuilt, whatever the files' dates say)
+static const char kBuildIdMarker[] = "mod16-build-id=" MOD16_BUILD_ID;
+extern "C" const char* mod16_build_id(void) { return kBuildIdMarker + sizeof("mod16-build-id=") - 1; }
 
 extern "C" const char* mod16_strerror(int status) {
     switch (status) {
@@ -2642,6 +2645,63 @@ extern "C" int mod16_fold_diag(mod16_ctx* ctx, const double* gathered, int world
     hipLaunchKernelGGL(fold_diag_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), gathered, world, diag);
     HIPCHK(ctx, hipGetLastError());
     return MOD16_OK;
+}
+
+// ---------------------------------------------- parameter rasters -> class raster
+// (mod16_classify_*: DEVICE pointers; waits for the stream, because the caller decides on the answer)
+template <typename T>
+static int classify_entry(mod16_ctx* ctx, const T* const* params, const int64_t* pstride, int64_t n,
+                          const T* rows, int nrows, uint8_t* cls, int64_t* unmatched, void* stream) {
+    if (!ctx) return MOD16_ERR_ARG;
+    if (!params || !pstride || !rows || !cls || !unmatched || n < 0 || nrows < 1 || nrows > kClassRows)
+        return fail(ctx, MOD16_ERR_ARG, "mod16_classify: params, pstride, rows (1 .. 13), cls and unmatched are required");
+    *unmatched = -1;
+    if (n == 0) return MOD16_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ClassifyArgs<T> a;
+    a.dense = 0;
+    for (int k = 0; k < kClassPars; ++k) {
+        if (!params[k]) return fail(ctx, MOD16_ERR_ARG, "mod16_classify: a parameter pointer is NULL");
+        if (pstride[k] != 0 && pstride[k] != 1) return fail(ctx, MOD16_ERR_ARG, "mod16_classify: strides are 0 (one value) or 1 (a raster)");
+        a.par[k] = params[k];
+        if (pstride[k]) a.dense |= 1u << k;
+    }
+    // rows (host) and the answer word share one small device block
+    char* block = nullptr;
+    const size_t rbytes = (sizeof(T) * kClassRows * kClassPars + 15) / 16 * 16;      // (the 64-bit answer word behind them: aligned)
+    HIPCHK(ctx, hipMalloc(&block, rbytes + 8));
+    const unsigned long long none = ~0ull;
+    hipError_t e = hipMemcpyAsync(block, rows, sizeof(T) * nrows * kClassPars, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(block + rbytes, &none, 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        a.rows = reinterpret_cast<const T*>(block);
+        a.nrows = nrows;
+        a.n = n;
+        a.cls = cls;
+        a.unmatched = reinterpret_cast<unsigned long long*>(block + rbytes);
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, (int64_t)ctx->cus * 16));
+        hipLaunchKernelGGL(classify_kernel<T>, dim3(grid), dim3(kBlock), 0, st, a);
+        e = hipGetLastError();
+    }
+    unsigned long long got = none;
+    if (e == hipSuccess) e = hipMemcpyAsync(&got, block + rbytes, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(block);
+    HIPCHK(ctx, e);
+    *unmatched = got == none ? -1 : (int64_t)got;
+    return MOD16_OK;
+}
+
+extern "C" int mod16_classify_f64(mod16_ctx* ctx, const double* const* params, const int64_t* pstride, int64_t n,
+                                  const double* rows, int nrows, uint8_t* cls, int64_t* unmatched, void* stream) {
+    MOD16_LOCK(ctx);
+    return classify_entry<double>(ctx, params, pstride, n, rows, nrows, cls, unmatched, stream);
+}
+extern "C" int mod16_classify_f32(mod16_ctx* ctx, const float* const* params, const int64_t* pstride, int64_t n,
+                                  const float* rows, int nrows, uint8_t* cls, int64_t* unmatched, void* stream) {
+    MOD16_LOCK(ctx);
+    return classify_entry<float>(ctx, params, pstride, n, rows, nrows, cls, unmatched, stream);
 }
 
 // ---------------------------------------------------------------- generator

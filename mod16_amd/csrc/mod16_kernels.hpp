@@ -433,6 +433,77 @@ __global__ void __launch_bounds__(kFinalBlock) diag_final_fused_kernel(const dou
     }
 }
 
+// ------------------------------------------------ parameter rasters -> class raster
+// The reference's multi-class idiom gathers the BPLUT per pixel (mod16/utils.py:81-117, notebook
+// cell 32: MOD16({k: bplut[k][pft_map]})): eleven parameter rasters that hold, pixel for pixel, one
+// of at most 13 rows. This kernel turns them back into a class raster (mod16_classify_*): every
+// pixel's eleven values are compared BIT FOR BIT (a NaN row -- an invalid class -- matches itself)
+// with `nrows` candidate rows and the pixel gets the index of the first row that matches; a pixel that
+// matches none reports its index (the smallest such index of the launch, so that the caller can take
+// that pixel's row in and try again) -- the production pipeline then reads 14 drivers + 1 byte per
+// pixel where the plain kernel read 25 arrays. One pass over the 11 rasters, HBM-bound (89 B/pixel
+// in float64): a hash of the pixel's values picks the candidate row.
+template <typename T> struct ParamBits;
+template <> struct ParamBits<double> { typedef unsigned long long type; };
+template <> struct ParamBits<float> { typedef unsigned type; };
+constexpr int kClassRows = 13, kClassPars = 11;
+
+template <typename T> struct ClassifyArgs {
+    const T* par[kClassPars];
+    uint32_t dense;            // bit k set: parameter k is a dense raster, else ONE value (par[k][0])
+    const T* rows;             // device [nrows][11]: the candidate rows
+    int nrows;
+    int64_t n;
+    uint8_t* cls;
+    unsigned long long* unmatched;     // device word, UINT64_MAX before the launch: atomicMin of the index of a pixel that matches no row
+};
+
+template <typename U> __device__ __forceinline__ unsigned mix_param(unsigned h, U bits) {
+    const unsigned lo = (unsigned)bits, hi = sizeof(U) == 8 ? (unsigned)((unsigned long long)bits >> 32) : 0u;
+    return (h ^ lo ^ (hi * 0x85ebca6bu)) * 0x9e3779b1u;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) classify_kernel(const ClassifyArgs<T> a) {
+    typedef typename ParamBits<T>::type U;
+    __shared__ U rows[kClassRows][kClassPars];
+    __shared__ unsigned row_hash[kClassRows];
+    for (int i = threadIdx.x; i < a.nrows * kClassPars; i += kBlock)
+        rows[i / kClassPars][i % kClassPars] = reinterpret_cast<const U*>(a.rows)[i];
+    __syncthreads();
+    if ((int)threadIdx.x < a.nrows) {
+        unsigned h = 0x1234567u;
+        for (int k = 0; k < kClassPars; ++k) h = mix_param<U>(h, rows[threadIdx.x][k]);
+        row_hash[threadIdx.x] = h;
+    }
+    __syncthreads();
+    U one[kClassPars];                 // the values of the parameters that are not rasters
+#pragma unroll
+    for (int k = 0; k < kClassPars; ++k) one[k] = ((a.dense >> k) & 1u) ? U(0) : *reinterpret_cast<const U*>(a.par[k]);
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    unsigned long long missing = ~0ull;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += step) {
+        U v[kClassPars];
+        unsigned h = 0x1234567u;
+#pragma unroll
+        for (int k = 0; k < kClassPars; ++k) {
+            v[k] = ((a.dense >> k) & 1u) ? reinterpret_cast<const U*>(a.par[k])[i] : one[k];
+            h = mix_param<U>(h, v[k]);
+        }
+        int found = -1;
+        for (int r = 0; r < a.nrows && found < 0; ++r) {
+            if (row_hash[r] != h) continue;
+            bool same = true;
+#pragma unroll
+            for (int k = 0; k < kClassPars; ++k) same &= rows[r][k] == v[k];
+            found = same ? r : -1;
+        }
+        a.cls[i] = (uint8_t)(found < 0 ? 0 : found);
+        if (found < 0 && (unsigned long long)i < missing) missing = (unsigned long long)i;
+    }
+    if (missing != ~0ull) atomicMin(a.unmatched, missing);
+}
+
 // ------------------------------------------------------- copy (measurement aid)
 // One-shot 16-byte-per-lane copy, the reference point "measured copy bandwidth"
 // of SURVEY.md section 8d next to the 8 TB/s nominal peak (mod16_measure_copy).

@@ -873,3 +873,57 @@ def test_a_loop_over_parameter_sets_on_device_tensors(m16, golden):
             assert same_bits(g.cpu().numpy(), w), k
     mod16_amd.release_device_cache()
     assert not mod16_amd._tensor_local.contexts
+
+
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_gathered_parameter_tensors_take_the_pipeline(m16, dtype):
+    """The reference's multi-class idiom on device tensors (notebook cell 32):
+    MOD16({k: bplut[k][pft_map]}).evapotranspiration(*tensors) -- eleven parameter rasters that are a
+    gather of the table's rows (all 11 valid classes + the two invalid ones, whose rows are NaN) are
+    recognised (mod16_classify_*), turned into a class raster on the device and run through the
+    production pipeline: the numpy call's bits (which are the plain kernel's, per-pixel parameters).
+    The recognition is kept with the model for as long as the tensors are unchanged; genuinely
+    per-pixel parameters (more than 13 distinct rows) keep taking the plain kernel."""
+    import torch
+    import mod16_amd
+    from mod16_amd.utils import restore_bplut, bplut_table
+    from mod16_amd.models import COLLECTION61_BPLUT
+    np_dtype = np.dtype(dtype)
+    table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
+    shape = (1030, 1024)                                    # > 2^20 pixels
+    cls, drv = synth.drivers(shape, seed=21, dtype=np_dtype)
+    cls[5, 7:9] = [0, 11]                                   # the invalid classes are there
+    cls[cls == 3] = 4
+    cls[1000, 1000] = 3                                     # ... and class 3 only where the sample does not look
+    names = mod16_amd.MOD16.required_parameters
+    par_h = {k: table[:, j][cls].astype(np_dtype) for j, k in enumerate(names)}
+    par_d = {k: torch.from_numpy(v).cuda() for k, v in par_h.items()}
+    par_d['beta'] = 250.0                                   # one of them a plain number
+    dev = [torch.from_numpy(a).cuda() for a in drv]
+    m_host, m_dev = m16.MOD16(par_h), m16.MOD16(par_d)
+    want = m_host.evapotranspiration(*drv)
+    got = m_dev.evapotranspiration(*dev)
+    torch.cuda.synchronize()
+    answer = m_dev._gather_cache['answer']
+    assert answer is not None and answer[1].dtype == torch.uint8
+    found = answer[0][:, 10] == 250.0                        # (rows in use: beta is a number in every one)
+    assert np.isfinite(answer[0][found, 0]).sum() == 11 and np.isnan(answer[0][found, 0]).sum() == 1   # 11 classes + the NaN row
+    for g, w in zip(got, want):
+        assert g.dtype == getattr(torch, dtype) and same_bits(g.cpu().numpy(), w)
+    # the class raster the library made: every pixel's row IS its parameters
+    back = answer[0][answer[1].cpu().numpy().reshape(shape)]
+    assert same_bits(back[..., 7].astype(np_dtype), par_h['csl'])
+    # again: the recognition is reused (same objects, unchanged) -- and redone after an in-place change
+    first = answer[1].data_ptr()
+    for g, w in zip(m_dev.evapotranspiration(*dev, separate=True)[0], m_host.evapotranspiration(*drv, separate=True)[0]):
+        assert same_bits(g.cpu().numpy(), w)
+    assert m_dev._gather_cache['answer'][1].data_ptr() == first
+    for j, f in ((0, 1.5), (1, 1.7), (2, 1.9)):               # now the raster holds more than 13 rows
+        par_d['csl'][0, j] *= f
+        par_h['csl'][0, j] = par_d['csl'][0, j].item()
+    got = m_dev.evapotranspiration(*dev)
+    torch.cuda.synchronize()
+    assert m_dev._gather_cache['answer'] is None             # not a gather any more: the plain kernel
+    for g, w in zip(got, m_host.evapotranspiration(*drv)):
+        assert same_bits(g.cpu().numpy(), w)
+    mod16_amd.release_device_cache()

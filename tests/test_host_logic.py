@@ -308,3 +308,22 @@ def test_pinned_pool_bound_per_rank_and_deferred_frees(monkeypatch):
     pool.deferred.append(333)
     pool.trim()
     assert freed == [111, 333]
+
+
+def test_build_is_judged_by_the_digest_in_the_library(tmp_path):
+    """mod16_amd/csrc/build.py rebuilds a library whose embedded build id is not the digest of the
+    sources beside it -- whatever the files' dates say (round 5 compared dates: a snapshot that
+    already held a library never met the compiler): the in-tree library is current, a copy of it
+    with another id is not, and neither is a file without the marker."""
+    sys.path.insert(0, os.path.join(ROOT, 'mod16_amd', 'csrc'))
+    import build
+    assert build.built_id(build.OUT) == build.build_id() and build.up_to_date(build.OUT)
+    assert build.built_id(build.OUT_EXP) == build.build_id(['-DMOD16_EXPERIMENTS'])
+    assert build.up_to_date(build.OUT_EXP, ['-DMOD16_EXPERIMENTS']) and not build.up_to_date(build.OUT_EXP)
+    blob = open(build.OUT, 'rb').read()
+    mine = build.build_id().encode()
+    other = tmp_path / 'other.so'
+    other.write_bytes(blob.replace(b'mod16-build-id=' + mine, b'mod16-build-id=' + b'0123456789abcdef'))
+    os.utime(other, None)                                  # newer than every source
+    assert build.built_id(str(other)) == '0123456789abcdef' and not build.up_to_date(str(other))
+    assert build.built_id(str(tmp_path / 'absent.so')) is None
