@@ -18,7 +18,7 @@
 #if defined(MOD16_TRIVIAL_BODY) || defined(MOD16_NO_GUARD) || defined(MOD16_EXPERIMENT_SEED_RCP) || \
     defined(MOD16_PRIO) || defined(MOD16_REPRO_V4) || defined(MOD16_NO_FUSED_FINAL) ||                \
     defined(MOD16_NO_REDO_LAUNCH) || defined(MOD16_KK_M) || defined(MOD16_NO_FMA_KK) ||               \
-    defined(MOD16_DYN_RUN) || defined(MOD16_MIXED_NO_CANCEL) || defined(MOD16_MIXED_CANCEL)
+    defined(MOD16_DYN_RUN) || defined(MOD16_MIXED_NO_CANCEL) || defined(MOD16_MIXED_CANCEL) || defined(MOD16_F64_CAND)
 #error "MOD16_* measurement switches need -DMOD16_EXPERIMENTS (they are not part of the product build)"
 #endif
 #endif
@@ -99,6 +99,13 @@ template <> struct FastMath<double> {
     static __device__ __forceinline__ T vmin_k(T a, T k) {
         T d;
         asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k));
+        return d;
+    }
+
+    // min(max(x, 0), 1) as v_max_f64 + v_min_f64 (a NaN x gives 0: v_max passes it over)
+    static __device__ __forceinline__ T clamp01(T x) {
+        T d;
+        asm("v_max_f64 %0, %1, 0\n\tv_min_f64 %0, %0, 1.0" : "=&v"(d) : "v"(x));
         return d;
     }
 

@@ -560,6 +560,19 @@ template <int LEVEL> struct KPin {
     static __device__ __forceinline__ double per_period(double c) { return LEVEL >= 1 ? in_vgpr(c) : c; }
     static __device__ __forceinline__ double per_pixel(double c) { return LEVEL >= 2 ? in_vgpr(c) : c; }
 };
+// Round 6, fewer float64 instructions per pixel (three candidates, A/B on one device:
+// profiles/r06_ab_f64_candidates.txt; 1018 -> 987 vector instructions per pair of pixels in the
+// totals loop). MOD16_F64_CAND (measurement builds) keeps the first n of the two that stayed:
+//   1  LAI = 0 is not replaced by `tiny` (:935): nothing divides by LAI in conductances, and such a
+//      pixel's canopy is the 0 of :961 whatever its quotient (as fwet = 0 since round 5)
+//   2  the two VPD ramps (:527-531 r_tot, :1148-1150 m_vpd) from ONE clamp of (vpd - vpd_open) /
+//      (vpd_close - vpd_open) to [0, 1] (v_max_f64 + v_min_f64) instead of two compares and two
+//      64-bit selects each
+// (the third, the Tetens exponent as one fma behind the shared reciprocal, gained nothing and cost
+// accuracy: see period_fast)
+#ifndef MOD16_F64_CAND
+#define MOD16_F64_CAND 2
+#endif
 // Quantities that do not depend on the period (day / night).
 template <typename T> struct PixelShared {
     T oma;        // 1 - albedo
@@ -571,6 +584,7 @@ template <typename T> struct PixelShared {
     T glsh_l, glwv_l;   // gl_sh * l_wet, gl_wv * l_wet
     T glsh_lai;   // gl_sh * lai (transpiration, :1242)
     T m_tmin;     // Tmin ramp (day only)
+    T drbl;       // rbl_max - rbl_min
     bool lai_pos, lai_tiny;
 };
 
@@ -617,6 +631,8 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     T r_es = r_both * ta, rta = r_both * d_es;
     // (a NaN temperature stays NaN through the table exp: rint, the fmas and the table product
     // all propagate it; an infinite one gives inf * 0 in r_es)
+    // (round 6 tried 17.27 - 17.27 * 237.3 r_es, one fma: no time gained, and the exponent's ABSOLUTE
+    // error near 0 C -- 2e-15 instead of 2e-16 |x| -- showed as 2e-9 in the worst pixels of the grid)
     T e_es = M::exp_tab5s((KP::per_period(17.27) * tc) * r_es, tb);
     T esat = T(1e3 * 0.6108) * e_es;
     if constexpr (RAW) {
@@ -663,6 +679,9 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     T t2 = t * t;
     T g_rr = (K<T>::sigma4 * (t2 * t2)) * M::rcp(nn);
     T rcfv = rho_cp * vpd;             // rho Cp vpd
+#if MOD16_F64_CAND >= 2
+    T vramp = M::clamp01((vpd - p.vpd_open) * p.inv_dvpd);
+#endif
 
     // -- wet canopy, :866-961 in conductances:
     //    1/r_a = g_h + 1/r_r ; evap = numer g_e / ((s lhv) g_e + k_p / r_a)
@@ -683,9 +702,16 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     }
     // -- bare soil, :449-544 and :795-864
     {
+#if MOD16_F64_CAND >= 2
+        // rbl_min + (rbl_max - rbl_min) clamp01((vpd - vpd_open) / (vpd_close - vpd_open)), :527-531:
+        // exactly rbl_min up to vpd_open, rbl_max to an ulp from vpd_close on. A NaN vpd leaves the
+        // clamp as 0 (v_max_f64 passes a NaN over) -- and the period as NaN through rho Cp vpd.
+        T r0 = __builtin_fma(vramp, sh.drbl, p.rbl_min);
+#else
         T r0 = __builtin_fma(-(p.vpd_close - vpd), p.rbl_slope, p.rbl_max);   // :527-531
         r0 = (vpd >= p.vpd_close) ? p.rbl_max : r0;
         r0 = (vpd <= p.vpd_open) ? p.rbl_min : r0;
+#endif
         T r_tot = r0 * inv_rcorr;                                  // :533
         T w = __builtin_fma(r_tot, g_rr, T(1));                    // r_tot / r_as
         T num = __builtin_fma((s * rad_soil), r_tot, (rcfv * sh.omf) * w);
@@ -710,9 +736,13 @@ __device__ __forceinline__ void period_fast(const PixelIn<T>& x, const ClassPar<
     {
         T g_s = T(0);
         if (DAY) {
+#if MOD16_F64_CAND >= 2
+            T m_vpd = T(1) - vramp;                                // :1148-1150 (exactly 1 / 0 outside the ramp)
+#else
             T m_vpd = __builtin_fma(-(vpd - p.vpd_open), p.inv_dvpd, T(1));
             m_vpd = (vpd < p.vpd_open) ? T(1) : m_vpd;
             m_vpd = (vpd >= p.vpd_close) ? T(0) : m_vpd;
+#endif
             g_s = ((p.csl * sh.m_tmin) * m_vpd) * inv_rcorr;       // :1237
         }
         T gsc = __builtin_fma(p.g_cut, inv_rcorr, g_s);            // :1238
@@ -770,12 +800,22 @@ __device__ __forceinline__ PixelOut<T> et_pixel_fast(const PixelIn<T>& x, const 
     sh.p_rel = x.pa * KP::per_pixel(0.2050207779207528);        // 293.15^1.75 / 101300
     sh.k_p = x.pa * KP::per_pixel(1013.0 / 0.622);
     sh.p_mbar_k = x.pa * KP::per_pixel(1013.0 * 0.348444 / 100.0);
+#if MOD16_F64_CAND >= 1
+    sh.l_wet = x.lai;
+    sh.lai_tiny = x.lai <= K<T>::tiny;                 // (:935 made a LAI of 0 `tiny`: one of them)
+    sh.lai_pos = x.lai > T(0);
+    sh.glsh_lai = p.gl_sh * x.lai;
+    sh.glsh_l = sh.glsh_lai;
+    sh.glwv_l = p.gl_wv * x.lai;
+#else
     sh.l_wet = (x.lai == T(0)) ? K<T>::tiny : x.lai;
     sh.lai_tiny = sh.l_wet <= K<T>::tiny;
     sh.lai_pos = x.lai > T(0);
     sh.glsh_l = p.gl_sh * sh.l_wet;
     sh.glwv_l = p.gl_wv * sh.l_wet;
     sh.glsh_lai = p.gl_sh * x.lai;
+#endif
+    sh.drbl = p.rbl_max - p.rbl_min;
     T tm = x.tmin - K<T>::t0;
     sh.m_tmin = (tm - p.tmin_close) * p.inv_dtmin;
     sh.m_tmin = (tm < p.tmin_close) ? T(0) : sh.m_tmin;
