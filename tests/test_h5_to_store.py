@@ -185,3 +185,96 @@ def test_converted_container_through_run_store_matches_the_oracle(tmp_path):
             gaps[tag] = max(float(np.nanmax(np.where(t != 0, np.abs(o - t) / np.abs(t), 0.0))) for o, t in zip(ours, tower))
     assert gaps['homogeneous'] < 1e-5, gaps          # same inputs in every sub-pixel: the two orders agree
     assert gaps['mixed'] > 1e-3, gaps                # heterogeneous sub-grid: mean of ETs != ET of means
+
+
+def test_field_map_covers_what_the_reference_reads():
+    """tools/h5_to_store.py's field map against the layout AS THE REFERENCE STATES IT
+    (tests/golden/calval_layout.json: the file specification of calibration.py:50-112 and every
+    dataset _load_data, :304-423, opens -- tests/golden/make_calval_layout.py reads both out of the
+    reference's text): every look-up key the reference's forward-run inputs come from is a key of
+    the converter (same key, same day / night indices), every default path is a dataset of the
+    documented layout with the rank the converter expects, nothing is read that the reference does
+    not read, and the keys left out are the ones that are no forward-run input."""
+    import json
+    import h5_to_store
+    from conftest import GOLDEN
+    from mod16_amd import io
+    lay = json.load(open(os.path.join(GOLDEN, 'calval_layout.json')))
+    documented = {e['path']: e for e in lay['documented']}
+    ref_keys = lay['load_data']['lookup_keys']
+    # look-up keys: the reference's, plus class_map (a configuration key there, calibration.py:336)
+    mine = dict(h5_to_store.SOURCES)
+    assert 'class_map' in lay['load_data']['config_keys'] and 'class_map' in mine
+    assert set(mine) - {'class_map'} == set(ref_keys) - {'VPD'}, (sorted(mine), sorted(ref_keys))
+    for key, indices in ref_keys.items():
+        if key == 'VPD':
+            continue                                    # optional in the reference too (:391-393): --subgrid mean reads it if named
+        v = mine[key]
+        if indices:                                     # lookup[KEY][i]: a [daytime, nighttime] pair, same indices read
+            assert isinstance(v, list) and len(v) == 2 and all(v[i] for i in indices), key
+        else:
+            assert isinstance(v, str), key
+    # every default path is documented, with the rank the converter handles
+    rank = {'class_map': ['N', 'P'], 'elevation': ['N'], 'albedo': ['T', 'N', 'P'], 'fPAR': ['T', 'N', 'P'], 'LAI': ['T', 'N', 'P']}
+    for key, v in mine.items():
+        for path in (v if isinstance(v, list) else [v]):
+            if path is None:
+                continue
+            assert path in documented, path
+            assert documented[path]['dims'] == rank.get(key, ['T', 'N']), (path, documented[path]['dims'])
+    # names the reference lets its configuration change are the ones --name changes here (all keys);
+    # the MODIS and land-cover names carry the star in the documented layout
+    for key in ('albedo', 'fPAR', 'LAI', 'class_map'):
+        assert documented[mine[key]]['starred'], key
+    # the store's files: one per dynamic driver of mod16_amd.io, each fed by a look-up key
+    assert set(h5_to_store.STORE_FROM) == {name for _, name in io.DYNAMIC_FIELDS}
+    for name, (key, index) in h5_to_store.STORE_FROM.items():
+        assert h5_to_store.source(mine, key, index) == name      # default names: the store mirrors the container
+    # the shipped configuration's keys: the forward-run ones are all here; annual_precip is a constraint
+    # of the calibration (:constraints), not a driver
+    shipped = set(lay['shipped_config_datasets'])
+    assert shipped - set(mine) - {'VPD'} == {'annual_precip'}
+    # what _load_data opens besides the drivers is calibration bookkeeping the forward run does not need
+    assert set(lay['load_data']['literal_paths']) == {'FLUXNET/site_id', 'FLUXNET/validation_mask', 'time', 'weights'}
+
+
+@pytest.mark.gpu
+def test_tower_protocol_subgrid_mean_matches_the_oracle(tmp_path):
+    """--subgrid mean: the reference's own tower protocol (calibration.py:336-340, :380-423) -- fPAR,
+    LAI and albedo averaged over the sub-grid BEFORE one forward run per tower-day on the sub-grid's
+    dominant PFT. The converter writes the processed drivers (VPD and air pressure through the
+    library's methods), run_processed streams them through the forward run; against the oracle fed
+    the container's own fields through the oracle's restatement of that pre-processing."""
+    import fake_h5py
+    import h5_to_store
+    from mod16_amd import io
+    from mod16_amd.utils import restore_bplut, bplut_table, pft_dominant
+    from mod16_amd.models import COLLECTION61_BPLUT
+    from parity import assert_parity
+    table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
+    bplut = {k: table[:, j] for j, k in enumerate(oracle.PARAM_NAMES)}
+    T = T_ALL - T0
+    src = container()
+    out_dir = h5_to_store.convert(fake_h5py.File(src), str(tmp_path / 'm'), t0=T0, subgrid='mean')
+    # the means are np.nanmean over the sub-grid, as floats (no MODIS codes), scaled as :422-423
+    with np.errstate(all='ignore'):
+        want_fpar = np.nanmean(src['MODIS/MOD15A2HGF_fPAR'][T0:].astype(np.float64), axis=-1) / 100
+    got_fpar = np.load(os.path.join(out_dir, 'fpar.npy'))
+    assert got_fpar.shape == (T, N) and got_fpar.dtype == np.float32
+    assert np.allclose(got_fpar, want_fpar, rtol=1e-6, equal_nan=True)
+    assert np.array_equal(np.load(os.path.join(out_dir, 'class.npy'))[0], pft_dominant(src['state/PFT']).astype(np.uint8))
+    assert not np.load(os.path.join(out_dir, 'sw_rad_night.npy')).any()
+    day, night = h5_to_store.run_processed(table, out_dir)
+    # the oracle on the same protocol
+    cls_t, raw_t, fpar_t, lai_t = reference_inputs(src, 'mean')
+    cls_dom = np.broadcast_to(pft_dominant(src['state/PFT']).astype(np.uint8), (T, N))
+    with np.errstate(all='ignore'):
+        params = oracle.gather_params(bplut, cls_dom)
+        vpd_d = oracle.vpd_from_humidity(raw_t[9], raw_t[11], raw_t[5])
+        vpd_n = np.maximum(oracle.vpd_from_humidity(raw_t[10], raw_t[12], raw_t[6]), 0)
+        want = oracle.evapotranspiration(params, *raw_t[:9], vpd_d, vpd_n, oracle.air_pressure(raw_t[13]),
+                                         fpar_t / 100, lai_t / 10)
+    for g, w, what in zip((day, night), want, ('day', 'night')):
+        assert g.shape == (T, N) and g.dtype == np.float32
+        # float32 drivers (VPD is a difference of like numbers in humid air): 2e-4
+        assert_parity(np.asarray(g), np.asarray(w, np.float64).astype(np.float32), 2e-4, what)
