@@ -22,14 +22,28 @@
  *     65536, 0 = never; mod16_et_*, mod16_et_raw_*, mod16_method_*,
  *     mod16_et_static_*) issue no copy commands: the kernel reads its inputs
  *     from a page-locked buffer of the ctx and writes its outputs there (one
- *     launch, one synchronisation; same kernels, same results), and a class
+ *     launch, one synchronisation; same kernels, same results -- with ONE
+ *     exception: a MOD16_MATH_MIXED call whose pixel count is no multiple of
+ *     four computes its last, incomplete vector through the pipeline here and
+ *     with the float64 (FAST) arithmetic on the staged path: those up to three
+ *     pixels agree to the mixed form's tolerance, not bit for bit), and a class
  *     code >= 13 is found before anything is launched;
  *   - DEVICE launches of one ctx share its diagnostics workspace: on ONE stream
  *     they are ordered anyway and nothing is added between them; the first
  *     launch a ctx makes on a second stream waits for the device once, and
  *     from then on every launch records an event the next one on another
  *     stream waits for (a stream may be destroyed by its owner at any time:
- *     the library never touches a stream it is not launching on);
+ *     the library never touches a stream it is not launching on). That one
+ *     wait is hipDeviceSynchronize(): other contexts of the process stall with
+ *     it, and it fails (MOD16_ERR_HIP) while another thread captures a stream
+ *     in hipStreamCaptureModeGlobal -- a program that does either gives every
+ *     stream its own ctx, or launches once on each stream before it starts
+ *     capturing;
+ *   - a launch that did not process its whole raster (kStatusIncomplete, see
+ *     mod16_check_status) is found by the kernels that run BEHIND the pipeline
+ *     kernel: the guard's pass (every guarded launch) or the diagnostics sum
+ *     (MOD16_DOMAIN_TRUSTED launches) -- a trusted launch without diagnostics
+ *     is not checked;
  *   - a ctx serialises the calls made on it (every entry point holds the ctx's
  *     mutex), so sharing one between host threads is safe; for concurrency use
  *     one ctx per host thread and GPU (each owns its staging slabs, streams,
@@ -123,14 +137,21 @@ enum mod16_where { MOD16_HOST = 0, MOD16_DEVICE = 1 };
                                  feeds the humidity terms, packed float32 elsewhere
                                  (dense class rasters; other shapes run FAST). Its domain
                                  is physical drivers (|lw|, |sw|, |albedo|, |vpd|, |fpar|,
-                                 |lai| < 1e5, 1e3 <= pressure < 1e7 Pa, 90 K < T < 1332 K);
+                                 |lai|, |tmin| < 1e5, 1e3 <= pressure < 1e7 Pa, 90 K < T < 1332 K);
                                  pixels outside it are computed in the reference's order,
-                                 float64, like FAST's */
+                                 float64, like FAST's. Values whose wet-canopy or bare-soil
+                                 numerator cancels below 1/320 of its terms relative to the
+                                 period's total (one pixel in 700 of the synthetic grid) are
+                                 computed again with the FAST form's float64 arithmetic behind
+                                 the pipeline kernel (round 6): against that arithmetic no value
+                                 of the global grid is off by more than 2.0e-4 of itself. With
+                                 MOD16_DOMAIN_TRUSTED nothing is revisited, that tail included */
 /* The caller vouches that every driver lies inside the domain above (quality-controlled or
  * NaN-masked rasters): the totals form of the production pipeline (dense class raster,
  * outputs day + night; mod16_et_*, mod16_et_diag_*, mod16_et_tiled_*, their graphs) then runs
  * the instance without the domain test and without the dispatch that revisits flagged pixels
- * (-1.6 % kernel time on the float64 global grid, -2.3 % MIXED: tools/guardcost.py, round 5). A pixel outside the domain then
+ * (-1.6 % kernel time on the float64 global grid, round 5; MIXED: -7 %, of which 5 % are the
+ * cancellation budgets of round 6: profiles/r06_mixed_cancel_threshold.txt). A pixel outside the domain then
  * gets whatever the rearranged arithmetic gives. Other forms and shapes ignore the flag. */
 #define MOD16_DOMAIN_TRUSTED 4u
 

@@ -16,14 +16,18 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SRC = os.path.join(HERE, 'mod16_capi.hip')
-DEPS = [SRC] + sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.hpp')) + [
+SRC = os.path.join(HERE, 'mod16_capi.hip')          # all families as ONE unit (variants, listings, tests/host_asan)
+CAPI = os.path.join(HERE, 'capi')
+FAMILIES = sorted(os.path.join(CAPI, f) for f in os.listdir(CAPI) if f.endswith('.hip'))
+DEPS = [SRC] + FAMILIES + sorted(os.path.join(d, f) for d in (HERE, CAPI) for f in os.listdir(d) if f.endswith('.hpp')) + [
     os.path.join(os.path.dirname(PKG), 'include', 'mod16_hip.h')]
 OUT = os.path.join(PKG, 'libmod16hip.so')
 OUT_EXP = os.path.join(PKG, 'libmod16hip_exp.so')
+OBJ = os.path.join(HERE, 'build')                    # object files of the families (git-ignored)
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-         '-fvisibility=hidden', '-Wall', '-Wno-unused-function']
+COMPILE = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-Wall', '-Wno-unused-function']
+FLAGS = COMPILE + ['-shared']                        # (the one-unit command line: see tools/README.md)
+JOBS = max(1, min(8, os.cpu_count() or 1))
 
 
 def build_id(extra=()):
@@ -33,7 +37,7 @@ def build_id(extra=()):
         h.update(os.path.basename(d).encode() + b'\0')
         with open(d, 'rb') as f:
             h.update(f.read())
-    h.update(' '.join(FLAGS + list(extra)).encode())
+    h.update(' '.join(FLAGS + list(extra)).encode())      # (round 5's flag string: ids stay comparable)
     try:
         h.update(subprocess.check_output([HIPCC, '--version'], stderr=subprocess.STDOUT))
     except (OSError, subprocess.CalledProcessError):
@@ -58,28 +62,47 @@ def up_to_date(out, extra=()):
     return built_id(out) == build_id(extra)
 
 
-def command(out, extra):
+def commands(out, extra):
+    '''(compile commands of the families, link command) of one library.'''
     name = os.path.basename(out)
-    return [HIPCC] + FLAGS + list(extra) + ['-DMOD16_BUILD_ID="%s"' % build_id(extra),
-                                            '-Wl,-soname,' + name, '-o', out, SRC]
+    tag = os.path.splitext(name)[0]
+    define = '-DMOD16_BUILD_ID="%s"' % build_id(extra)
+    objs, compiles = [], []
+    for fam in FAMILIES:
+        obj = os.path.join(OBJ, '%s_%s.o' % (tag, os.path.splitext(os.path.basename(fam))[0]))
+        objs.append(obj)
+        compiles.append([HIPCC] + COMPILE + list(extra) + [define, '-c', fam, '-o', obj])
+    link = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,-soname,' + name, '-o', out] + objs
+    return compiles, link
 
 
 def build(force=False, verbose=True, experiments=True):
-    '''Compiles what is out of date (the two libraries side by side).'''
+    '''Compiles what is out of date: the entry-point families of capi/ side by side (JOBS at a time),
+    then one link per library.'''
     todo = [(OUT, [])] + ([(OUT_EXP, ['-DMOD16_EXPERIMENTS'])] if experiments else [])
-    procs = []
-    for out, extra in todo:
-        if not force and up_to_date(out, extra):
-            continue
-        cmd = command(out, extra)
-        if verbose:
-            print(' '.join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, proc in procs:
+    todo = [(out, extra) for out, extra in todo if force or not up_to_date(out, extra)]
+    if not todo:
+        return OUT
+    os.makedirs(OBJ, exist_ok=True)
+    plans = [commands(out, extra) for out, extra in todo]
+    queue = [cmd for compiles, _ in plans for cmd in compiles]
+    running = []
+    while queue or running:
+        while queue and len(running) < JOBS:
+            cmd = queue.pop(0)
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            running.append((cmd, subprocess.Popen(cmd)))
+        cmd, proc = running.pop(0)
         if proc.wait() != 0:
+            for _, other in running:
+                other.kill()
             raise subprocess.CalledProcessError(proc.returncode, cmd)
-    if procs:
-        write_build_info()
+    for _, link in plans:
+        if verbose:
+            print(' '.join(link), flush=True)
+        subprocess.check_call(link)
+    write_build_info()
     return OUT
 
 

@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(kBlock) diag_partial_kernel(const T* __restric
     diag_block_reduce(acc, partial + (int64_t)blockIdx.x * kDiag);
 }
 
-__global__ void __launch_bounds__(kBlock) diag_final_kernel(const double* partial, int nblocks,
+static __global__ void __launch_bounds__(kBlock) diag_final_kernel(const double* partial, int nblocks,
                                                             double* out) {
     double acc[kDiag] = {0, 0, 0, 0, 0, 0, -__builtin_huge_val(), -__builtin_huge_val()};
     for (int b = threadIdx.x; b < nblocks; b += kBlock) {
@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(kBlock) diag_final_kernel(const double* partia
 // partials [b * per, (b + 1) * per) to out[b].
 // serial_word / status (trusted launches): see diag_final_fused_kernel -- the kernel that reads the
 // runs' own partials compares every run's marker.
-__global__ void __launch_bounds__(kBlock) diag_stage_kernel(const double* partial, int64_t count,
+static __global__ void __launch_bounds__(kBlock) diag_stage_kernel(const double* partial, int64_t count,
                                                             int64_t per, double* out,
                                                             const unsigned* serial_word = nullptr,
                                                             unsigned* status = nullptr) {
@@ -384,7 +384,7 @@ constexpr int kFinalBlock = 1024;
 // given to the kernel that reads the runs' OWN partials -- this one, or diag_stage_kernel for a
 // two-level sum): the launch's serial number AFTER the pipeline kernel incremented it and the status
 // word -- field kSerialField of every partial must hold this launch's marker.
-__global__ void __launch_bounds__(kFinalBlock) diag_final_fused_kernel(const double* partial,
+static __global__ void __launch_bounds__(kFinalBlock) diag_final_fused_kernel(const double* partial,
                                                                        int nblocks, int64_t n,
                                                                        double* out,
                                                                        const unsigned* serial_word = nullptr,
@@ -508,7 +508,7 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(const ClassifyArgs<T> 
 // One-shot 16-byte-per-lane copy, the reference point "measured copy bandwidth"
 // of SURVEY.md section 8d next to the 8 TB/s nominal peak (mod16_measure_copy).
 typedef float copy_vec_t __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(kBlock) copy_kernel(const copy_vec_t* __restrict__ src,
+static __global__ void __launch_bounds__(kBlock) copy_kernel(const copy_vec_t* __restrict__ src,
                                                       copy_vec_t* __restrict__ dst, int64_t nvec) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < nvec) dst[i] = src[i];

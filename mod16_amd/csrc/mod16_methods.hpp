@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(kBlock) static_obj_redo_kernel(const StaticObj
 // several loads in flight per thread; the slices are combined in order through LDS. (One thread per
 // draw walking all 391 blocks was 92 us per kernel -- two of them 13 % of an evaluation.)
 constexpr int kObjSlices = 8, kObjPerBlock = kBlock / kObjSlices;
-__global__ void __launch_bounds__(kBlock) static_obj_any_kernel(const unsigned* any_gs, const double* redo, int64_t ndraw,
+static __global__ void __launch_bounds__(kBlock) static_obj_any_kernel(const unsigned* any_gs, const double* redo, int64_t ndraw,
                                                                 int gx, unsigned* any_draw) {
     __shared__ unsigned sm[kObjSlices][kObjPerBlock];
     const int dl = threadIdx.x % kObjPerBlock, slice = threadIdx.x / kObjPerBlock;
@@ -624,7 +624,7 @@ __global__ void __launch_bounds__(kBlock) static_obj_any_kernel(const unsigned* 
 // the slices are added in order -- then the flagged pixels'. A fixed order: the same bits on every
 // launch. (By now the partials of a draw without g_surf > 0 anywhere hold the pass without
 // transpiration.)
-__global__ void __launch_bounds__(kBlock) static_obj_final_kernel(const double* partial, const double* redo,
+static __global__ void __launch_bounds__(kBlock) static_obj_final_kernel(const double* partial, const double* redo,
                                                                   const unsigned* any_draw, int64_t ndraw, int gx,
                                                                   double* sse, double* count) {
     __shared__ double sm[kObjSlices][kObjPerBlock][2];

@@ -359,7 +359,9 @@ constexpr int kCancelCap = 32;       // entries per run (64 bytes = one partial'
 // per SIMD; they alone are told to stay within two, and do so without a spill or a register parked
 // in the accumulator file -- the float32-raster ones because their four pixels per thread are kept
 // apart, see the loop; tests/test_abi.py::test_no_kernel_spills_vector_registers)
-constexpr int stream_min_waves(int mode, bool f64) { return mode == kStreamRawTotalHours ? 2 : 1; }
+// (round 6: the float64 raw-driver instance without the 8-day total as well -- 252 registers in round 5,
+// 258 once the ramps became clamps)
+constexpr int stream_min_waves(int mode, bool f64) { return mode == kStreamRawTotalHours || (mode == kStreamRaw && f64) ? 2 : 1; }
 #define MOD16_STREAM_BOUNDS __launch_bounds__(kBlock) \
     __attribute__((amdgpu_waves_per_eu(stream_min_waves(MODE, sizeof(T) == 8), 8)))
 template <typename T, int MODE, bool PITCHED = false, bool GUARD = true>

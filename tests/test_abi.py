@@ -172,7 +172,8 @@ def test_shipped_library_reads_no_experiment_switch(lib):
     assert not any(n.startswith(('MOD16_NO_', 'MOD16_EXPERIMENT', 'MOD16_TRIVIAL', 'MOD16_PRIO', 'MOD16_DYN'))
                    for n in shipped), shipped
     assert switches | {'MOD16_HOST_THREADS'} <= env_names(lib.EXP_LIB_PATH)
-    src = open(os.path.join(ROOT, 'mod16_amd', 'csrc', 'mod16_capi.hip')).read()
+    capi = os.path.join(ROOT, 'mod16_amd', 'csrc', 'capi')       # the library's host side, every family of it
+    src = ''.join(open(os.path.join(capi, f)).read() for f in sorted(os.listdir(capi)))
     product = re.sub(r'#ifdef MOD16_EXPERIMENTS.*?#endif', '', src, flags=re.S)
     assert re.findall(r'getenv\("(\w+)"\)', product) == ['MOD16_HOST_THREADS', 'MOD16_SMALL_PIXELS']
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'

@@ -2,6 +2,7 @@
 reference's own parse (golden), model construction, marshalling rules."""
 import io
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -315,6 +316,7 @@ def test_build_is_judged_by_the_digest_in_the_library(tmp_path):
     sources beside it -- whatever the files' dates say (round 5 compared dates: a snapshot that
     already held a library never met the compiler): the in-tree library is current, a copy of it
     with another id is not, and neither is a file without the marker."""
+    from conftest import ROOT
     sys.path.insert(0, os.path.join(ROOT, 'mod16_amd', 'csrc'))
     import build
     assert build.built_id(build.OUT) == build.build_id() and build.up_to_date(build.OUT)
