@@ -77,6 +77,13 @@ class _Worker(threading.Thread):
     def run(self):
         while True:
             fn, box, done = self.jobs.get()
+            if fn is None:                      # shutdown(): the thread's context goes with it
+                table = getattr(_lib._local, 'contexts', None) or {}
+                for ctx in table.values():
+                    ctx.close()
+                table.clear()
+                done.set()
+                return
             try:
                 box.append((True, fn(_lib.context(self.device))))
             except BaseException as exc:        # handed to the caller's thread
@@ -119,6 +126,26 @@ def run(devices, fn):
         if not ok:
             raise value
     return [value for _, value in results]
+
+
+def shutdown():
+    '''Ends the worker threads of the sharded calls and frees what they hold -- per (list position,
+    device) a library context with up to ~4.7 GB of staging slabs in HBM and its page-locked
+    buffers, which otherwise live as long as the process. Waits for a sharded call
+    in flight; the next ``devices=[...]`` call starts new workers.'''
+    with _call_lock:
+        with _workers_lock:
+            workers = list(_workers.values())
+            _workers.clear()
+        waits = []
+        for w in workers:
+            done = threading.Event()
+            w.jobs.put((None, None, done))
+            waits.append((w, done))
+        for w, done in waits:
+            done.wait()
+            w.join(timeout=10)
+    return len(workers)
 
 
 def fold_diag(parts):

@@ -93,6 +93,15 @@ def test_run_keeps_list_order_and_raises_the_first_failure(monkeypatch):
     with pytest.raises(IndexError, match='class code'):
         multi.run([3, 3, 5], fn)
     assert done == [0]
+    # shutdown(): the workers end (their contexts go with them) and the next call starts new ones
+    old = [t for t in threading.enumerate() if t.name.startswith('mod16-dev')]
+    assert {t.ident for t in old} == set(again) and multi.shutdown() == 3
+    assert not any(t.is_alive() for t in old)
+    assert not [t for t in threading.enumerate() if t.name.startswith('mod16-dev')]
+    assert len(set(multi.run([3, 3, 5], lambda i, ctx: ctx[2]))) == 3
+    new = [t for t in threading.enumerate() if t.name.startswith('mod16-dev')]
+    assert len(new) == 3 and not any(t in old for t in new)
+    assert multi.shutdown() == 3 and multi.shutdown() == 0
 
 
 def test_entry_points_fail_loudly_without_a_gpu():
