@@ -335,6 +335,10 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
         s.wide_row = s.out_row = s.byte_row = 0;
     }
     const StreamGeom g = stream_geom(ctx, s.n, V, s.tile_shift);
+    // (the pipeline kernel's piece numbers and tile rows are 32-bit scalars: 2^30 pieces are 137 G
+    // float64 pixels -- a raster of 1.7 TB -- and a row is 15 tiles' worth of elements)
+    if (g.npiece > kMaxPieces || (uint64_t)s.wide_row >> 32 || (uint64_t)s.out_row >> 32 || (uint64_t)s.byte_row >> 32)
+        return fail(ctx, MOD16_ERR_ARG, "pipeline launch: more than 2^30 pieces, or a tile row of 2^32 elements or more");
     unsigned long long* ctr = ctx->force_counter ? ctx->force_counter
                                                  : ctx->dyn_counters + 16 * (ctx->dyn_next++ % 64);
     // the ticket counter of the dynamic schedule (a statically scheduled raster never reads it):
@@ -380,6 +384,8 @@ static int launch_stream(mod16_ctx* ctx, StreamArgs<T> s, hipStream_t st, double
     for (int k = 2; k < NW && pitched; ++k)
         pitched = reinterpret_cast<const char*>(s.wide[k]) - reinterpret_cast<const char*>(s.wide[0]) == k * pitch_b;
     s.wide_pitch = pitched ? pitch_b / (ptrdiff_t)sizeof(T) : 0;
+    s.dma_step[0] = (int64_t)pitch_b - 1024;
+    s.dma_step[1] = (int64_t)pitch_b + 3072;
     if (pitched) hipLaunchKernelGGL((et_stream_kernel<T, MODE, true, GUARD>), dim3(grid), dim3(kBlock), 0, st, s);
     else hipLaunchKernelGGL((et_stream_kernel<T, MODE, false, GUARD>), dim3(grid), dim3(kBlock), 0, st, s);
     // pixels outside the domain of the production arithmetic (mod16_physics.hpp, "domain

@@ -82,6 +82,15 @@ template <> struct StreamSpec<kStreamRaw> { static constexpr int NW = 14, NB = 3
 template <> struct StreamSpec<kStreamRawTotal> { static constexpr int NW = 14, NB = 3, NOUT = 3; };
 template <> struct StreamSpec<kStreamRawTotalHours> { static constexpr int NW = 15, NB = 3, NOUT = 3; };
 
+// f(integral_constant<int, K>) for K = A ... B - 1: a loop whose index is a constant expression
+// (the immediate operands of the LDS-DMA builtin)
+template <int A, int B, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (A < B) {
+        f(std::integral_constant<int, A>{});
+        static_for<A + 1, B>(f);
+    }
+}
+
 template <typename T> struct StreamArgs {
     const T* wide[16];         // offset 0 of the kernel-argument segment (re-read in the loop)
     const uint8_t* bytes[4];   // offset 128: class raster, then fpar_pct, lai_x10
@@ -94,6 +103,7 @@ template <typename T> struct StreamArgs {
     unsigned long long* dyn_counter;   // ticket counter of the dynamic schedule; word [2] (unsigned) behind it: blocks finished
     double hours;              // kStreamRawTotal: the (scalar) hours of daylight
     int64_t wide_pitch;        // PITCHED: wide[k] = wide[0] + k * wide_pitch (elements)
+    int64_t dma_step[2];       // PITCHED: wide_pitch in bytes - 1024, + 3072 (et_stream_kernel's issue())
     int run_shift;             // a run is 2^run_shift pieces (kDynRun for large rasters, less for
                                // small ones so that every wave of the chip gets work)
     // Tiled rasters (2-level layout): pixel i of an array lives at
@@ -116,7 +126,8 @@ template <typename T> struct StreamArgs {
     // (piece, pixel, lane); the count travels in the run's partial (kCancelShift)
     uint16_t* cancel_list;
 };
-constexpr int kNoTile = 40;    // more pieces per "tile" than any raster has: one tile, plain arrays
+constexpr int kNoTile = 31;    // more pieces per "tile" than any raster has: one tile, plain arrays
+constexpr int64_t kMaxPieces = int64_t(1) << 30;   // piece numbers are 32-bit in et_stream_kernel
 static_assert(__builtin_offsetof(StreamArgs<double>, wide) == 0 &&
               __builtin_offsetof(StreamArgs<double>, bytes) == 128 &&
               __builtin_offsetof(StreamArgs<float>, wide) == 0 &&
@@ -384,38 +395,47 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char* const ws = stage + wave * kSlot;
+    // Piece numbers are 32-bit (round 6; the launch refuses a raster of more than kMaxPieces): the
+    // loop's scalar bookkeeping -- run state, the claim, three tile offsets -- is single adds, shifts
+    // and 32 x 32 -> 64 multiplications instead of register pairs with carries (a scalar instruction
+    // costs ~0.7 of a vector one at two waves per SIMD, and the loop held ~190 of them).
     const int64_t nvec_s = a.n / V;
-    const int64_t npiece = (nvec_s + 63) / 64;
-    // (the loop compares it with a per-lane index twice per iteration: in a vector register
-    // pair it is an operand; as a scalar pair hipcc spills it and reads it back lane by lane)
-    int64_t nvec = nvec_s;
-    asm("" : "+v"(nvec));
-    const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+    const int npiece = (int)((nvec_s + 63) >> 6);
+    const int nfull = (int)(nvec_s >> 6);          // pieces whose 64 vectors all exist
+    const int nrem = (int)(nvec_s & 63);           // vectors of the ragged piece behind them (0: none)
+    const int nwaves = (int)gridDim.x * (kBlock / 64);
     const int rs = a.run_shift, rl = 1 << rs;
-    int64_t cbase = ((int64_t)blockIdx.x * (kBlock / 64) + wave) << rs;
-    int64_t next_base = npiece;
+    int cbase = (int)((blockIdx.x * (kBlock / 64) + wave) << rs);
+    // the run behind the current one. Static schedule (small rasters): the wave's next run, a fixed
+    // stride on; dynamic: whatever the claim made in a run's first iteration returns, read in its
+    // second (`claim_run`: the one test of the loop's head)
+    const int sstride = a.static_sched ? nwaves << rs : 0;
+    const int claim_run = a.static_sched ? -1 : 1;
+    int next_base = a.static_sched ? cbase + sstride : npiece;
     unsigned long long ticket = 0;
     int run = 0;
-    auto vec_of = [&](int64_t cb, int r) { return (cb + r) * 64 + lane; };
-    // element offsets of the piece (cb, r) in the wide arrays, the outputs and the byte
-    // arrays (wave-uniform, forced into SGPRs)
+    // lanes of piece p that hold a vector of the raster: 64, the ragged piece's, or none (wave-uniform)
+    auto lanes_of = [&](int p) { return p < nfull ? 64 : p == nfull ? nrem : 0; };
+    // element offsets of piece p in the wide arrays, the outputs and the byte arrays (wave-uniform,
+    // in SGPRs). Rows between tiles fit 32 bits (launch_stream checks); plain arrays are ONE tile
+    // (tile_shift = kNoTile = 31: tile 0), whose offset within is the one 64-bit quantity.
     struct Offs { int64_t w, o, b; };
-    auto uniform64 = [](int64_t x) {
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x);
-        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)x >> 32));
-        return (int64_t)(((unsigned long long)hi << 32) | lo);
-    };
-    auto offs_of = [&](int64_t cb, int r) {
-        const int64_t piece = uniform64(cb + r);
-        const int64_t tile = piece >> a.tile_shift;
-        const int64_t q = (piece - (tile << a.tile_shift)) * (int64_t)(64 * V);
-        return Offs{tile * a.wide_row + q, tile * a.out_row + q, tile * a.byte_row + q};
+    constexpr int kLogPiece = V == 2 ? 7 : V == 4 ? 8 : 6;       // log2 of the elements of a piece
+    static_assert((64 * V) == (1 << kLogPiece), "elements per piece");
+    auto offs_of = [&](int p) {
+        const unsigned piece = (unsigned)__builtin_amdgcn_readfirstlane(p);
+        const unsigned tile = piece >> a.tile_shift;
+        const uint64_t q = (uint64_t)(piece - (tile << a.tile_shift)) << kLogPiece;
+        return Offs{(int64_t)((uint64_t)tile * (uint64_t)(unsigned)a.wide_row + q),
+                    (int64_t)((uint64_t)tile * (uint64_t)(unsigned)a.out_row + q),
+                    (int64_t)((uint64_t)tile * (uint64_t)(unsigned)a.byte_row + q)};
     };
     const unsigned lane_elem = (unsigned)lane * (unsigned)V;
-    auto advance = [&](int64_t& cb, int& r) {
-        if (((++r) >> rs) != 0) { r = 0; cb = next_base; }
+    auto advance = [&](int& cb, int& r) {
+        if (((++r) >> rs) != 0) { r = 0; cb = next_base; next_base += sstride; }
     };
-    int64_t v = vec_of(cbase, run);
+    int lanes = lanes_of(cbase + run);             // of the piece this iteration computes
+    int64_t out_first = 0;                         // its offset in the outputs (found when its DMA was issued)
     double dsum_d = 0, dsum_n = 0, dmax_d = -__builtin_huge_val(), dmax_n = -__builtin_huge_val();
     float fmax_d = -__builtin_huge_valf(), fmax_n = -__builtin_huge_valf();   // mixed forms: maxima of float32 values
     unsigned nan_d = 0, nan_n = 0;
@@ -484,9 +504,13 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         asm volatile("" : "+s"(ka));
         if constexpr (PITCHED) {
             p.w[0] = *reinterpret_cast<const char* const __attribute__((address_space(4)))*>(ka);
+            // (the two steps between successive DMA bases, see issue())
             p.w[1] = reinterpret_cast<const char*>(
                 *reinterpret_cast<const int64_t __attribute__((address_space(4)))*>(
-                    ka + __builtin_offsetof(StreamArgs<T>, wide_pitch)) * (int64_t)sizeof(T));
+                    ka + __builtin_offsetof(StreamArgs<T>, dma_step)));
+            p.w[2] = reinterpret_cast<const char*>(
+                *reinterpret_cast<const int64_t __attribute__((address_space(4)))*>(
+                    ka + __builtin_offsetof(StreamArgs<T>, dma_step) + 8));
         } else {
 #pragma unroll
             for (int k = 0; k < NW; ++k)
@@ -503,22 +527,28 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         asm volatile("" : "+s"(wl));
         const int64_t first_b = of.w * (int64_t)sizeof(T);
         const int64_t first = of.b;
+        // The instruction's immediate offset (< 4096) is added to BOTH addresses of an LDS-DMA load:
+        // four successive LDS slots (1 KiB each) are reached from ONE value of M0 by the offsets 0,
+        // 1024, 2048, 3072, with the global base moved back by the same amount -- M0 is written
+        // (and its hazard slot spent) 4 times per piece instead of 14 (round 6).
         if constexpr (PITCHED) {
-            // (base and pitch: read again in this iteration, load_ptrs -- which also keeps
-            // the 14 addresses from being hoisted)
-            const int64_t pitch_b = (int64_t)(uintptr_t)p.w[1];
+            // (base and steps: read again in this iteration, load_ptrs -- which also keeps
+            // the 14 addresses from being hoisted). Base k+1 = base k + pitch - 1024 inside a
+            // group of four slots, + pitch + 3072 into the next group: the host precomputes both.
+            const int64_t step_in = (int64_t)(uintptr_t)p.w[1], step_over = (int64_t)(uintptr_t)p.w[2];
             const char* pk = p.w[0] + first_b;
-#pragma unroll
-            for (int k = 0; k < NW; ++k) {
-                __builtin_amdgcn_global_load_lds((gptr_t)(pk + lb), (lptr_t)(uintptr_t)(wl + k * 1024),
-                                                 16, 0, kDmaNt);
-                pk += pitch_b;
-            }
+            static_for<0, NW>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                __builtin_amdgcn_global_load_lds((gptr_t)(pk + lb), (lptr_t)(uintptr_t)(wl + (k & ~3) * 1024),
+                                                 16, (k & 3) * 1024, kDmaNt);
+                pk += (k & 3) == 3 ? step_over : step_in;
+            });
         } else {
-#pragma unroll
-            for (int k = 0; k < NW; ++k)
-                __builtin_amdgcn_global_load_lds((gptr_t)((p.w[k] + first_b) + lb),
-                                                 (lptr_t)(uintptr_t)(wl + k * 1024), 16, 0, kDmaNt);
+            static_for<0, NW>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                __builtin_amdgcn_global_load_lds((gptr_t)((p.w[k] + (first_b - (k & 3) * 1024)) + lb),
+                                                 (lptr_t)(uintptr_t)(wl + (k & ~3) * 1024), 16, (k & 3) * 1024, kDmaNt);
+            });
         }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
@@ -533,7 +563,9 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     {
         Ptrs p;
         load_ptrs(p);
-        if (v < nvec) issue(offs_of(cbase, run), p);
+        const Offs of = offs_of(cbase + run);
+        out_first = of.o;
+        if (lane < lanes) issue(of, p);
     }
     for (int i = threadIdx.x; i < MOD16_LUT_ROWS * kLutCols; i += kBlock) {
         const double x = a.lut64[i];
@@ -548,7 +580,6 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const GuardConsts gc = RAW ? raw_guard_consts() : guard_consts();      // (three register pairs held through the loop)
-    bool flushed = false;
 #pragma nounroll
     for (; cbase + run < npiece; ) {
         Ptrs ptrs;
@@ -559,11 +590,10 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         // everything but the NOUT stores of the previous iteration (and its
         // diagnostics flush, if any) must be complete: this iteration's DMA and,
         // one iteration after a claim, the claim's atomic
-        if (flushed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOUT + 1) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOUT) : "memory");
-        if (a.static_sched) {
-            if (run == 0) next_base = cbase + (nwaves << rs);
-        } else if (run == 1) {
+        // (behind a flush the partial's store is one more: once per run the wait then covers the
+        // oldest output store as well -- cheaper than a two-way branch in every iteration)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOUT) : "memory");
+        if (run == claim_run) {
             asm volatile("" : "+v"(ticket));
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ticket);
             const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ticket >> 32));
@@ -572,9 +602,10 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
             // overflow into a base the loop guard accepts (round 5's injected 0x3f3f... did: a wild
             // DMA read and a wild store). A stale ticket INSIDE the raster only skips runs, which the
             // markers report (kStatusIncomplete). Scalar, once per run: not in the per-piece path.
-            unsigned long long tk = ((unsigned long long)hi << 32) | lo;
-            tk = tk > (unsigned long long)npiece ? (unsigned long long)npiece : tk;
-            next_base = (nwaves + (int64_t)tk) << rs;
+            // (the bound is in RUNS, one past the raster's: base >= npiece, and no shift can overflow)
+            const unsigned past = ((unsigned)npiece >> rs) + 1u;
+            const unsigned tk = (hi != 0u || lo > past) ? past : lo;
+            next_base = (int)(((unsigned)nwaves + tk) << rs);
         }
         typedef typename Vec<T, V>::type VT;
         VT in[NW];
@@ -586,17 +617,18 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
             asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0"
                          : "=v"(ticket) : "v"(a.dyn_counter), "v"(one) : "memory");
         }
-        int64_t cb_n = cbase;
+        int cb_n = cbase;
         int run_n = run;
         advance(cb_n, run_n);
-        const int64_t vn = vec_of(cb_n, run_n);
-        if (vn < nvec) issue(offs_of(cb_n, run_n), ptrs);
+        const int lanes_n = lanes_of(cb_n + run_n);
+        const Offs of_n = offs_of(cb_n + run_n);
+        if (lane < lanes_n) issue(of_n, ptrs);
         asm volatile("" ::: "memory");
 #ifdef MOD16_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
 
-        if (v < nvec) {   // only the last piece is ragged
+        if (lane < lanes) {   // only the last piece is ragged
             VT res[NOUT];
             // `bad`: one of this thread's pixels lies outside the domain of the production arithmetic
             // (mod16_physics.hpp, "domain guard"). Such a pixel gets a NaN fPAR, which makes both
@@ -674,7 +706,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                                 asm volatile("" : "+s"(ka));
                                 uint16_t* list = *reinterpret_cast<uint16_t* const __attribute__((address_space(4)))*>(
                                                      ka + __builtin_offsetof(StreamArgs<T>, cancel_list)) +
-                                                 ((cbase >> rs) * kCancelCap + cancel_cnt);
+                                                 ((int64_t)(cbase >> rs) * kCancelCap + cancel_cnt);
                                 const unsigned r0 = __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0u));
                                 const unsigned r1 = __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0u));
                                 const unsigned ent = (unsigned)((run << 8) | (lane << 2) | jj);
@@ -827,10 +859,13 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                 // float32 raster, float64 arithmetic, raw drivers: four pixels per thread interleaved
                 // need more than 256 registers (one wave per SIMD, or spills inside the counted-vmcnt
                 // loop); one pixel after the other they fit
-                if constexpr (V == 4 && RAW) __builtin_amdgcn_sched_barrier(0);
+                // (round 6, second session: with the loop's scalar bookkeeping in 32 bits the potential-ET and
+                // component instances were scheduled into 258 - 260 as well: every float32-raster instance
+                // of the float64 arithmetic but the totals one, which stays below 240 on its own)
+                if constexpr (V == 4 && MODE != kStreamTotals) __builtin_amdgcn_sched_barrier(0);
             }
             }
-            const int64_t first = offs_of(cbase, run).o;
+            const int64_t first = out_first;
 #pragma unroll
             for (int k = 0; k < NOUT; ++k)
                 __builtin_nontemporal_store(res[k], reinterpret_cast<VT*>((a.out[k] + first) + lane_elem));
@@ -848,17 +883,18 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         // diagnostics partial: one per run (dynamic schedule: which wave computes a run is not
         // fixed, the run's pixels are) or one per wave (static schedule: the wave's runs are;
         // stored behind the loop, once the wave has revisited its flagged pieces)
-        flushed = !a.static_sched && (cb_n + run_n >= npiece || run_n == 0);
+        const bool flushed = !a.static_sched && (cb_n + run_n >= npiece || run_n == 0);
         if (flushed) {
             const double f = diag_fields();
             // (agent scope = written through to memory: the block that adds the partials up
             // may sit behind another L2)
             if (lane < kDiag)
-                __hip_atomic_store(a.diag_partial + (cbase >> rs) * kDiag + lane, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.diag_partial + (int64_t)(cbase >> rs) * kDiag + lane, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         cbase = cb_n;
         run = run_n;
-        v = vn;
+        lanes = lanes_n;
+        out_first = of_n.o;
     }
     // What runs behind the loop reads the kernel arguments again (through a pointer the compiler
     // cannot see through): the pointers redo_piece needs would otherwise be live -- in scalar
@@ -902,7 +938,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
     // ((w + (i >> rs) nwaves) << rs) + (i & (rl - 1)); the last flag bit stands for every
     // iteration from there on.
     if (late.static_sched) {
-        const int64_t first_cbase = ((int64_t)blockIdx.x * (kBlock / 64) + wave) << rs;
+        const int first_cbase = (int)((blockIdx.x * (kBlock / 64) + wave) << rs);
         // ONE partial per BLOCK: the block's four waves add theirs up in LDS (fixed order:
         // wave 0 + wave 1 + ...), so the block that sums the partials of the whole launch
         // afterwards reads a quarter of them -- one round trip to memory instead of two on
@@ -910,7 +946,8 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         __shared__ double wave_part[kBlock / 64][kDiag];
         double f = lane < 6 ? 0.0 : -__builtin_huge_val();        // a wave without work adds nothing
         if (first_cbase < npiece) {
-            const unsigned long long mine = (unsigned long long)uniform64((int64_t)flags);     // (diag_fields() stores and clears them)
+            const unsigned long long mine =      // (diag_fields() stores and clears them)
+                ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(flags >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)flags);
             f = diag_fields();
             if constexpr (GUARD) if (__builtin_expect(mine != 0ull, 0)) {
                 RedoAcc acc;

@@ -161,9 +161,18 @@ static void shadow_stream(const StreamArgs<T>& a, int mode, bool pitched, dim3 g
         need(a.diag_out, sizeof(double) * kDiag, 8, "diagnostics vector", name);
         need(a.done_counter, 4, 4, "blocks-done counter", name);
     }
-    if (pitched)
+    if (pitched) {
         for (int k = 1; k < NW; ++k)
             if (a.wide[k] != a.wide[0] + k * a.wide_pitch) die("%s: wide[%d] is not wide[0] + %d * pitch", name, k, k);
+        // the two steps between successive DMA bases (four LDS slots per value of M0, et_stream_kernel's issue())
+        const int64_t pitch_b = a.wide_pitch * (int64_t)sizeof(T);
+        if (a.dma_step[0] != pitch_b - 1024 || a.dma_step[1] != pitch_b + 3072)
+            die("%s: DMA steps %lld / %lld for a pitch of %lld bytes", name, (long long)a.dma_step[0], (long long)a.dma_step[1], (long long)pitch_b);
+    }
+    // 32-bit piece numbers and tile rows in the kernel
+    if (npiece > kMaxPieces || (uint64_t)a.wide_row >> 32 || (uint64_t)a.out_row >> 32 || (uint64_t)a.byte_row >> 32)
+        die("%s: %lld pieces / rows %lld %lld %lld do not fit the kernel's 32-bit scalars", name, (long long)npiece,
+            (long long)a.wide_row, (long long)a.out_row, (long long)a.byte_row);
     const bool tiled = a.tile_shift != kNoTile;
     // plain arrays: one check per array; tiled: per tile (pieces of a tile are contiguous)
     const int64_t per_tile = tiled ? (int64_t(1) << a.tile_shift) : npiece;
