@@ -362,7 +362,7 @@ __device__ __forceinline__ void et_pair_mixed_parts(const float (&in)[14][2], co
         __builtin_elementwise_min(__builtin_elementwise_abs(agd - lim_d), __builtin_elementwise_abs(agn - lim_n)),
         __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_abs(dd), __builtin_elementwise_abs(a_d)),
                                   __builtin_elementwise_abs(dn)));
-    if (__any((dist.x <= tol.x) | (dist.y <= tol.y))) {
+    if (__builtin_expect(__any((dist.x <= tol.x) | (dist.y <= tol.y)), 0)) {     // (out of line: the hot path falls through)
         float r[4][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {

@@ -593,7 +593,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         // (behind a flush the partial's store is one more: once per run the wait then covers the
         // oldest output store as well -- cheaper than a two-way branch in every iteration)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOUT) : "memory");
-        if (run == claim_run) {
+        if (__builtin_expect(run == claim_run, 0)) {
             asm volatile("" : "+v"(ticket));
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ticket);
             const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ticket >> 32));
@@ -612,7 +612,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         unsigned bits[NB];
         SlotRead<NW, NB>::go(in, bits, (unsigned)(uintptr_t)(lptr_t)ws + lane * 16u,
                              (unsigned)(uintptr_t)(lptr_t)ws + NW * 1024u + lane * 4u);
-        if (run == 0 && lane == 0 && !a.static_sched) {
+        if (__builtin_expect(run == 0 && lane == 0 && !a.static_sched, 0)) {
             const unsigned long long one = 1;
             asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0"
                          : "=v"(ticket) : "v"(a.dyn_counter), "v"(one) : "memory");
@@ -651,7 +651,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                     cls_bad = cls_bad | (c >= 13u);
                     cls_of[j] = c >= 13u ? 13u : c;
                 }
-                if (cls_bad) atomicOr(a.status, kStatusClassRange);
+                if (__builtin_expect(cls_bad, 0)) atomicOr(a.status, kStatusClassRange);
 #pragma unroll
                 for (int jj = 0; jj < V; jj += 2) {   // pairs of pixels: packed float32 arithmetic
                     float pin[14][2];
@@ -766,7 +766,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
                 cls_bad = cls_bad | (c >= 13u);
                 cls_of[j] = c >= 13u ? 13u : c;
             }
-            if (cls_bad) atomicOr(a.status, kStatusClassRange);
+            if (__builtin_expect(cls_bad, 0)) atomicOr(a.status, kStatusClassRange);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 PixelIn<double> x;
@@ -884,7 +884,7 @@ __global__ void MOD16_STREAM_BOUNDS et_stream_kernel(const StreamArgs<T> a) {
         // fixed, the run's pixels are) or one per wave (static schedule: the wave's runs are;
         // stored behind the loop, once the wave has revisited its flagged pieces)
         const bool flushed = !a.static_sched && (cb_n + run_n >= npiece || run_n == 0);
-        if (flushed) {
+        if (__builtin_expect(flushed, 0)) {
             const double f = diag_fields();
             // (agent scope = written through to memory: the block that adds the partials up
             // may sit behind another L2)
