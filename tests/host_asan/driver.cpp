@@ -133,6 +133,11 @@ static void tiled_cases(mod16_ctx* ctx, const char* what) {
         l = r.lay; l.driver_row = tile - V; EXPECT(bad(l, r.bytes[0], r.wide.data(), r.n, r.outs[0]) == MOD16_ERR_ARG);
         l = r.lay; l.out_row += 1; EXPECT(bad(l, r.bytes[0], r.wide.data(), r.n, r.outs[0]) == MOD16_ERR_ARG);
         l = r.lay; l.cls_row = 0; EXPECT(bad(l, r.bytes[0], r.wide.data(), r.n, r.outs[0]) == MOD16_ERR_ARG);
+        // what the pipeline kernel's 32-bit scalars cannot hold (round 6): more than 2^30 pieces of 64 vectors,
+        // a row between tiles of 2^32 elements -- refused before anything is launched
+        EXPECT(bad(r.lay, r.bytes[0], r.wide.data(), (((int64_t)1 << 30) + 1) * 64 * V, r.outs[0]) == MOD16_ERR_ARG);
+        l = r.lay; l.driver_row = (int64_t)1 << 32; EXPECT(bad(l, r.bytes[0], r.wide.data(), r.n, r.outs[0]) == MOD16_ERR_ARG);
+        l = r.lay; l.out_row = (int64_t)1 << 32; EXPECT(bad(l, r.bytes[0], r.wide.data(), r.n, r.outs[0]) == MOD16_ERR_ARG);
         EXPECT(bad(r.lay, r.bytes[0] + 1, r.wide.data(), r.n, r.outs[0]) == MOD16_ERR_ARG);
         EXPECT(bad(r.lay, r.bytes[0], r.wide.data(), r.n - 1, r.outs[0]) == MOD16_ERR_ARG);
         EXPECT(bad(r.lay, r.bytes[0], r.wide.data(), r.n, r.outs[0] + 1) == MOD16_ERR_ARG);
