@@ -361,6 +361,11 @@ MOD16_API int mod16_et_diag_f32(mod16_ctx* ctx, const uint8_t* cls,
  * DEVICE pointers and must stay valid and in place; the raster's contents may
  * change between launches. Replays of one graph must be ordered (one stream, or
  * events); deferred errors surface through mod16_check_status as usual.
+ * A graph belongs to the context it was captured with -- its kernels read the
+ * context's parameter and exp / log tables and report into its status word:
+ * destroy the graph first. Once the context is gone, mod16_graph_launch and
+ * mod16_time_graph return MOD16_ERR_ARG (nothing is launched);
+ * mod16_graph_destroy still frees the graph, in either order.
  */
 typedef struct mod16_graph mod16_graph;
 MOD16_API int mod16_graph_et_diag_f64(mod16_ctx* ctx, const uint8_t* cls,
@@ -604,6 +609,10 @@ MOD16_API int mod16_time_et(mod16_ctx* ctx, int is_f32, const uint8_t* cls,
  * MOD16_MATH_FAST or, float32, MOD16_MATH_MIXED); mod16_graph_et_tiled_* captures
  * it for replay with mod16_graph_launch. Host arrays reach the layout with 2-D
  * copies (hipMemcpy2DAsync, width = tile, destination pitch = row).
+ * Limits of one pipeline launch (any layout; MOD16_ERR_ARG beyond them): 2^30
+ * pieces of 64 vectors -- 1.4e11 float64 or 2.7e11 float32 pixels, three orders of
+ * magnitude above what 288 GB hold -- and rows below 2^32 elements: the kernel
+ * keeps its piece numbers and tile offsets in single 32-bit scalar registers.
  */
 typedef struct mod16_layout {
     int64_t tile;        /* pixels per tile */

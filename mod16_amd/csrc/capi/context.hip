@@ -38,6 +38,11 @@ extern "C" int mod16_device_count(int* count) {
 
 extern "C" int mod16_destroy(mod16_ctx* ctx) {
     if (!ctx) return MOD16_OK;
+    {   // graphs captured with this context can be destroyed, but not replayed any more
+        std::lock_guard<std::mutex> lock(graph_registry_mu());
+        for (mod16_graph* g : ctx->graphs) g->ctx = nullptr;
+        ctx->graphs.clear();
+    }
     (void)hipSetDevice(ctx->device);
     for (int s = 0; s < kSlots; ++s) {
         if (ctx->slab[s]) (void)hipFree(ctx->slab[s]);

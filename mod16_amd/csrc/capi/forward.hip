@@ -136,6 +136,13 @@ extern "C" int mod16_et_diag_f32(mod16_ctx* ctx, const uint8_t* cls, const float
 
 extern "C" int mod16_graph_destroy(mod16_graph* g) {
     if (!g) return MOD16_OK;
+    {
+        std::lock_guard<std::mutex> lock(graph_registry_mu());
+        if (g->ctx) {
+            std::vector<mod16_graph*>& v = g->ctx->graphs;
+            v.erase(std::remove(v.begin(), v.end(), g), v.end());
+        }
+    }
     (void)hipSetDevice(g->device);           // the context may be gone already (interpreter exit)
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
@@ -184,6 +191,7 @@ static int graph_entry(mod16_ctx* ctx, const uint8_t* cls, const T* const* drive
         mod16_graph_destroy(g);
         return rc;
     }
+    graph_register(ctx, g);
     *out = g;
     return MOD16_OK;
 }
@@ -204,7 +212,12 @@ extern "C" int mod16_graph_et_diag_f32(mod16_ctx* ctx, const uint8_t* cls, const
 }
 extern "C" int mod16_graph_launch(mod16_graph* g, void* stream) {
     if (!g || !g->exec) return MOD16_ERR_ARG;
-    // (a graph may outlive the context it was built with: no error text through g->ctx)
+    // (a graph may outlive the context it was built with -- to be destroyed, not replayed: its
+    // kernels point into the context's tables. No error text through g->ctx either way)
+    if (!graph_alive(g)) {
+        fprintf(stderr, "mod16_graph_launch: the context this graph was captured with has been destroyed\n");
+        return MOD16_ERR_ARG;
+    }
     const hipError_t e = hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) {
         fprintf(stderr, "mod16_graph_launch: %s\n", hipGetErrorString(e));

@@ -51,6 +51,15 @@ static hipError_t ws_alloc(DiagWs& ws, int64_t blocks) {
     return hipMemset(ws.done(), 0, 128);
 }
 
+// A captured graph's kernel nodes point into its context (parameter table, exp / log tables, status
+// word): the context keeps a list of its live graphs, and mod16_destroy marks them dead -- a replay
+// of one returns MOD16_ERR_ARG instead of reading freed memory; mod16_graph_destroy still frees it.
+// One process-wide lock (an inline function: the same object in every translation unit of the library).
+inline std::mutex& graph_registry_mu() {
+    static std::mutex mu;
+    return mu;
+}
+
 struct mod16_ctx {
     std::recursive_mutex api_mu;     // every entry point holds it: a ctx may be shared by threads
     int device = 0;
@@ -77,6 +86,7 @@ struct mod16_ctx {
     unsigned* static_flag = nullptr; // device word of mod16_et_static_*
     DiagWs ws;                       // diagnostics partials of launches outside a graph
     std::vector<void*> retired;      // outgrown workspaces (freed with the context)
+    std::vector<mod16_graph*> graphs; // graphs captured with this context and still alive (graph_registry_mu)
     DiagWs* force_ws = nullptr;      // workspace to use instead (graph capture)
     hipEvent_t ws_event = nullptr;   // recorded behind the last launch that produced diagnostics in `ws`
     hipStream_t ws_stream = nullptr; // ... and the stream it ran on
@@ -914,13 +924,22 @@ static int run_host(mod16_ctx* ctx, const EtArgs<T>& h, unsigned flags, double* 
 // sequence of mod16_et_diag_* (counter reset, pipeline kernel, staged fixed-order
 // sum) captured once and replayed with one call per time step.
 struct mod16_graph {
-    mod16_ctx* ctx = nullptr;                // for error text at launch; not touched by destroy
+    mod16_ctx* ctx = nullptr;                // NULL once the context has been destroyed (graph_registry_mu)
     int device = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     unsigned long long* counter = nullptr;   // its own ticket counter: replays never meet the ring
     DiagWs ws;                               // its own diagnostics workspace (freed with the graph)
 };
+static void graph_register(mod16_ctx* ctx, mod16_graph* g) {
+    std::lock_guard<std::mutex> lock(graph_registry_mu());
+    ctx->graphs.push_back(g);
+}
+// false: the context the graph was captured with is gone (its tables with it)
+static bool graph_alive(const mod16_graph* g) {
+    std::lock_guard<std::mutex> lock(graph_registry_mu());
+    return g->ctx != nullptr;
+}
 
 
 // ------------------------------------------------------------- diagnostics

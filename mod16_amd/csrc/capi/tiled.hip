@@ -209,6 +209,7 @@ static int graph_tiled_entry(mod16_ctx* ctx, const mod16_layout* lay, const uint
         mod16_graph_destroy(g);
         return rc;
     }
+    graph_register(ctx, g);
     *out = g;
     return MOD16_OK;
 }
@@ -258,7 +259,7 @@ extern "C" int mod16_time_et_tiled(mod16_ctx* ctx, int is_f32, const mod16_layou
 
 // mean milliseconds per replay of a captured step, HIP events on `stream`
 extern "C" int mod16_time_graph(mod16_graph* g, int launches, void* stream, float* ms) {
-    if (!g || !g->exec || !ms || launches <= 0) return MOD16_ERR_ARG;
+    if (!g || !g->exec || !ms || launches <= 0 || !graph_alive(g)) return MOD16_ERR_ARG;
     if (hipSetDevice(g->device) != hipSuccess) return MOD16_ERR_HIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;

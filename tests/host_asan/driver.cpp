@@ -310,6 +310,27 @@ int main(int argc, char** argv) {
     plain_device_cases<float>(ctx, "float32");
     host_cases<double>(ctx, "float64");
     host_cases<float>(ctx, "float32");
+    {   // a graph and its context, destroyed in either order: once the context is gone a replay is
+        // refused (its kernels would read the freed tables), the graph itself can still be freed
+        mod16_ctx* c2 = nullptr;
+        EXPECT(mod16_create(0, &c2) == MOD16_OK && c2);
+        OK(mod16_set_bplut_f64(c2, lut));
+        const int64_t tile = 4096;
+        Raster<double> r(3 * tile, tile, 14, 1, 2);
+        double* dd = static_cast<double*>(dmalloc(64));
+        mod16_graph *g1 = nullptr, *g2 = nullptr;
+        EXPECT(mod16_graph_et_tiled_f64(c2, &r.lay, r.bytes[0], r.wide.data(), r.n, r.outs[0], r.outs[1], MOD16_MATH_FAST, dd, &g1) == MOD16_OK);
+        EXPECT(mod16_graph_et_tiled_f64(c2, &r.lay, r.bytes[0], r.wide.data(), r.n, r.outs[0], r.outs[1], MOD16_MATH_FAST, dd, &g2) == MOD16_OK);
+        EXPECT(mod16_graph_launch(g1, nullptr) == MOD16_OK);
+        EXPECT(mod16_graph_destroy(g1) == MOD16_OK);          // graph first: leaves the context's list
+        EXPECT(mod16_destroy(c2) == MOD16_OK);                // context first: g2 is dead ...
+        float ms = 0;
+        EXPECT(mod16_graph_launch(g2, nullptr) == MOD16_ERR_ARG);
+        EXPECT(mod16_time_graph(g2, 1, nullptr, &ms) == MOD16_ERR_ARG);
+        EXPECT(mod16_graph_destroy(g2) == MOD16_OK);          // ... and still freed
+        (void)hipFree(dd);
+        printf("host_asan: graph lifetime: done\n");
+    }
     {   // the stand-alone reduction, the rank-order fold, the copy probe
         const int64_t n = 1200 * 1200 + 1;
         double* day = static_cast<double*>(dmalloc(8 * n));

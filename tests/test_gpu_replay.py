@@ -142,3 +142,41 @@ def test_no_ticket_value_sends_the_kernel_outside_its_raster(env, byte, monkeypa
     eng.check()
     assert torch.equal(diag, ref)
     assert torch.equal(torch.nan_to_num(ras.flat(ras.day), nan=-7.0), torch.nan_to_num(day_ref, nan=-7.0))
+
+
+def test_a_graph_whose_context_is_gone_is_refused_not_replayed(env):
+    """a captured graph's kernels read the context's tables and write its status
+    word. mod16_destroy marks the context's live graphs dead: a replay returns MOD16_ERR_ARG (nothing
+    is launched -- the raster keeps the last good step), mod16_graph_destroy still frees the graph;
+    a graph destroyed before its context leaves the context's list."""
+    torch, RasterEngine, table = env
+    from mod16_amd import _lib
+    eng = RasterEngine(table)
+    n = 1 << 22
+    ras = eng.alloc_tiled(n)
+    eng.synth_tiled(ras, seed=7)
+    diag = torch.zeros(8, dtype=torch.float64, device='cuda')
+    first, second = eng.bind_tiled(ras, diag), eng.bind_tiled(ras, diag)
+    first()
+    torch.cuda.synchronize()
+    eng.ctx.check(0)
+    want = ras.flat(ras.day, 0, 1 << 16).clone()
+    import ctypes
+    stream = ctypes.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)
+    lib = eng.ctx.lib
+    assert lib.mod16_graph_destroy(first._graph.handle) == _lib.OK          # graph first
+    first._graph.handle = None
+    eng.ctx.close()                                           # then the context, under a live graph
+    ras.day.zero_()
+    torch.cuda.synchronize()
+    assert lib.mod16_graph_launch(second._graph.handle, stream) == _lib.ERR_ARG
+    torch.cuda.synchronize()
+    assert not ras.day.any()                                  # nothing ran
+    assert lib.mod16_graph_destroy(second._graph.handle) == _lib.OK
+    second._graph.handle = None
+    # a fresh context on the same raster: whole again
+    eng2 = RasterEngine(table)
+    eng2.run_tiled(ras, diag)
+    torch.cuda.synchronize()
+    eng2.check()
+    assert torch.equal(ras.flat(ras.day, 0, 1 << 16), want)

@@ -22,6 +22,7 @@ def test_host_half_of_the_library_is_clean_under_asan_and_ubsan(tmp_path):
     assert 'planted fault detected' in out, out[-2000:]
     # the shadows that carry the launch geometry ran, on both data types and on the big rasters
     assert 'et_stream_kernel' in out and 'et_stream_redo_kernel' in out and 'et_kernel' in out
+    assert 'graph lifetime: done' in out
     for what in ('tiled rasters, float64', 'tiled rasters, float32', 'plain device arrays, float64',
                  'HOST mode, float64', 'HOST mode, float32'):
         assert what in out, what
