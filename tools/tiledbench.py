@@ -2,7 +2,7 @@
 """Kernel time of the production pipeline on plain arrays (one slab, arrays 0.5 GiB
 apart) against tiled rasters of several tile sizes, same process, same field.
 
-  python tools/tiledbench.py [--rows 21600] [--dtype float64] [--math fast] [--tiles 4096,8192,16384]
+  python tools/tiledbench.py [--rows 21600] [--dtype float64] [--math fast] [--tiles 4096,8192,16384] [--experiments]
 """
 import argparse
 import json
@@ -27,10 +27,12 @@ def main():
     ap.add_argument('--launches', type=int, default=10)
     ap.add_argument('--rounds', type=int, default=3)
     ap.add_argument('--no-plain', action='store_true')
+    ap.add_argument('--experiments', action='store_true',
+                    help='the -DMOD16_EXPERIMENTS build: MOD16_RUN_SHIFT, MOD16_STATIC_BELOW, ... from the environment apply')
     args = ap.parse_args()
     table = bplut_table(restore_bplut(COLLECTION61_BPLUT), beta=250)
     math = {'mixed': _lib.MATH_MIXED}.get(args.math, _lib.MATH_FAST)
-    eng = RasterEngine(table, dtype=args.dtype, math=math)
+    eng = RasterEngine(table, dtype=args.dtype, math=math, experiments=args.experiments)
     n = args.rows * 43200
     bpp = eng.bytes_per_pixel
     diag = torch.zeros(8, dtype=torch.float64, device='cuda')
