@@ -265,3 +265,34 @@ def test_f5_reference_float32_run(env, math):
                     (math, name, what, mine, theirs)
             else:
                 assert all(a <= b for a, b in zip(mine, theirs)), (math, name, what, mine, theirs)
+
+
+def test_class_surface_takes_the_mixed_form_on_float32_tensors(env):
+    """``MOD16(params)`` with ``model.math = MATH_MIXED`` on float32 tensors resident on the GPU: the
+    class surface runs the mixed-precision pipeline instance (1.3x faster than the float64 arithmetic
+    on the same tensors) -- same NaN masks, the mixed form's accuracy; float64 tensors ignore the flag
+    (same bits as FAST)."""
+    torch, _lib, RasterEngine, table = env
+    import mod16_amd
+    n = 3 * 4096 * 1024 + 4 * 37          # dynamic schedule, ragged end
+    eng = RasterEngine(table, dtype='float32')
+    _, drv = eng.synth(n, seed=23)
+    params = dict(zip(mod16_amd.MOD16.required_parameters, (float(v) for v in table[7])))
+    fast, mixed = mod16_amd.MOD16(params), mod16_amd.MOD16(params)
+    mixed.math = _lib.MATH_MIXED
+    want = fast.evapotranspiration(*drv)
+    got = mixed.evapotranspiration(*drv)
+    torch.cuda.synchronize()
+    for g, w, what in zip(got, want, ('day', 'night')):
+        assert g.dtype == torch.float32 and g.shape == w.shape
+        assert torch.equal(torch.isnan(g), torch.isnan(w)), what
+        rel = torch.nan_to_num((g.double() - w.double()).abs() / w.double().abs(), nan=0.0, posinf=0.0)
+        assert float(rel.max()) < 1e-3, (what, float(rel.max()))
+        assert float(rel.median()) < 2e-7, (what, float(rel.median()))
+        assert not torch.equal(g, w), 'the flag did not reach the kernel'
+    drv64 = [d.double() for d in drv[:14]]
+    a = fast.evapotranspiration(*drv64)
+    b = mixed.evapotranspiration(*drv64)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x.view(torch.int64), y.view(torch.int64))
