@@ -902,6 +902,7 @@ def build_summary(line):
         'class_device_f32_frac': _dig(cfg, 'class_surface_device', 'one_pft_float32', 'frac'),
         'class_gather_f64_frac': _dig(cfg, 'class_surface_device', 'pft_gather_float64', 'frac'),
         'class_gather_f32_frac': _dig(cfg, 'class_surface_device', 'pft_gather_float32', 'frac'),
+        'class_device_f32_mixed_frac': _dig(cfg, 'class_surface_device', 'one_pft_mixed_float32', 'frac'),
         'c5_trusted_frac': c5.get('mixed_trusted_frac'),
         'c5_n_gt_1e-4': _dig(c5, 'mixed_vs_float64_arithmetic_full_grid', 'n_rel_err_gt_1e-4'),
         'c5_n_gt_1e-3': _dig(c5, 'mixed_vs_float64_arithmetic_full_grid', 'n_rel_err_gt_1e-3'),
@@ -1211,6 +1212,10 @@ def class_surface_config(torch, np, RasterEngine, table, n=10800 * 21600):
         tt = torch.from_numpy(table).cuda().to(drv[0].dtype)
         models['pft_gather'] = mod16_amd.MOD16({k: tt[:, j][cls.long()] for j, k in enumerate(names)})
         del tt
+        if dtype == 'float32':      # the opt-in mixed-precision form on the class surface (model.math)
+            from mod16_amd import _lib
+            models['one_pft_mixed'] = mod16_amd.MOD16(dict(zip(names, (float(v) for v in table[7]))))
+            models['one_pft_mixed'].math = _lib.MATH_MIXED
         for name, model in models.items():
             res = model.evapotranspiration(*drv)
             torch.cuda.synchronize()
